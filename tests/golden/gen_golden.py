@@ -1,0 +1,487 @@
+#!/usr/bin/env python3
+"""Regenerate ``tests/golden/*.npz`` by RUNNING the upstream reference on CPU.
+
+BUILD-CONTAINER ONLY (needs ``/root/reference``).  Each fixture stores seeded inputs
+and the outputs produced by the reference's own code:
+
+  * ``forward_native`` of RMSNorm / SiluAndMul / RotaryEmbedding / Llama3RotaryEmbedding
+    (scratchpad/nn/layers/{layernorm,activation,rotary_embedding}.py),
+  * ``MHATokenToKVPool.set_kv_buffer``, ``ReqToTokenPool``, ``TokenToKVPoolAllocator``
+    (scratchpad/memory/pool.py),
+  * ``compute_position_triton/torch`` (scratchpad/model_executor/forward_info.py),
+  * ``write_req_to_token_pool_triton`` (scratchpad/scheduler/schedule_batch.py),
+  * the in-tree Triton kernels ``decode_attention_fwd`` / ``extend_attention_fwd``
+    (scratchpad/nn/attention/triton_attn/) executed by the Triton interpreter,
+  * the full reference ``LlamaForCausalLM`` (2 layers, tiny) for prefill + decode logits.
+
+The fixtures are data only (inputs and expected outputs); nothing of the reference's
+source text is stored.  Usage:  python tests/golden/gen_golden.py [name ...]
+"""
+import math
+import os
+import sys
+
+os.environ["TRITON_INTERPRET"] = "1"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_loader  # noqa: E402
+
+_ref_loader.install()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def _np(t):
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().numpy()
+    return np.asarray(t)
+
+
+def _grid(t, step=64.0, lim=255.0):
+    """Round to multiples of 1/64 with |k| <= 255: exactly representable in bf16, fp16 and fp32,
+    so the SAME fixture inputs can be fed to the HIP kernels in any dtype without input rounding."""
+    return torch.clamp(torch.round(t * step), -lim, lim) / step
+
+
+def _randn(*shape, generator, scale=1.0):
+    return _grid(torch.randn(*shape, generator=generator) * scale)
+
+
+def _save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    packed = {}
+    for k, v in arrays.items():
+        a = _np(v)
+        # grid inputs are exact in fp16: store them as fp16 (tests/golden/__init__.py widens them back)
+        if a.dtype == np.float32 and a.size > 64 and np.array_equal(a.astype(np.float16).astype(np.float32), a):
+            a = a.astype(np.float16)
+        packed[k] = a
+    np.savez_compressed(path, **packed)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays")
+
+
+def gen_rmsnorm():
+    from scratchpad.nn.layers.layernorm import RMSNorm
+
+    g = torch.Generator().manual_seed(101)
+    out = {}
+    for i, (T, H, eps) in enumerate([(5, 64, 1e-5), (3, 256, 1e-6), (1, 4096, 1e-5), (7, 96, 1e-5)]):
+        m = RMSNorm(H, eps)
+        m.weight.data = _grid(torch.randn(H, generator=g) * 0.5 + 1.0)
+        x = _randn(T, H, generator=g, scale=1.5)
+        r = _randn(T, H, generator=g)
+        y = m.forward_native(x.clone())
+        y2, r2 = m.forward_native(x.clone(), r.clone())
+        out.update({f"c{i}_x": x, f"c{i}_w": m.weight.data, f"c{i}_eps": np.float64(eps),
+                    f"c{i}_res": r, f"c{i}_y": y, f"c{i}_y_fused": y2, f"c{i}_res_out": r2})
+    out["num_cases"] = np.int64(4)
+    _save("rmsnorm", **out)
+
+
+def gen_silu_mul():
+    from scratchpad.nn.layers.activation import SiluAndMul
+
+    g = torch.Generator().manual_seed(102)
+    m = SiluAndMul()
+    out = {}
+    for i, (T, d) in enumerate([(4, 32), (3, 176), (1, 1024)]):
+        x = _randn(T, 2 * d, generator=g, scale=2.0)
+        out[f"c{i}_x"] = x
+        out[f"c{i}_y"] = m.forward_native(x)
+    out["num_cases"] = np.int64(3)
+    _save("silu_mul", **out)
+
+
+def gen_rotary():
+    from scratchpad.nn.layers.rotary_embedding import get_rope
+
+    g = torch.Generator().manual_seed(103)
+    out = {}
+    llama3 = {"rope_type": "llama3", "factor": 32.0, "low_freq_factor": 1.0,
+              "high_freq_factor": 4.0, "original_max_position_embeddings": 8192}
+    cases = [
+        # head, rot_dim, max_pos, base, neox, scaling, Hq, Hkv, T
+        (64, 64, 256, 10000, True, None, 4, 2, 9),
+        (128, 128, 192, 500000, True, None, 8, 2, 6),
+        (64, 64, 384, 500000, True, llama3, 8, 2, 7),
+        (128, 128, 320, 500000, True, dict(llama3, factor=8.0), 4, 1, 5),
+        (64, 64, 128, 10000, False, None, 4, 4, 5),      # GPT-J interleaved style
+        (64, 32, 128, 10000, True, None, 4, 2, 5),       # partial rotary
+    ]
+    for i, (hs, rd, mp, base, neox, sc, Hq, Hkv, T) in enumerate(cases):
+        rope = get_rope(hs, rd, mp, base, neox, sc, dtype=torch.float32)
+        pos = torch.randint(0, mp, (T,), generator=g, dtype=torch.int64)
+        pos[0] = 0
+        pos[-1] = mp - 1
+        q = _randn(T, Hq * hs, generator=g)
+        k = _randn(T, Hkv * hs, generator=g)
+        q2, k2 = rope.forward_native(pos, q.clone(), k.clone())
+        out.update({
+            f"c{i}_head_size": np.int64(hs), f"c{i}_rotary_dim": np.int64(rd),
+            f"c{i}_max_pos": np.int64(mp), f"c{i}_base": np.float64(base),
+            f"c{i}_neox": np.int64(neox), f"c{i}_positions": pos, f"c{i}_q": q, f"c{i}_k": k,
+            f"c{i}_q_out": q2, f"c{i}_k_out": k2,
+            # the whole cache pins _compute_inv_freq/_compute_cos_sin_cache (incl. llama3)
+            f"c{i}_cos_sin_cache": rope.cos_sin_cache,
+        })
+        if sc is not None:
+            out[f"c{i}_scaling"] = np.array([sc["factor"], sc["low_freq_factor"],
+                                             sc["high_freq_factor"],
+                                             sc["original_max_position_embeddings"]], np.float64)
+    out["num_cases"] = np.int64(len(cases))
+    _save("rotary", **out)
+
+
+def gen_kv_pool():
+    from types import SimpleNamespace
+    from scratchpad.memory.pool import (MHATokenToKVPool, ReqToTokenPool,
+                                        TokenToKVPoolAllocator)
+
+    g = torch.Generator().manual_seed(104)
+    size, Hkv, D, L = 40, 2, 16, 3
+    pool = MHATokenToKVPool(size, 1, torch.float32, Hkv, D, L, "cpu", False)
+    out = {"size": np.int64(size), "head_num": np.int64(Hkv), "head_dim": np.int64(D),
+           "layer_num": np.int64(L)}
+    for layer in range(L):
+        T = 6 + layer
+        loc = torch.randperm(size, generator=g)[:T] + 1
+        if layer == 2:
+            loc[0] = 0  # padded rows write the reserved dummy slot 0
+        k = _randn(T, Hkv, D, generator=g)
+        v = _randn(T, Hkv, D, generator=g)
+        pool.set_kv_buffer(SimpleNamespace(layer_id=layer), loc, k, v)
+        out.update({f"l{layer}_loc": loc, f"l{layer}_k": k, f"l{layer}_v": v})
+    for layer in range(L):
+        out[f"l{layer}_k_buffer"] = pool.get_key_buffer(layer)
+        out[f"l{layer}_v_buffer"] = pool.get_value_buffer(layer)
+
+    # allocator trace: alloc / free / free_group / backup-restore, recorded as int arrays
+    alloc = TokenToKVPoolAllocator(16, torch.float32, "cpu", pool)
+    a0 = alloc.alloc(5)
+    a1 = alloc.alloc(4)
+    avail0 = alloc.available_size()
+    alloc.free(a0[1:3])
+    a2 = alloc.alloc(8)
+    too_many = alloc.alloc(100)
+    state = alloc.backup_state()
+    a3 = alloc.alloc(1)
+    alloc.restore_state(state)
+    a4 = alloc.alloc(1)
+    alloc.free_group_begin()
+    alloc.free(a1[:2])
+    alloc.free(a2[:3])
+    avail_in_group = alloc.available_size()
+    alloc.free_group_end()
+    out.update({"alloc_a0": a0, "alloc_a1": a1, "alloc_avail0": np.int64(avail0),
+                "alloc_a2": a2, "alloc_too_many_is_none": np.int64(too_many is None),
+                "alloc_a3": a3, "alloc_a4": a4,
+                "alloc_avail_in_group": np.int64(avail_in_group),
+                "alloc_free_final": alloc.free_slots})
+    alloc.clear()
+    out["alloc_free_after_clear"] = alloc.free_slots
+
+    r2t = ReqToTokenPool(5, 12, "cpu", False)
+    r0 = r2t.alloc(2)
+    r1 = r2t.alloc(2)
+    r2t.free(r0[0])
+    r2 = r2t.alloc(2)
+    none = r2t.alloc(3)
+    r2t.write((torch.tensor([1, 3]), torch.tensor([4, 7])), torch.tensor([11, 13], dtype=torch.int32))
+    r2t.write((2, slice(0, 3)), torch.tensor([5, 6, 7], dtype=torch.int32))
+    out.update({"r2t_r0": r0, "r2t_r1": r1, "r2t_r2": r2, "r2t_none": np.int64(none is None),
+                "r2t_table": r2t.req_to_token, "r2t_avail": np.int64(r2t.available_size())})
+    _save("kv_pool", **out)
+
+
+def gen_positions():
+    from scratchpad.model_executor.forward_info import (compute_position_torch,
+                                                        compute_position_triton)
+    from scratchpad.scheduler.schedule_batch import write_req_to_token_pool_triton
+
+    g = torch.Generator().manual_seed(105)
+    out = {}
+    prefix = torch.tensor([0, 3, 17, 0, 600], dtype=torch.int32)
+    ext = torch.tensor([5, 1, 9, 1, 530], dtype=torch.int32)
+    pos_t, start_t = compute_position_triton(prefix, ext, int(ext.sum()))
+    pos_p, start_p = compute_position_torch(prefix, ext)
+    assert torch.equal(pos_t, pos_p) and torch.equal(start_t, start_p)
+    out.update({"prefix_lens": prefix, "extend_lens": ext, "positions": pos_t,
+                "extend_start_loc": start_t})
+    # decode positions: clamp(seq_lens - 1, min=0)  (forward_info.py clamp_position)
+    seq = torch.tensor([1, 0, 7, 4096], dtype=torch.int64)
+    out.update({"decode_seq_lens": seq, "decode_positions": torch.clamp(seq - 1, min=0).to(torch.int64)})
+
+    # write_req_to_token_pool_triton
+    bs, ctx = 5, 1200
+    table = torch.zeros(8, ctx, dtype=torch.int32)
+    req_idx = torch.tensor([6, 0, 3, 7, 2], dtype=torch.int64)
+    seq_lens = (prefix + ext).to(torch.int64)
+    total = int(ext.sum())
+    out_loc = (torch.randperm(5000, generator=g)[:total] + 1).to(torch.int64)
+    # cached-prefix slots are copied by the scheduler before the kernel runs
+    pre_slots = []
+    for i in range(bs):
+        p = (torch.randperm(5000, generator=g)[: int(prefix[i])] + 6000).to(torch.int32)
+        table[req_idx[i], : int(prefix[i])] = p
+        pre_slots.append(p)
+    table_in = table.clone()
+    write_req_to_token_pool_triton[(bs,)](table, req_idx, prefix.to(torch.int64), seq_lens,
+                                          ext.to(torch.int64), out_loc, ctx)
+    out.update({"w_table_in": table_in, "w_req_pool_indices": req_idx, "w_pre_lens": prefix.to(torch.int64),
+                "w_seq_lens": seq_lens, "w_extend_lens": ext.to(torch.int64),
+                "w_out_cache_loc": out_loc, "w_table_out": table})
+    _save("positions", **out)
+
+
+def _paged_setup(g, bs, seq_lens, Hkv, D, pool_slots, n_req_rows, ctx):
+    """random KV pool + req_to_token rows with a random slot permutation"""
+    k_buf = _randn(pool_slots + 1, Hkv, D, generator=g)
+    v_buf = _randn(pool_slots + 1, Hkv, D, generator=g)
+    r2t = torch.zeros(n_req_rows, ctx, dtype=torch.int32)
+    req_idx = torch.randperm(n_req_rows, generator=g)[:bs].to(torch.int64)
+    perm = torch.randperm(pool_slots, generator=g) + 1
+    off = 0
+    for b in range(bs):
+        L = int(seq_lens[b])
+        r2t[req_idx[b], :L] = perm[off: off + L].to(torch.int32)
+        off += L
+    return k_buf, v_buf, r2t, req_idx
+
+
+def gen_decode():
+    from scratchpad.nn.attention.triton_attn.decode_attention import decode_attention_fwd
+
+    g = torch.Generator().manual_seed(106)
+    out = {}
+    cases = [
+        # bs, Hq, Hkv, D, seq_lens, logit_cap
+        (4, 8, 2, 64, [1, 37, 64, 130], 0.0),      # GQA group 4, D=64 (Llama-3.2-1B head shape)
+        (3, 8, 2, 128, [5, 129, 70], 0.0),         # GQA group 4, D=128 (Llama-3-8B head shape)
+        (3, 8, 1, 128, [3, 65, 200], 0.0),         # group 8 (Llama-3-70B TP=8 rank shape)
+        (3, 4, 4, 64, [2, 33, 90], 0.0),           # MHA path (group 1)
+        (2, 8, 2, 64, [40, 77], 30.0),             # logit soft-cap
+    ]
+    for i, (bs, Hq, Hkv, D, lens, cap) in enumerate(cases):
+        seq = torch.tensor(lens, dtype=torch.int64)
+        total = int(seq.sum())
+        k_buf, v_buf, r2t, req_idx = _paged_setup(g, bs, seq, Hkv, D, total + 9, bs + 3, max(lens) + 4)
+        q = _randn(bs, Hq, D, generator=g)
+        o = torch.zeros(bs, Hq, D)
+        start = torch.zeros(bs, dtype=torch.int64)
+        start[1:] = torch.cumsum(seq[:-1], 0)
+        logits = torch.empty(Hq, total)
+        scale = 1.0 / math.sqrt(D)
+        decode_attention_fwd(q, k_buf, v_buf, o, r2t, req_idx, start, seq, logits,
+                             int(seq.max()), scale, cap)
+        out.update({f"c{i}_q": q, f"c{i}_k_buffer": k_buf, f"c{i}_v_buffer": v_buf,
+                    f"c{i}_req_to_token": r2t, f"c{i}_req_pool_indices": req_idx,
+                    f"c{i}_seq_lens": seq, f"c{i}_sm_scale": np.float64(scale),
+                    f"c{i}_logit_cap": np.float64(cap), f"c{i}_o": o})
+    out["num_cases"] = np.int64(len(cases))
+    _save("decode_attention", **out)
+
+
+def gen_extend():
+    from scratchpad.nn.attention.triton_attn.extend_attention import extend_attention_fwd
+
+    g = torch.Generator().manual_seed(107)
+    out = {}
+    cases = [
+        # Hq, Hkv, D, prefix_lens, extend_lens, logit_cap
+        (8, 2, 64, [0, 0, 0], [5, 70, 131], 0.0),          # pure prefill, ragged
+        (8, 2, 128, [17, 0, 64], [9, 33, 1], 0.0),         # cached prefix + MIXED-like row (extend_len 1)
+        (8, 1, 128, [130, 3], [66, 140], 0.0),             # group 8, prefix longer than a tile
+        (4, 4, 64, [10, 0], [20, 45], 0.0),                # MHA
+        (8, 2, 64, [12, 0], [30, 50], 30.0),               # soft-cap
+    ]
+    for i, (Hq, Hkv, D, pre, ext, cap) in enumerate(cases):
+        bs = len(pre)
+        pre_t = torch.tensor(pre, dtype=torch.int32)
+        ext_t = torch.tensor(ext, dtype=torch.int32)
+        seq = (pre_t + ext_t).to(torch.int64)
+        total = int(seq.sum())
+        k_buf, v_buf, r2t, req_idx = _paged_setup(g, bs, seq, Hkv, D, total + 5, bs + 2, int(seq.max()) + 4)
+        T = int(ext_t.sum())
+        q = _randn(T, Hq, D, generator=g)
+        k_ext = torch.empty(T, Hkv, D)
+        v_ext = torch.empty(T, Hkv, D)
+        start = torch.zeros(bs, dtype=torch.int32)
+        start[1:] = torch.cumsum(ext_t[:-1], 0)
+        # the new tokens' K/V are ALSO in the pool already (KV store precedes the kernel:
+        # triton_backend.py forward_extend); k_extend/v_extend are the contiguous copies.
+        out_loc = torch.empty(T, dtype=torch.int64)
+        for b in range(bs):
+            s, p, e = int(start[b]), pre[b], ext[b]
+            slots = r2t[req_idx[b], p: p + e].to(torch.int64)
+            out_loc[s: s + e] = slots
+            k_ext[s: s + e] = k_buf[slots]
+            v_ext[s: s + e] = v_buf[slots]
+        o = torch.zeros(T, Hq, D)
+        scale = 1.0 / math.sqrt(D)
+        extend_attention_fwd(q, k_ext, v_ext, o, k_buf, v_buf, r2t, req_idx, seq, ext_t, start,
+                             int(ext_t.max()), scale, cap)
+        out.update({f"c{i}_q": q,  # k_extend/v_extend == k/v_buffer[out_cache_loc]; not stored
+                    f"c{i}_k_buffer": k_buf, f"c{i}_v_buffer": v_buf, f"c{i}_req_to_token": r2t,
+                    f"c{i}_req_pool_indices": req_idx, f"c{i}_seq_lens": seq,
+                    f"c{i}_extend_seq_lens": ext_t, f"c{i}_extend_prefix_lens": pre_t,
+                    f"c{i}_extend_start_loc": start, f"c{i}_out_cache_loc": out_loc,
+                    f"c{i}_sm_scale": np.float64(scale), f"c{i}_logit_cap": np.float64(cap),
+                    f"c{i}_o": o})
+    out["num_cases"] = np.int64(len(cases))
+    _save("extend_attention", **out)
+
+
+def gen_tiny_llama():
+    """Full reference LlamaForCausalLM (2 layers) on CPU: ragged prefill then one decode step."""
+    import transformers
+    import scratchpad.nn.models.llama.llama as L
+    from scratchpad.distributed import init_distributed_environment, initialize_model_parallel
+    from scratchpad.memory.pool import MHATokenToKVPool, ReqToTokenPool
+    from scratchpad.model_executor.cuda_graph_runner import _to_torch
+    from scratchpad.model_executor.forward_info import (CaptureHiddenMode, ForwardBatch,
+                                                        ForwardMode, compute_position_torch)
+    from scratchpad.nn.attention.backend import AttentionBackend
+    from scratchpad.nn.attention.triton_attn.decode_attention import decode_attention_fwd
+    from scratchpad.nn.attention.triton_attn.extend_attention import extend_attention_fwd
+
+    init_distributed_environment(world_size=1, rank=0, distributed_init_method="tcp://127.0.0.1:29517",
+                                 local_rank=0, backend="gloo")
+    initialize_model_parallel(1)
+
+    out = {}
+    variants = [
+        # name, hidden, inter, layers, Hq, Hkv, vocab, theta, scaling, tie
+        ("a", 256, 256, 2, 4, 1, 256, 500000.0, None, True),     # D=64, group 4, tied head
+        ("b", 256, 320, 2, 2, 2, 192, 500000.0,                    # D=128, MHA, llama3 rope, untied
+         {"rope_type": "llama3", "factor": 32.0, "low_freq_factor": 1.0,
+          "high_freq_factor": 4.0, "original_max_position_embeddings": 64}, False),
+    ]
+    for name, hidden, inter, nl, Hq, Hkv, vocab, theta, scaling, tie in variants:
+        torch.manual_seed(108)
+        cfg = transformers.LlamaConfig(
+            vocab_size=vocab, hidden_size=hidden, intermediate_size=inter, num_hidden_layers=nl,
+            num_attention_heads=Hq, num_key_value_heads=Hkv, max_position_embeddings=128,
+            rms_norm_eps=1e-5, tie_word_embeddings=tie)
+        # transformers>=5 keeps RoPE params only in cfg.rope_parameters; the reference reads attributes
+        cfg.rope_theta = theta
+        cfg.rope_scaling = scaling
+        D = hidden // Hq
+        model = L.LlamaForCausalLM(cfg).eval()
+        for pname, p in model.named_parameters():
+            if "norm" in pname:
+                p.data = _grid(1.0 + 0.1 * torch.randn_like(p))
+            else:
+                # multiples of 1/1024, |k| <= 255: exact in bf16/fp16 (std 0.05)
+                p.data = _grid(torch.randn_like(p) * 0.05, step=1024.0, lim=255.0)
+        _to_torch(model, reverse=False, num_tokens=2)  # CustomOp -> forward_native
+        kv = MHATokenToKVPool(96, 1, torch.float32, Hkv, D, nl, "cpu", False)
+        r2t = ReqToTokenPool(4, 64, "cpu", False)
+
+        class Probe(AttentionBackend):
+            def init_forward_metadata(self, fb):
+                pass
+
+            def forward_extend(self, q, k, v, layer, fb, save_kv_cache=True):
+                o = torch.empty_like(q)
+                fb.token_to_kv_pool.set_kv_buffer(layer, fb.out_cache_loc, k, v)
+                extend_attention_fwd(
+                    q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), k.contiguous(), v.contiguous(),
+                    o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
+                    *fb.token_to_kv_pool.get_kv_buffer(layer.layer_id),
+                    fb.req_to_token_pool.req_to_token, fb.req_pool_indices, fb.seq_lens,
+                    fb.extend_seq_lens, fb.extend_start_loc, int(fb.extend_seq_lens.max()),
+                    layer.scaling, layer.logit_cap)
+                return o
+
+            def forward_decode(self, q, k, v, layer, fb, save_kv_cache=True):
+                q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
+                o = torch.empty_like(q)
+                fb.token_to_kv_pool.set_kv_buffer(layer, fb.out_cache_loc, k, v)
+                start = torch.zeros_like(fb.seq_lens)
+                start[1:] = torch.cumsum(fb.seq_lens[:-1], 0)
+                logits = torch.empty(layer.tp_q_head_num, int(fb.seq_lens.sum()))
+                decode_attention_fwd(
+                    q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
+                    *fb.token_to_kv_pool.get_kv_buffer(layer.layer_id),
+                    o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
+                    fb.req_to_token_pool.req_to_token, fb.req_pool_indices, start, fb.seq_lens,
+                    logits, int(fb.seq_lens.max()), layer.scaling, layer.logit_cap)
+                return o
+
+        backend = Probe()
+        g = torch.Generator().manual_seed(109)
+        ext = [5, 9, 1]
+        bs = len(ext)
+        ids = torch.randint(0, vocab, (sum(ext),), generator=g)
+        req_idx = torch.tensor([2, 0, 3], dtype=torch.int64)
+        slots = (torch.randperm(90, generator=g) + 1).to(torch.int64)
+        out_loc = slots[: sum(ext)]
+        off = 0
+        for b in range(bs):
+            r2t.req_to_token[req_idx[b], : ext[b]] = out_loc[off: off + ext[b]].to(torch.int32)
+            off += ext[b]
+        pre_t = torch.zeros(bs, dtype=torch.int32)
+        ext_t = torch.tensor(ext, dtype=torch.int32)
+        positions, start_loc = compute_position_torch(pre_t, ext_t)
+        seq = torch.tensor(ext, dtype=torch.int64)
+        fb = ForwardBatch(
+            forward_mode=ForwardMode.EXTEND, batch_size=bs, input_ids=ids, req_pool_indices=req_idx,
+            seq_lens=seq, out_cache_loc=out_loc, seq_lens_sum=int(seq.sum()), positions=positions,
+            extend_num_tokens=sum(ext), extend_seq_lens=ext_t, extend_prefix_lens=pre_t,
+            extend_start_loc=start_loc, extend_prefix_lens_cpu=[0] * bs, extend_seq_lens_cpu=ext,
+            req_to_token_pool=r2t, token_to_kv_pool=kv, attn_backend=backend,
+            capture_hidden_mode=CaptureHiddenMode.NULL)
+        res = model.forward(ids, positions, fb)
+        prefill_logits = res.next_token_logits.clone()
+        next_ids = torch.argmax(prefill_logits, dim=-1)
+
+        # decode step (ScheduleBatch.prepare_for_decode: seq_lens += 1, alloc, write req_to_token)
+        dec_loc = slots[sum(ext): sum(ext) + bs]
+        seq2 = seq + 1
+        for b in range(bs):
+            r2t.req_to_token[req_idx[b], int(seq[b])] = int(dec_loc[b])
+        fb2 = ForwardBatch(
+            forward_mode=ForwardMode.DECODE, batch_size=bs, input_ids=next_ids, req_pool_indices=req_idx,
+            seq_lens=seq2, out_cache_loc=dec_loc, seq_lens_sum=int(seq2.sum()),
+            positions=torch.clamp(seq2 - 1, min=0).to(torch.int64),
+            req_to_token_pool=r2t, token_to_kv_pool=kv, attn_backend=backend,
+            capture_hidden_mode=CaptureHiddenMode.NULL)
+        res2 = model.forward(next_ids, fb2.positions, fb2)
+        decode_logits = res2.next_token_logits.clone()
+
+        # a second extend with a cached prefix: re-run request 1's last 4 tokens on top of its first 5
+        sd = {k: v for k, v in model.state_dict().items()}
+        pfx = f"{name}_"
+        out.update({pfx + "w::" + k: v for k, v in sd.items()})
+        out.update({
+            pfx + "cfg": np.array([hidden, inter, nl, Hq, Hkv, vocab, int(tie)], np.int64),
+            pfx + "rope_theta": np.float64(theta), pfx + "rms_eps": np.float64(1e-5),
+            pfx + "max_pos": np.int64(128),
+            pfx + "input_ids": ids, pfx + "extend_lens": ext_t, pfx + "req_pool_indices": req_idx,
+            pfx + "out_cache_loc": out_loc, pfx + "positions": positions,
+            pfx + "prefill_logits": prefill_logits, pfx + "next_ids": next_ids,
+            pfx + "decode_out_cache_loc": dec_loc, pfx + "decode_logits": decode_logits,
+            pfx + "k_buffer0_after": kv.get_key_buffer(0), pfx + "v_buffer1_after": kv.get_value_buffer(1),
+        })
+        if scaling is not None:
+            out[pfx + "rope_scaling"] = np.array(
+                [scaling["factor"], scaling["low_freq_factor"], scaling["high_freq_factor"],
+                 scaling["original_max_position_embeddings"]], np.float64)
+        from scratchpad.nn.layers import rotary_embedding as _re
+        _re._ROPE_DICT.clear()
+    _save("tiny_llama", **out)
+
+
+GENERATORS = {
+    "rmsnorm": gen_rmsnorm, "silu_mul": gen_silu_mul, "rotary": gen_rotary, "kv_pool": gen_kv_pool,
+    "positions": gen_positions, "decode_attention": gen_decode, "extend_attention": gen_extend,
+    "tiny_llama": gen_tiny_llama,
+}
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(GENERATORS)
+    for n in names:
+        GENERATORS[n]()
