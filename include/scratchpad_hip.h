@@ -1,0 +1,148 @@
+/*
+ * scratchpad_hip.h - C ABI of the MI355X (gfx950) hot-path library `libscratchpad_hip.so`.
+ *
+ * This is the drop-in boundary beneath Scratchpad's four Python seams.
+ * The reference exports no C ABI itself - it calls third-party wheels (flashinfer v0.2.3,
+ * triteia / triteia_cuda) - so every entry point below cites the reference call site it
+ * replaces (paths relative to /root/reference/scratchpad).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every buffer (inputs, outputs, workspaces, the KV pool) is
+ *    allocated and owned by the caller (torch on the Python side); the library allocates nothing
+ *    and keeps no state;
+ *  - every function enqueues on `stream` (a hipStream_t passed as void*) and returns without
+ *    synchronising; all are HIP-graph capturable (no host sync, no malloc, launch geometry
+ *    depends only on host-visible arguments, never on device-side seq_lens values);
+ *  - return 0 on success, a negative sp_status otherwise; nothing throws;
+ *  - `dtype`: SP_F32 / SP_F16 / SP_BF16 - the activation & KV-pool element type;
+ *  - strides are in ELEMENTS; innermost dimensions are contiguous;
+ *  - `idx64`: 1 if req_pool_indices / seq_lens are int64 (eager mode), 0 if int32 (graph mode),
+ *    as in ForwardBatch (model_executor/forward_info.py:84-104, cuda_graph_runner.py:193-199);
+ *  - KV slot 0 is the reserved dummy slot (memory/pool.py:126-127, 249-253): padded rows carry
+ *    out_cache_loc == 0 and seq_len == fill value and are harmless.
+ */
+#ifndef SCRATCHPAD_HIP_H
+#define SCRATCHPAD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP_ABI_VERSION 1
+#define SP_API __attribute__((visibility("default")))
+
+typedef enum { SP_F32 = 0, SP_F16 = 1, SP_BF16 = 2 } sp_dtype;
+
+typedef enum {
+  SP_OK = 0,
+  SP_ERR_INVALID_ARG = -1, /* null pointer, negative size, misaligned buffer */
+  SP_ERR_UNSUPPORTED = -2, /* head_dim / group size / dtype combination not built */
+  SP_ERR_WORKSPACE = -3,   /* workspace too small */
+  SP_ERR_LAUNCH = -4       /* hipLaunchKernel failed (see hipGetLastError) */
+} sp_status;
+
+SP_API int sp_abi_version(void);
+SP_API const char* sp_status_string(int status);
+
+/* ---- RMSNorm: replaces flashinfer.norm.rmsnorm / fused_add_rmsnorm
+ *      (nn/layers/layernorm.py:22-32; semantics of forward_native 34-51).
+ * sp_rmsnorm:           out[t,:] = round(x[t,:] * rsqrt(mean(x^2)+eps)) * weight
+ * sp_fused_add_rmsnorm: residual[t,:] = round(x + residual) (in place), then
+ *                       x[t,:] = round(fp32(x+residual) * rsqrt(..)) * weight   (in place)       */
+SP_API int sp_rmsnorm(void* out, const void* x, const void* weight, int64_t num_tokens, int hidden,
+               int64_t x_stride, int64_t out_stride, float eps, int dtype, void* stream);
+SP_API int sp_fused_add_rmsnorm(void* x, void* residual, const void* weight, int64_t num_tokens,
+                         int hidden, int64_t x_stride, int64_t res_stride, float eps, int dtype,
+                         void* stream);
+
+/* ---- SiLU-and-mul: replaces flashinfer.activation.silu_and_mul (nn/layers/activation.py:26-31).
+ * out[t, j] = silu(x[t, j]) * x[t, d + j],  x: [T, 2d]                                           */
+SP_API int sp_silu_and_mul(void* out, const void* x, int64_t num_tokens, int d, int64_t x_stride,
+                    int64_t out_stride, int dtype, void* stream);
+
+/* ---- Rotary embedding, in place on q and k: replaces triteia_cuda.rotary_embedding
+ *      (nn/layers/rotary_embedding.py:132-164; semantics of forward_native 102-130).
+ * cos_sin_cache: [max_position, rotary_dim] = cos || sin, in `dtype`; positions int64 [T].
+ * q: [T, Hq*head_size], k: [T, Hkv*head_size].  is_neox: 1 = halves, 0 = GPT-J interleaved.
+ * If k_buffer/v_buffer are non-null the rotated k rows and the v rows are ALSO scattered to
+ * the KV pool at out_cache_loc (fused KV store, = sp_kv_store below); pass NULL to skip.        */
+SP_API int sp_rotary_embedding(const int64_t* positions, void* q, void* k, const void* cos_sin_cache,
+                        int64_t num_tokens, int num_q_heads, int num_kv_heads, int head_size,
+                        int rotary_dim, int64_t q_stride, int64_t k_stride, int is_neox,
+                        const void* v, int64_t v_stride, void* k_buffer, void* v_buffer,
+                        const int64_t* out_cache_loc, int64_t kv_buffer_stride, int dtype,
+                        void* stream);
+
+/* ---- KV store: replaces `k_buffer[layer][loc] = cache_k` (MHATokenToKVPool.set_kv_buffer,
+ *      memory/pool.py:392-424).  k,v: [T, Hkv, D] (token stride given); buffers [P+1, Hkv, D].  */
+SP_API int sp_kv_store(void* k_buffer, void* v_buffer, const int64_t* loc, const void* k, const void* v,
+                int64_t num_tokens, int num_kv_heads, int head_dim, int v_head_dim,
+                int64_t k_stride, int64_t v_stride, int64_t k_buffer_stride,
+                int64_t v_buffer_stride, int dtype, void* stream);
+
+/* ---- req_to_token scatter: replaces write_req_to_token_pool_triton
+ *      (scheduler/schedule_batch.py:1546-1580).  All index arrays int64, table int32.           */
+SP_API int sp_write_req_to_token(int32_t* req_to_token, int64_t row_stride,
+                          const int64_t* req_pool_indices, const int64_t* pre_lens,
+                          const int64_t* seq_lens, const int64_t* extend_lens,
+                          const int64_t* out_cache_loc, int batch_size, void* stream);
+
+/* ---- positions: replaces compute_position_triton (model_executor/forward_info.py:400-449)
+ *      and clamp_position (469-471).                                                             */
+SP_API int sp_compute_position(int64_t* positions, int32_t* extend_start_loc,
+                        const int32_t* extend_prefix_lens, const int32_t* extend_seq_lens,
+                        int batch_size, void* stream);
+SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64, int batch_size,
+                      void* stream);
+
+/* ---- Paged decode attention: replaces decode_attention_fwd (nn/attention/triton_attn/
+ *      decode_attention.py:547-608; call site triton_backend.py:183-195) and flashinfer
+ *      BatchDecodeWithPagedKVCacheWrapper.forward (flashinfer_backend.py:475-482).
+ * For request b and q head h:  o = softmax(q.K[idx]^T * sm_scale [soft-capped]) . V[idx],
+ *   idx = req_to_token[req_pool_indices[b], kv_start[b] : kv_start[b] + seq_lens[b]]
+ * q,o: [bs, Hq, D]; buffers [P+1, Hkv, D] with token stride kv_buffer_stride; page_size = 1.
+ * kv_start may be NULL (= 0); it is the encoder offset of encoder-decoder models
+ * (flashinfer_backend.py:593-621).  `chunk` tokens per split and `max_seq_len` (an upper bound
+ * on every seq_lens[b], e.g. the context length under graph capture) fix the launch geometry:
+ * num_splits = ceil(max_seq_len / chunk).  workspace: sp_decode_attention_workspace_bytes().     */
+SP_API size_t sp_decode_attention_workspace_bytes(int batch_size, int num_q_heads, int v_head_dim,
+                                           int64_t max_seq_len, int chunk);
+SP_API int sp_decode_attention(void* out, const void* q, const void* k_buffer, const void* v_buffer,
+                        const int32_t* req_to_token, int64_t req_to_token_stride,
+                        const void* req_pool_indices, const void* seq_lens, const void* kv_start,
+                        int idx64, int batch_size, int num_q_heads, int num_kv_heads,
+                        int head_dim, int64_t q_stride, int64_t out_stride,
+                        int64_t kv_buffer_stride, float sm_scale, float logit_cap,
+                        int64_t max_seq_len, int chunk, void* workspace, size_t workspace_bytes,
+                        int dtype, void* stream);
+
+/* ---- Ragged extend (prefill) attention: replaces extend_attention_fwd (nn/attention/
+ *      triton_attn/extend_attention.py:229-327; call site triton_backend.py:137-154) and the
+ *      flashinfer ragged+paged+merge_state / paged-only paths (flashinfer_backend.py:400-444).
+ * New token t (0-based) of request b attends to kv positions [0, prefix_b + t] of
+ * req_to_token[req_pool_indices[b], kv_start[b] + ...]; the new tokens' K/V must already be in
+ * the pool (KV store precedes the kernel, triton_backend.py:131-134).  causal = 0 gives the
+ * cross-attention form: every row attends to all seq_lens[b] kv positions
+ * (flashinfer_backend.py:408-417).  q,o: [T, Hq, D]; extend_* are int32 [bs].
+ * num_tokens = sum(extend_seq_lens) (host-known: ForwardBatch.extend_num_tokens) and
+ * max_extend_len >= max(extend_seq_lens), max_seq_len >= max(seq_lens) fix the launch geometry.
+ * workspace: sp_extend_attention_workspace_bytes().                                              */
+SP_API size_t sp_extend_attention_workspace_bytes(int64_t num_tokens, int batch_size, int num_q_heads,
+                                           int head_dim, int dtype);
+SP_API int sp_extend_attention(void* out, const void* q, const void* k_buffer, const void* v_buffer,
+                        const int32_t* req_to_token, int64_t req_to_token_stride,
+                        const void* req_pool_indices, const void* seq_lens, const void* kv_start,
+                        int idx64, const int32_t* extend_seq_lens,
+                        const int32_t* extend_start_loc, int batch_size, int64_t num_tokens,
+                        int num_q_heads, int num_kv_heads, int head_dim, int64_t q_stride,
+                        int64_t out_stride, int64_t kv_buffer_stride, float sm_scale,
+                        float logit_cap, int causal, int max_extend_len, int64_t max_seq_len,
+                        void* workspace, size_t workspace_bytes, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCRATCHPAD_HIP_H */

@@ -1,0 +1,305 @@
+"""ctypes binding of ``libscratchpad_hip.so`` (C ABI: ``include/scratchpad_hip.h``).
+
+There is no fallback: if the library is missing or a call fails, a ``RuntimeError`` is raised
+(the reference's convention - exceptions in the forward thread are logged and the parent is
+signalled, managers/tp_worker_client.py:110-116).  Tensors are passed as raw device pointers on
+``torch.cuda.current_stream()``; nothing here synchronises.
+"""
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libscratchpad_hip.so")
+_lib = None
+
+SP_F32, SP_F16, SP_BF16 = 0, 1, 2
+_DTYPES = {torch.float32: SP_F32, torch.float16: SP_F16, torch.bfloat16: SP_BF16}
+
+_vp, _i64, _i32, _f32, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
+                              ctypes.c_size_t)
+
+# name -> (restype, argtypes); must list every symbol include/scratchpad_hip.h declares
+SIGNATURES = {
+    "sp_abi_version": (_i32, []),
+    "sp_status_string": (ctypes.c_char_p, [_i32]),
+    "sp_rmsnorm": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp]),
+    "sp_fused_add_rmsnorm": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp]),
+    "sp_silu_and_mul": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _i32, _vp]),
+    "sp_rotary_embedding": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64,
+                                   _i32, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "sp_kv_store": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _i64,
+                           _i64, _i32, _vp]),
+    "sp_write_req_to_token": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "sp_compute_position": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp]),
+    "sp_clamp_position": (_i32, [_vp, _vp, _i32, _i32, _vp]),
+    "sp_decode_attention_workspace_bytes": (_sz, [_i32, _i32, _i32, _i64, _i32]),
+    "sp_decode_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32,
+                                   _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32, _i64, _i32,
+                                   _vp, _sz, _i32, _vp]),
+    "sp_extend_attention_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32]),
+    "sp_extend_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp,
+                                   _i32, _i64, _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32,
+                                   _i32, _i32, _i64, _vp, _sz, _i32, _vp]),
+}
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"{_LIB_PATH} is missing: build it with `python -m scratchpad_amd.build` "
+            "(or __graft_entry__.build()); there is no fallback path")
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sp_abi_version() != 1:
+        raise RuntimeError("libscratchpad_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(status: int, what: str):
+    if status != 0:
+        msg = load().sp_status_string(status).decode()
+        raise RuntimeError(f"{what} failed: {msg} ({status})")
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"unsupported dtype {t.dtype}") from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("scratchpad_amd HIP ops need device tensors (no CPU fallback)")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """View as [rows, inner] with a contiguous inner dimension (copy only if unavoidable)."""
+    if t.dim() == 1:
+        t = t.unsqueeze(0)
+    if t.stride(-1) != 1:
+        t = t.contiguous()
+    if t.dim() > 2:
+        t = t.reshape(-1, t.shape[-1])
+    return t
+
+
+# --------------------------------------------------------------------------- elementwise
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    _gpu(x, weight)
+    x2 = _rows(x)
+    out = torch.empty((x2.shape[0], x2.shape[1]), dtype=x.dtype, device=x.device)
+    w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+    _check(load().sp_rmsnorm(out.data_ptr(), x2.data_ptr(), w.data_ptr(), x2.shape[0], x2.shape[1],
+                             x2.stride(0), out.stride(0), eps, _dt(x), _stream()), "sp_rmsnorm")
+    return out.view(x.shape)
+
+
+def fused_add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float):
+    """In place on both x and residual (flashinfer.norm.fused_add_rmsnorm contract)."""
+    _gpu(x, residual, weight)
+    if x.stride(-1) != 1 or residual.stride(-1) != 1 or x.dim() != 2 or residual.dim() != 2:
+        raise RuntimeError("fused_add_rmsnorm needs 2-D row-contiguous x and residual (in-place op)")
+    w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+    _check(load().sp_fused_add_rmsnorm(x.data_ptr(), residual.data_ptr(), w.data_ptr(), x.shape[0],
+                                       x.shape[1], x.stride(0), residual.stride(0), eps, _dt(x),
+                                       _stream()), "sp_fused_add_rmsnorm")
+
+
+def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
+    _gpu(x)
+    x2 = _rows(x)
+    d = x2.shape[1] // 2
+    out = torch.empty((x2.shape[0], d), dtype=x.dtype, device=x.device)
+    _check(load().sp_silu_and_mul(out.data_ptr(), x2.data_ptr(), x2.shape[0], d, x2.stride(0),
+                                  out.stride(0), _dt(x), _stream()), "sp_silu_and_mul")
+    return out.view(*x.shape[:-1], d)
+
+
+def rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
+                     head_size: int, cos_sin_cache: torch.Tensor, is_neox: bool,
+                     value: Optional[torch.Tensor] = None, k_buffer: Optional[torch.Tensor] = None,
+                     v_buffer: Optional[torch.Tensor] = None,
+                     out_cache_loc: Optional[torch.Tensor] = None) -> None:
+    """In place on query/key ([T, H*head_size], row-contiguous views allowed).  With
+    value/k_buffer/v_buffer/out_cache_loc also scatters rotated k and v into the KV pool."""
+    _gpu(positions, query, key, cos_sin_cache, value, k_buffer, v_buffer, out_cache_loc)
+    if query.dim() != 2 or key.dim() != 2 or query.stride(-1) != 1 or key.stride(-1) != 1:
+        raise RuntimeError("rotary_embedding needs 2-D row-contiguous q and k (in-place op)")
+    if cos_sin_cache.dtype != query.dtype or not cos_sin_cache.is_contiguous():
+        raise RuntimeError("cos_sin_cache must be contiguous and in the activation dtype")
+    if positions.dtype != torch.int64:
+        positions = positions.to(torch.int64)
+    positions = positions.contiguous()
+    T = query.shape[0]
+    Hq, Hkv = query.shape[1] // head_size, key.shape[1] // head_size
+    fused = k_buffer is not None
+    kv_stride = v_stride = 0
+    if fused:
+        if value.dim() != 2 or value.stride(-1) != 1:
+            raise RuntimeError("fused KV store needs a 2-D row-contiguous value")
+        if out_cache_loc.dtype != torch.int64:
+            out_cache_loc = out_cache_loc.to(torch.int64)
+        kv_stride, v_stride = k_buffer.stride(0), value.stride(0)
+    _check(load().sp_rotary_embedding(
+        positions.data_ptr(), query.data_ptr(), key.data_ptr(), cos_sin_cache.data_ptr(), T, Hq, Hkv,
+        head_size, cos_sin_cache.shape[1], query.stride(0), key.stride(0), int(is_neox),
+        _ptr(value) if fused else None, v_stride, _ptr(k_buffer), _ptr(v_buffer),
+        _ptr(out_cache_loc) if fused else None, kv_stride, _dt(query), _stream()),
+        "sp_rotary_embedding")
+
+
+def kv_store(k_buffer: torch.Tensor, v_buffer: torch.Tensor, loc: torch.Tensor,
+             cache_k: torch.Tensor, cache_v: torch.Tensor) -> None:
+    _gpu(k_buffer, v_buffer, loc, cache_k, cache_v)
+    if cache_k.dtype != k_buffer.dtype or cache_v.dtype != v_buffer.dtype:
+        raise RuntimeError("kv_store: cache dtype must equal the pool dtype")
+    T = cache_k.shape[0]
+    k2 = cache_k.reshape(T, -1)
+    v2 = cache_v.reshape(T, -1)
+    if k2.stride(-1) != 1:
+        k2 = k2.contiguous()
+    if v2.stride(-1) != 1:
+        v2 = v2.contiguous()
+    if loc.dtype != torch.int64:
+        loc = loc.to(torch.int64)
+    loc = loc.contiguous()
+    Hkv, D, Dv = k_buffer.shape[1], k_buffer.shape[2], v_buffer.shape[2]
+    _check(load().sp_kv_store(k_buffer.data_ptr(), v_buffer.data_ptr(), loc.data_ptr(), k2.data_ptr(),
+                              v2.data_ptr(), T, Hkv, D, Dv, k2.stride(0), v2.stride(0),
+                              k_buffer.stride(0), v_buffer.stride(0), _dt(k_buffer), _stream()),
+           "sp_kv_store")
+
+
+# --------------------------------------------------------------------------- index kernels
+def write_req_to_token(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor,
+                       pre_lens: torch.Tensor, seq_lens: torch.Tensor, extend_lens: torch.Tensor,
+                       out_cache_loc: torch.Tensor) -> None:
+    _gpu(req_to_token, req_pool_indices, pre_lens, seq_lens, extend_lens, out_cache_loc)
+    if req_to_token.dtype != torch.int32:
+        raise RuntimeError("req_to_token must be int32")
+    args = [t.to(torch.int64).contiguous() for t in
+            (req_pool_indices, pre_lens, seq_lens, extend_lens, out_cache_loc)]
+    _check(load().sp_write_req_to_token(req_to_token.data_ptr(), req_to_token.stride(0),
+                                        *[t.data_ptr() for t in args], req_pool_indices.shape[0],
+                                        _stream()), "sp_write_req_to_token")
+
+
+def compute_position(extend_prefix_lens: torch.Tensor, extend_seq_lens: torch.Tensor,
+                     extend_num_tokens: int):
+    _gpu(extend_prefix_lens, extend_seq_lens)
+    if extend_prefix_lens.dtype != torch.int32 or extend_seq_lens.dtype != torch.int32:
+        raise RuntimeError("extend_prefix_lens / extend_seq_lens must be int32")
+    bs = extend_seq_lens.shape[0]
+    positions = torch.empty(extend_num_tokens, dtype=torch.int64, device=extend_seq_lens.device)
+    start = torch.empty(bs, dtype=torch.int32, device=extend_seq_lens.device)
+    _check(load().sp_compute_position(positions.data_ptr(), start.data_ptr(),
+                                      extend_prefix_lens.contiguous().data_ptr(),
+                                      extend_seq_lens.contiguous().data_ptr(), bs, _stream()),
+           "sp_compute_position")
+    return positions, start
+
+
+def clamp_position(seq_lens: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _gpu(seq_lens)
+    if seq_lens.dtype not in (torch.int32, torch.int64):
+        raise RuntimeError("seq_lens must be int32 or int64")
+    seq_lens = seq_lens.contiguous()
+    if out is None:
+        out = torch.empty(seq_lens.shape[0], dtype=torch.int64, device=seq_lens.device)
+    _check(load().sp_clamp_position(out.data_ptr(), seq_lens.data_ptr(),
+                                    int(seq_lens.dtype == torch.int64), seq_lens.shape[0],
+                                    _stream()), "sp_clamp_position")
+    return out
+
+
+# --------------------------------------------------------------------------- attention
+def _idx_pair(req_pool_indices: torch.Tensor, seq_lens: torch.Tensor):
+    if req_pool_indices.dtype != seq_lens.dtype:
+        req_pool_indices = req_pool_indices.to(seq_lens.dtype)
+    if seq_lens.dtype not in (torch.int32, torch.int64):
+        raise RuntimeError("seq_lens / req_pool_indices must be int32 or int64")
+    return req_pool_indices.contiguous(), seq_lens.contiguous(), int(seq_lens.dtype == torch.int64)
+
+
+def decode_workspace_bytes(bs: int, Hq: int, Dv: int, max_seq_len: int, chunk: int) -> int:
+    return int(load().sp_decode_attention_workspace_bytes(bs, Hq, Dv, max_seq_len, chunk))
+
+
+def decode_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
+                     v_buffer: torch.Tensor, req_to_token: torch.Tensor,
+                     req_pool_indices: torch.Tensor, seq_lens: torch.Tensor, sm_scale: float,
+                     logit_cap: float, max_seq_len: int, chunk: int, workspace: torch.Tensor,
+                     kv_start: Optional[torch.Tensor] = None) -> None:
+    """q, out: [bs, Hq, D] (row stride free); buffers [P+1, Hkv, D]."""
+    _gpu(out, q, k_buffer, v_buffer, req_to_token, req_pool_indices, seq_lens, workspace, kv_start)
+    bs, Hq, D = q.shape
+    if q.stride(2) != 1 or q.stride(1) != D or out.stride(2) != 1 or out.stride(1) != D:
+        raise RuntimeError("decode_attention: q/out must be [bs, Hq, D] with contiguous heads")
+    if k_buffer.dtype != q.dtype or v_buffer.dtype != q.dtype:
+        raise RuntimeError("decode_attention: KV pool dtype must equal q dtype")
+    req, seq, idx64 = _idx_pair(req_pool_indices, seq_lens)
+    if kv_start is not None:
+        kv_start = kv_start.to(seq.dtype).contiguous()
+    _check(load().sp_decode_attention(
+        out.data_ptr(), q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), req_to_token.data_ptr(),
+        req_to_token.stride(0), req.data_ptr(), seq.data_ptr(), _ptr(kv_start), idx64, bs, Hq,
+        k_buffer.shape[1], D, q.stride(0), out.stride(0), k_buffer.stride(0), sm_scale, logit_cap,
+        max_seq_len, chunk, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+        _dt(q), _stream()), "sp_decode_attention")
+
+
+def extend_workspace_bytes(num_tokens: int, bs: int, Hq: int, D: int, dtype: torch.dtype) -> int:
+    return int(load().sp_extend_attention_workspace_bytes(num_tokens, bs, Hq, D, _DTYPES[dtype]))
+
+
+def extend_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
+                     v_buffer: torch.Tensor, req_to_token: torch.Tensor,
+                     req_pool_indices: torch.Tensor, seq_lens: torch.Tensor,
+                     extend_seq_lens: torch.Tensor, extend_start_loc: torch.Tensor,
+                     sm_scale: float, logit_cap: float, causal: bool, max_extend_len: int,
+                     max_seq_len: int, workspace: torch.Tensor,
+                     kv_start: Optional[torch.Tensor] = None) -> None:
+    """q, out: [T, Hq, D]; the new tokens' K/V must already be in the pool."""
+    _gpu(out, q, k_buffer, v_buffer, req_to_token, req_pool_indices, seq_lens, extend_seq_lens,
+         extend_start_loc, workspace, kv_start)
+    T, Hq, D = q.shape
+    if q.stride(2) != 1 or q.stride(1) != D or out.stride(2) != 1 or out.stride(1) != D:
+        raise RuntimeError("extend_attention: q/out must be [T, Hq, D] with contiguous heads")
+    if k_buffer.dtype != q.dtype or v_buffer.dtype != q.dtype:
+        raise RuntimeError("extend_attention: KV pool dtype must equal q dtype")
+    if extend_seq_lens.dtype != torch.int32 or extend_start_loc.dtype != torch.int32:
+        raise RuntimeError("extend_seq_lens / extend_start_loc must be int32")
+    req, seq, idx64 = _idx_pair(req_pool_indices, seq_lens)
+    if kv_start is not None:
+        kv_start = kv_start.to(seq.dtype).contiguous()
+    _check(load().sp_extend_attention(
+        out.data_ptr(), q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), req_to_token.data_ptr(),
+        req_to_token.stride(0), req.data_ptr(), seq.data_ptr(), _ptr(kv_start), idx64,
+        extend_seq_lens.contiguous().data_ptr(), extend_start_loc.contiguous().data_ptr(),
+        seq.shape[0], T, Hq, k_buffer.shape[1], D, q.stride(0), out.stride(0), k_buffer.stride(0),
+        sm_scale, logit_cap, int(causal), max_extend_len, max_seq_len, workspace.data_ptr(),
+        workspace.numel() * workspace.element_size(), _dt(q), _stream()), "sp_extend_attention")

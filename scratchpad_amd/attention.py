@@ -1,0 +1,260 @@
+"""Attention plugin seam: AttentionBackend ABC, RadixAttention layer, and the HIP backend.
+
+Mirrors nn/attention/backend.py:11-105 (same abstract methods and dispatch),
+nn/attention/radix_attention.py:6-57, and plays the role of TritonAttnBackend /
+FlashInferAttnBackend (nn/attention/triton_backend.py:17-196, flashinfer_backend.py:49-496):
+it reads ``req_to_token`` directly like the Triton backend (no kv_indices materialisation) and
+implements the flashinfer backend's encoder-decoder dispatch (cross-attention reads kv slots
+[0, encoder_len); self-attention reads [encoder_len, encoder_len + seq_len)).
+"""
+from abc import ABC, abstractmethod
+from typing import TYPE_CHECKING, Optional
+
+import torch
+from torch import nn
+
+from . import _native
+
+if TYPE_CHECKING:
+    from .forward_info import ForwardBatch, ForwardMode
+
+
+class AttentionBackend(ABC):
+    """The base class of attention backends (backend.py:11-105)."""
+
+    @abstractmethod
+    def init_forward_metadata(self, forward_batch: "ForwardBatch"):
+        raise NotImplementedError()
+
+    def init_cuda_graph_state(self, max_bs: int):
+        raise NotImplementedError()
+
+    def init_forward_metadata_capture_cuda_graph(self, bs: int, num_tokens: int,
+                                                 req_pool_indices: torch.Tensor,
+                                                 seq_lens: torch.Tensor,
+                                                 encoder_lens: Optional[torch.Tensor],
+                                                 forward_mode: "ForwardMode", spec_info=None):
+        raise NotImplementedError()
+
+    def init_forward_metadata_replay_cuda_graph(self, bs: int, req_pool_indices: torch.Tensor,
+                                                seq_lens: torch.Tensor, seq_lens_sum: int,
+                                                encoder_lens: Optional[torch.Tensor],
+                                                forward_mode: "ForwardMode", spec_info=None,
+                                                seq_lens_cpu: Optional[torch.Tensor] = None):
+        raise NotImplementedError()
+
+    def get_cuda_graph_seq_len_fill_value(self):
+        raise NotImplementedError()
+
+    def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, layer: "RadixAttention",
+                forward_batch: "ForwardBatch", save_kv_cache: bool = True):
+        if forward_batch.forward_mode.is_decode():
+            return self.forward_decode(q, k, v, layer, forward_batch, save_kv_cache=save_kv_cache)
+        return self.forward_extend(q, k, v, layer, forward_batch, save_kv_cache=save_kv_cache)
+
+    def forward_decode(self, q, k, v, layer, forward_batch, save_kv_cache: bool = True):
+        raise NotImplementedError()
+
+    def forward_extend(self, q, k, v, layer, forward_batch, save_kv_cache: bool = True):
+        raise NotImplementedError()
+
+
+class RadixAttention(nn.Module):
+    """radix_attention.py:6-57: layer-local constants + delegation to the backend."""
+
+    def __init__(self, num_heads: int, head_dim: int, scaling: float, num_kv_heads: int,
+                 layer_id: int, logit_cap: float = 0.0, v_head_dim: int = -1,
+                 sliding_window_size: int = -1, is_cross_attention: bool = False,
+                 prefix: str = "", use_irope: bool = False):
+        super().__init__()
+        self.tp_q_head_num = num_heads
+        self.tp_k_head_num = num_kv_heads
+        self.tp_v_head_num = num_kv_heads
+        self.head_dim = head_dim
+        self.qk_head_dim = head_dim
+        self.v_head_dim = v_head_dim if v_head_dim != -1 else head_dim
+        self.scaling = scaling
+        self.layer_id = layer_id
+        self.logit_cap = logit_cap
+        self.sliding_window_size = sliding_window_size or -1
+        self.is_cross_attention = is_cross_attention
+        self.k_scale = None
+        self.v_scale = None
+        self.use_irope = use_irope
+
+    def forward(self, q, k, v, forward_batch: "ForwardBatch", save_kv_cache: bool = True):
+        if k is not None:
+            assert v is not None
+            k = k.view(-1, self.tp_k_head_num, self.qk_head_dim)
+            v = v.view(-1, self.tp_v_head_num, self.v_head_dim)
+        return forward_batch.attn_backend.forward(q, k, v, self, forward_batch, save_kv_cache)
+
+
+def _pow2_floor(x: int) -> int:
+    return 1 << (max(int(x), 1).bit_length() - 1)
+
+
+class HipAttnBackend(AttentionBackend):
+    """MI355X attention backend over ``sp_decode_attention`` / ``sp_extend_attention``.
+
+    Constructed with a ``model_runner`` like the reference's backends (reads ``model_config``,
+    ``tp_size``, ``token_to_kv_pool``, ``req_to_token_pool``, ``device``)."""
+
+    # work items (request x split x head-group) we want per launch, so that 256 CUs x 3-4
+    # resident workgroups see several waves of work and the ragged tail stays short
+    TARGET_ITEMS = 2048
+    MIN_CHUNK, MAX_CHUNK = 64, 512
+
+    def __init__(self, model_runner):
+        super().__init__()
+        _native.load()
+        cfg = model_runner.model_config
+        self.num_head = cfg.num_attention_heads // model_runner.tp_size
+        self.num_kv_head = cfg.get_num_kv_heads(model_runner.tp_size)
+        self.head_dim = cfg.head_dim
+        self.v_head_dim = model_runner.token_to_kv_pool.get_value_buffer(0).shape[-1]
+        self.max_context_len = cfg.context_len
+        self.device = model_runner.device
+        self.kv_dtype = model_runner.token_to_kv_pool.dtype
+        self.is_encoder_decoder = bool(getattr(cfg, "is_encoder_decoder", False))
+        self.forward_metadata = None
+        self._workspace = torch.empty(0, dtype=torch.uint8, device=self.device)
+        self._graph_workspace = None
+        self._graph_chunk = None
+
+    # ---------------------------------------------------------------- launch planning
+    def _head_groups(self, dtype: torch.dtype) -> int:
+        vec = 4 if dtype == torch.float32 else 8
+        rpl = 64 // (self.head_dim // vec)
+        hh = 1
+        while hh * 2 <= rpl and self.num_kv_head % (hh * 2) == 0:
+            hh *= 2
+        return self.num_kv_head // hh
+
+    def _plan_chunk(self, kv_tokens: int, dtype: torch.dtype) -> int:
+        groups = self._head_groups(dtype)
+        chunk = _pow2_floor(max(kv_tokens, 1) * groups // self.TARGET_ITEMS)
+        return max(self.MIN_CHUNK, min(self.MAX_CHUNK, chunk))
+
+    def _ensure_workspace(self, nbytes: int) -> torch.Tensor:
+        if self._workspace.numel() < nbytes:
+            self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._workspace
+
+    # ---------------------------------------------------------------- metadata hooks
+    def init_forward_metadata(self, forward_batch: "ForwardBatch"):
+        """Per-step plan.  Decode: (chunk, max_seq_len, workspace); extend: (max_extend_len,
+        max_seq_len, workspace).  No device sync: bounds come from host-side fields."""
+        pool_dtype = forward_batch.token_to_kv_pool.dtype
+        bs = forward_batch.batch_size
+        enc_max = 0
+        if forward_batch.encoder_lens_cpu:
+            enc_max = max(forward_batch.encoder_lens_cpu)
+        if forward_batch.forward_mode.is_decode():
+            if forward_batch.seq_lens_cpu is not None:
+                max_len = int(forward_batch.seq_lens_cpu.max())
+            else:
+                max_len = min(self.max_context_len, forward_batch.seq_lens_sum - (bs - 1))
+            max_len = max(max_len, enc_max, 1)
+            chunk = self._plan_chunk(forward_batch.seq_lens_sum, pool_dtype)
+            ws = self._ensure_workspace(_native.decode_workspace_bytes(
+                bs, self.num_head, self.v_head_dim, max_len, chunk))
+            self.forward_metadata = (chunk, max_len, ws)
+        else:
+            max_extend = max(forward_batch.extend_seq_lens_cpu)
+            if forward_batch.seq_lens_cpu is not None:
+                max_len = int(forward_batch.seq_lens_cpu.max())
+            else:
+                max_len = max(p + e for p, e in zip(forward_batch.extend_prefix_lens_cpu,
+                                                    forward_batch.extend_seq_lens_cpu))
+            max_len = max(max_len, enc_max, 1)
+            ws = self._ensure_workspace(_native.extend_workspace_bytes(
+                forward_batch.extend_num_tokens, bs, self.num_head, self.head_dim, pool_dtype))
+            self.forward_metadata = (max_extend, max_len, ws)
+
+    def init_cuda_graph_state(self, max_bs: int):
+        """Static split geometry + workspace for graph replay (triton_backend.py:70-80 allocates
+        static attn_logits the same way)."""
+        self.cuda_graph_max_seq_len = self.max_context_len
+        pool_dtype = self.kv_dtype
+        self._graph_chunk = self._plan_chunk(max_bs * self.max_context_len // 2, pool_dtype)
+        nbytes = _native.decode_workspace_bytes(max_bs, self.num_head, self.v_head_dim,
+                                                self.cuda_graph_max_seq_len, self._graph_chunk)
+        self._graph_workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+
+    def init_forward_metadata_capture_cuda_graph(self, bs, num_tokens, req_pool_indices, seq_lens,
+                                                 encoder_lens, forward_mode, spec_info=None):
+        assert forward_mode.is_decode(), "only decode is captured"
+        assert spec_info is None, "speculative decoding is out of scope"
+        self.forward_metadata = (self._graph_chunk, self.cuda_graph_max_seq_len,
+                                 self._graph_workspace)
+
+    def init_forward_metadata_replay_cuda_graph(self, bs, req_pool_indices, seq_lens, seq_lens_sum,
+                                                encoder_lens, forward_mode, spec_info=None,
+                                                seq_lens_cpu=None):
+        # geometry is static; the kernels read seq_lens / req_pool_indices from the graph's
+        # static input buffers, so there is nothing to rebuild (the reference recomputes
+        # start_loc / kv_indices here: triton_backend.py:103-113, flashinfer_backend.py:330-373)
+        self.forward_metadata = (self._graph_chunk, self.cuda_graph_max_seq_len,
+                                 self._graph_workspace)
+
+    def get_cuda_graph_seq_len_fill_value(self):
+        return 1  # padded rows attend to the dummy slot 0 only (triton_backend.py:115-116)
+
+    # ---------------------------------------------------------------- forward
+    def _kv_window(self, layer: RadixAttention, forward_batch: "ForwardBatch"):
+        """(seq_lens, kv_start) for this layer: flashinfer_backend.py:593-621, 792-828."""
+        if layer.is_cross_attention:
+            return forward_batch.encoder_lens, None
+        if self.is_encoder_decoder and forward_batch.encoder_lens is not None:
+            return forward_batch.seq_lens, forward_batch.encoder_lens
+        return forward_batch.seq_lens, None
+
+    def _store(self, layer, forward_batch, k, v, save_kv_cache):
+        if k is None or not save_kv_cache:
+            return
+        assert v is not None
+        cache_loc = (forward_batch.encoder_out_cache_loc if layer.is_cross_attention
+                     else forward_batch.out_cache_loc)
+        forward_batch.token_to_kv_pool.set_kv_buffer(layer, cache_loc, k, v)
+
+    def forward_extend(self, q, k, v, layer: RadixAttention, forward_batch: "ForwardBatch",
+                       save_kv_cache: bool = True):
+        if layer.sliding_window_size not in (-1, None):
+            raise NotImplementedError("sliding-window attention (Gemma) is out of scope")
+        if layer.qk_head_dim != layer.v_head_dim:
+            raise NotImplementedError("v_head_dim != head_dim (MLA) is out of scope")
+        q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
+        o = torch.empty_like(q)
+        # KV store BEFORE the kernel: the kernel reads every key, new ones included, from the pool
+        # (triton_backend.py:131-134)
+        self._store(layer, forward_batch, k, v, save_kv_cache)
+        max_extend, max_len, ws = self.forward_metadata
+        seq_lens, kv_start = self._kv_window(layer, forward_batch)
+        kb, vb = forward_batch.token_to_kv_pool.get_kv_buffer(layer.layer_id)
+        _native.extend_attention(
+            o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
+            q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), kb, vb,
+            forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices, seq_lens,
+            forward_batch.extend_seq_lens, forward_batch.extend_start_loc, layer.scaling,
+            layer.logit_cap, not layer.is_cross_attention, max_extend, max_len, ws, kv_start)
+        return o
+
+    def forward_decode(self, q, k, v, layer: RadixAttention, forward_batch: "ForwardBatch",
+                       save_kv_cache: bool = True):
+        if layer.sliding_window_size not in (-1, None):
+            raise NotImplementedError("sliding-window attention (Gemma) is out of scope")
+        if layer.qk_head_dim != layer.v_head_dim:
+            raise NotImplementedError("v_head_dim != head_dim (MLA) is out of scope")
+        q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
+        o = torch.empty_like(q)
+        self._store(layer, forward_batch, k, v, save_kv_cache)
+        chunk, max_len, ws = self.forward_metadata
+        seq_lens, kv_start = self._kv_window(layer, forward_batch)
+        kb, vb = forward_batch.token_to_kv_pool.get_kv_buffer(layer.layer_id)
+        _native.decode_attention(
+            o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
+            q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), kb, vb,
+            forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices, seq_lens,
+            layer.scaling, layer.logit_cap, max_len, chunk, ws, kv_start)
+        return o

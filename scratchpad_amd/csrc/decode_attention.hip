@@ -1,0 +1,433 @@
+// Paged (page_size = 1) decode attention for gfx950: one fused pass, split-KV + merge.
+//
+// Replaces the reference's two-pass Triton decode (nn/attention/triton_attn/decode_attention.py:
+// stage 1 QK^T -> fp32 logits in HBM, stage 2 softmax.V) and flashinfer's paged decode wrapper.
+//
+// Shape of the problem: 4 flop per KV byte - strictly HBM-bound, MFMA is not needed (a group of
+// 4-8 query heads per KV head is not a dense tile).  Everything is organised around reading the
+// gathered KV rows once, with full-line coalesced 16-byte-per-lane loads straight to VGPRs
+// (cdna_hip_programming.md 'GEMV / M<=16' row: no LDS round trip for once-read operands):
+//
+//   * a wave-instruction loads 1 KiB = RPL rows of D elements (RPL = 4 for 16-bit D=128); the
+//     rows are `HH` adjacent KV heads of one token (contiguous in the [P+1, Hkv, D] pool) times
+//     RPL/HH consecutive tokens;
+//   * every lane owns 16 bytes (VEC dims) of its row and all G query heads of that KV head:
+//     QK^T partials by v_dot2c (16-bit) / fma (fp32), then a DPP all-reduce over the LPR lanes of
+//     the row; PV accumulates VEC dims x G heads in registers;
+//   * each (wave, row) pair runs an independent online softmax over its tokens; the streams are
+//     merged through LDS at the end of the workgroup, and split-KV partials (normalised o +
+//     log2-sum-exp) are merged by a second tiny kernel;
+//   * slot indices come from one coalesced read of req_to_token per 64 tokens per wave and are
+//     handed to the lanes by ds_bpermute; K/V loads of the next batch are issued before the
+//     current batch is consumed (two register sets).
+//
+// Launch geometry depends only on (batch, heads, max_seq_len, chunk): graph-capturable.
+// Workgroups whose chunk starts beyond their request's seq_len exit at once.
+#include "sp_common.h"
+#include "attention_internal.h"
+
+namespace sp {
+
+
+static constexpr float kLog2e = 1.4426950408889634f;
+static constexpr float kNegBig = -1.0e30f;
+
+// ---- all-reduce (sum) across the LPR consecutive lanes that share a KV row ---------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+template <int LPR>
+__device__ __forceinline__ float row_allreduce(float v) {
+  static_assert(LPR == 8 || LPR == 16 || LPR == 32 || LPR == 64, "lanes per row");
+  v += dpp_mov<0xB1>(v);  // quad_perm [1,0,3,2]  (xor 1)
+  v += dpp_mov<0x4E>(v);  // quad_perm [2,3,0,1]  (xor 2)
+  if constexpr (LPR == 8) {
+    v += dpp_mov<0x141>(v);  // row_half_mirror: lane i <-> 7-i inside each 8 lanes
+  } else {
+    v += dpp_mov<0x124>(v);  // row_ror:4
+    v += dpp_mov<0x128>(v);  // row_ror:8   -> every lane of the 16-lane row has the row sum
+    if constexpr (LPR >= 32)
+      v += __builtin_bit_cast(
+          float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));  // xor 16
+    if constexpr (LPR == 64) v += __shfl_xor(v, 32, 64);
+  }
+  return v;
+}
+
+template <typename Tag>
+__device__ __forceinline__ float dot16(const u32x4& a, const u32x4& b, float acc);
+template <>
+__device__ __forceinline__ float dot16<f32_tag>(const u32x4& a, const u32x4& b, float acc) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    acc = __builtin_fmaf(__builtin_bit_cast(float, a[i]), __builtin_bit_cast(float, b[i]), acc);
+  return acc;
+}
+template <>
+__device__ __forceinline__ float dot16<bf16_tag>(const u32x4& a, const u32x4& b, float acc) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a[i]),
+                                          __builtin_bit_cast(bf16x2_t, b[i]), acc, false);
+  return acc;
+}
+template <>
+__device__ __forceinline__ float dot16<f16_tag>(const u32x4& a, const u32x4& b, float acc) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a[i]),
+                                 __builtin_bit_cast(f16x2_t, b[i]), acc, false);
+  return acc;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <typename Tag, int D, int G>
+struct DecodeCfg {
+  typedef Elem<Tag> E;
+  static constexpr int VEC = E::kVec;            // elements per lane
+  static constexpr int LPR = D / VEC;            // lanes per KV row
+  static constexpr int RPL = 64 / LPR;           // rows per wave-load
+  static constexpr int NB = 4;                   // wave-loads per batch (per K and per V)
+  static constexpr int WAVES = 4;
+  static constexpr int kLdsFloats = WAVES * RPL * G * (D + 2);
+};
+
+template <typename Tag, int D, int G>
+__global__ __launch_bounds__(256) void decode_attn_kernel(DecodeArgs a) {
+  typedef DecodeCfg<Tag, D, G> C;
+  typedef Elem<Tag> E;
+  constexpr int VEC = C::VEC, LPR = C::LPR, RPL = C::RPL, NB = C::NB, WAVES = C::WAVES;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  // blockIdx -> (request b, split c, head group hg); sibling head groups are adjacent so the two
+  // halves of a token's KV row are fetched at about the same time
+  int id = blockIdx.x;
+  const int hg = id % a.head_groups;
+  id /= a.head_groups;
+  const int c = id % a.num_splits;
+  const int b = id / a.num_splits;
+
+  const int seq = (int)load_idx(a.seq_lens, b, a.idx64);
+  const int cs = c * a.chunk;
+  if (cs >= seq) return;  // (also covers seq == 0) uniform for the whole workgroup
+  const int ce = min(cs + a.chunk, seq);
+  const int nsplit = (seq + a.chunk - 1) / a.chunk;
+  const int64_t req = load_idx(a.req_idx, b, a.idx64);
+  const int64_t kv0 = a.kv_start ? load_idx(a.kv_start, b, a.idx64) : 0;
+  const int32_t* idx_row = a.r2t + req * a.r2t_stride + kv0;
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = lane / LPR, col = lane % LPR;
+  const int HH = 1 << a.hh_shift;
+  const int TPL = RPL >> a.hh_shift;  // tokens per wave-load
+  const int head_local = row & (HH - 1);
+  const int tok_in_load = row >> a.hh_shift;
+  const int kv_head = hg * HH + head_local;
+
+  // q fragment: G heads x VEC dims, kept packed
+  u32x4 qf[G];
+  {
+    const char* qp = (const char*)a.q +
+                     ((int64_t)b * a.q_stride + (int64_t)kv_head * G * D + col * VEC) * E::kBytes;
+#pragma unroll
+    for (int g = 0; g < G; ++g) qf[g] = ld16(qp + (int64_t)g * D * E::kBytes);
+  }
+  const int64_t lane_off = ((int64_t)kv_head * D + col * VEC) * E::kBytes;
+  const int64_t tok_bytes = a.kv_stride * E::kBytes;
+
+  float m[G], l[G], acc[G][VEC];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    m[g] = kNegBig;
+    l[g] = 0.f;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[g][e] = 0.f;
+  }
+  const float cap = a.logit_cap;
+  const float qk_scale = cap > 0.f ? a.sm_scale : a.sm_scale * kLog2e;
+
+  // this wave's contiguous share of the chunk
+  const int sub = (a.chunk + WAVES - 1) / WAVES;
+  const int ws = cs + wave * sub;
+  const int we = min(ws + sub, ce);
+
+  for (int ps = ws; ps < we; ps += 64) {  // pieces of <= 64 tokens: one index register
+    const int n = min(64, we - ps);
+    const int myidx = lane < n ? idx_row[ps + lane] : 0;
+    const int nloads = (n + TPL - 1) / TPL;
+
+    u32x4 kA[NB], vA[NB], kB[NB], vB[NB];
+    auto issue = [&](u32x4(&kr)[NB], u32x4(&vr)[NB], int first_load) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int tl = (first_load + j) * TPL + tok_in_load;
+        // out-of-range rows read the reserved dummy slot 0 (always mapped) and are masked below
+        const int slot = __shfl(myidx, tl & 63, 64);
+        const int64_t off = (tl < n ? (int64_t)slot : 0) * tok_bytes + lane_off;
+        kr[j] = ld16(a.kbuf + off);
+        vr[j] = ld16(a.vbuf + off);
+      }
+    };
+    auto consume = [&](const u32x4(&kr)[NB], const u32x4(&vr)[NB], int first_load) {
+      float s[NB][G];
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int g = 0; g < G; ++g) s[j][g] = dot16<Tag>(qf[g], kr[j], 0.f);
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int g = 0; g < G; ++g) s[j][g] = row_allreduce<LPR>(s[j][g]);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const bool valid = (first_load + j) * TPL + tok_in_load < n;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          float x = s[j][g] * qk_scale;
+          if (cap > 0.f) x = cap * tanhf(x / cap) * kLog2e;
+          s[j][g] = valid ? x : -INFINITY;
+        }
+      }
+      float alpha[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float mx = m[g];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) mx = fmaxf(mx, s[j][g]);
+        alpha[g] = fast_exp2(m[g] - mx);
+        m[g] = mx;
+        float ps_ = 0.f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          s[j][g] = fast_exp2(s[j][g] - mx);
+          ps_ += s[j][g];
+        }
+        l[g] = l[g] * alpha[g] + ps_;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[g][e] *= alpha[g];
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        float vf[VEC];
+        unpack16<Tag>(vr[j], vf);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[g][e] = __builtin_fmaf(s[j][g], vf[e], acc[g][e]);
+      }
+    };
+
+    issue(kA, vA, 0);
+    for (int ld = 0; ld < nloads; ld += 2 * NB) {
+      if (ld + NB < nloads) issue(kB, vB, ld + NB);
+      consume(kA, vA, ld);
+      if (ld + NB < nloads) {
+        if (ld + 2 * NB < nloads) issue(kA, vA, ld + 2 * NB);
+        consume(kB, vB, ld + NB);
+      }
+    }
+  }
+
+  // ---- merge the WAVES x RPL streams of this workgroup through LDS ---------------------------
+  float* sm_acc = smem;                                // [WAVES][RPL][G][D]
+  float* sm_ml = smem + WAVES * RPL * G * D;           // [WAVES][RPL][G][2]
+  {
+    const int stream = wave * RPL + row;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float* dst = sm_acc + ((stream * G + g) * D + col * VEC);
+#pragma unroll
+      for (int e = 0; e < VEC; e += 4)
+        *(float4*)(dst + e) = make_float4(acc[g][e], acc[g][e + 1], acc[g][e + 2], acc[g][e + 3]);
+      if (col == 0) {
+        sm_ml[(stream * G + g) * 2] = m[g];
+        sm_ml[(stream * G + g) * 2 + 1] = l[g];
+      }
+    }
+  }
+  __syncthreads();
+  const int outs = HH * G * D;
+  for (int i = threadIdx.x; i < outs; i += 256) {
+    const int d = i % D;
+    const int g = (i / D) % G;
+    const int hl = i / (D * G);
+    float M = kNegBig;
+    for (int w = 0; w < WAVES; ++w)
+      for (int t = 0; t < TPL; ++t)
+        M = fmaxf(M, sm_ml[(((w * RPL) + (t << a.hh_shift) + hl) * G + g) * 2]);
+    float L = 0.f, O = 0.f;
+    for (int w = 0; w < WAVES; ++w)
+      for (int t = 0; t < TPL; ++t) {
+        const int stream = w * RPL + (t << a.hh_shift) + hl;
+        const float wgt = fast_exp2(sm_ml[(stream * G + g) * 2] - M);
+        L += sm_ml[(stream * G + g) * 2 + 1] * wgt;
+        O += sm_acc[(stream * G + g) * D + d] * wgt;
+      }
+    const int h = (hg * HH + hl) * G + g;
+    const float o = O / L;
+    if (nsplit == 1) {
+      E::store(a.out, (int64_t)b * a.o_stride + (int64_t)h * D + d, o);
+    } else {
+      const int64_t pi = ((int64_t)b * a.Hq + h) * a.num_splits + c;
+      a.part_o[pi * D + d] = o;
+      if (d == 0) a.part_lse[pi] = M + __builtin_amdgcn_logf(L);  // v_log_f32 = log2
+    }
+  }
+}
+
+// one wave per (request, q head): combine the split partials by their log2-sum-exp
+template <typename Tag, int D>
+__global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
+  typedef Elem<Tag> E;
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= a.bs * a.Hq) return;
+  const int lane = threadIdx.x & 63;
+  const int b = pair / a.Hq, h = pair - b * a.Hq;
+  const int seq = (int)load_idx(a.seq_lens, b, a.idx64);
+  const int nsplit = (seq + a.chunk - 1) / a.chunk;
+  if (nsplit <= 1) return;  // written directly by the attention kernel (or empty row)
+  const float* lse = a.part_lse + (int64_t)pair * a.num_splits;
+  const float* po = a.part_o + (int64_t)pair * a.num_splits * D;
+  float M = kNegBig;
+  for (int c = 0; c < nsplit; ++c) M = fmaxf(M, lse[c]);
+  constexpr int PER = D / 64;
+  float o[PER], W = 0.f;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) o[e] = 0.f;
+  for (int c = 0; c < nsplit; ++c) {
+    const float w = fast_exp2(lse[c] - M);
+    W += w;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) o[e] += w * po[(int64_t)c * D + e * 64 + lane];
+  }
+#pragma unroll
+  for (int e = 0; e < PER; ++e)
+    E::store(a.out, (int64_t)b * a.o_stride + (int64_t)h * D + e * 64 + lane, o[e] / W);
+}
+
+template <typename Tag, int D, int G>
+static int launch_decode(const DecodeArgs& a, hipStream_t st) {
+  typedef DecodeCfg<Tag, D, G> C;
+  const size_t lds = (size_t)C::kLdsFloats * sizeof(float);
+  const unsigned grid = (unsigned)a.bs * a.num_splits * a.head_groups;
+  static bool attr_set = false;  // benign race: idempotent
+  if (!attr_set && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)decode_attn_kernel<Tag, D, G>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  decode_attn_kernel<Tag, D, G><<<dim3(grid), 256, lds, st>>>(a);
+  SP_LAUNCH_CHECK();
+  if (a.num_splits > 1) {
+    decode_merge_kernel<Tag, D><<<dim3((a.bs * a.Hq + 3) / 4), 256, 0, st>>>(a);
+    SP_LAUNCH_CHECK();
+  }
+  return SP_OK;
+}
+
+template <typename Tag, int D>
+static int dispatch_group(const DecodeArgs& a, int G, hipStream_t st) {
+  switch (G) {
+    case 1: return launch_decode<Tag, D, 1>(a, st);
+    case 2: return launch_decode<Tag, D, 2>(a, st);
+    case 4: return launch_decode<Tag, D, 4>(a, st);
+    case 8: return launch_decode<Tag, D, 8>(a, st);
+    default: return SP_ERR_UNSUPPORTED;
+  }
+}
+
+template <typename Tag>
+static int dispatch_dim(const DecodeArgs& a, int D, int G, hipStream_t st) {
+  switch (D) {
+    case 64: return dispatch_group<Tag, 64>(a, G, st);
+    case 128: return dispatch_group<Tag, 128>(a, G, st);
+    default: return SP_ERR_UNSUPPORTED;
+  }
+}
+
+int run_decode(const DecodeArgs& a, int head_dim, int group, int dtype, hipStream_t st) {
+  SP_DISPATCH_DTYPE(dtype, return (dispatch_dim<Tag>(a, head_dim, group, st)));
+}
+
+int decode_heads_per_load_shift(int num_kv_heads, int head_dim, int dtype, int* head_groups) {
+  const int vec = dtype == SP_F32 ? 4 : 8;
+  const int rpl = 64 / (head_dim / vec);
+  int hh = 1, shift = 0;
+  while (hh * 2 <= rpl && num_kv_heads % (hh * 2) == 0) { hh *= 2; ++shift; }
+  *head_groups = num_kv_heads / hh;
+  return shift;
+}
+
+}  // namespace sp
+
+using namespace sp;
+
+static inline int64_t num_splits_for(int64_t max_seq_len, int chunk) {
+  int64_t s = (max_seq_len + chunk - 1) / chunk;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" size_t sp_decode_attention_workspace_bytes(int batch_size, int num_q_heads,
+                                                      int v_head_dim, int64_t max_seq_len,
+                                                      int chunk) {
+  if (batch_size <= 0 || num_q_heads <= 0 || v_head_dim <= 0 || chunk <= 0) return 0;
+  const int64_t s = num_splits_for(max_seq_len, chunk);
+  if (s <= 1) return 16;
+  return (size_t)batch_size * num_q_heads * s * (v_head_dim + 1) * sizeof(float) + 16;
+}
+
+extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffer,
+                                   const void* v_buffer, const int32_t* req_to_token,
+                                   int64_t req_to_token_stride, const void* req_pool_indices,
+                                   const void* seq_lens, const void* kv_start, int idx64,
+                                   int batch_size, int num_q_heads, int num_kv_heads, int head_dim,
+                                   int64_t q_stride, int64_t out_stride, int64_t kv_buffer_stride,
+                                   float sm_scale, float logit_cap, int64_t max_seq_len, int chunk,
+                                   void* workspace, size_t workspace_bytes, int dtype,
+                                   void* stream) {
+  SP_CHECK_ARG(out && q && k_buffer && v_buffer && req_to_token && req_pool_indices && seq_lens);
+  SP_CHECK_ARG(batch_size >= 0 && num_q_heads > 0 && num_kv_heads > 0 && head_dim > 0);
+  SP_CHECK_ARG(num_q_heads % num_kv_heads == 0 && max_seq_len >= 0);
+  // each wave takes chunk/4 tokens in pieces of 64: keep the split a multiple of 4
+  SP_CHECK_ARG(chunk >= 4 && chunk % 4 == 0);
+  SP_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)k_buffer & 15) == 0 &&
+               ((uintptr_t)v_buffer & 15) == 0);
+  if (batch_size == 0) return SP_OK;
+  const int eb = dtype == SP_F32 ? 4 : 2;
+  const int vec = 16 / eb;
+  SP_CHECK_ARG(q_stride % vec == 0 && kv_buffer_stride % vec == 0);
+  const int G = num_q_heads / num_kv_heads;
+  int Gk = G, qblocks = 1;  // groups wider than 8 are processed 8 query heads at a time
+  if (G > 8) {
+    if (G % 8) return SP_ERR_UNSUPPORTED;
+    Gk = 8;
+    qblocks = G / 8;
+  }
+  if (qblocks != 1) return SP_ERR_UNSUPPORTED;  // TODO(next): loop q-head blocks over one KV read
+  if (head_dim != 64 && head_dim != 128) return SP_ERR_UNSUPPORTED;
+
+  const int64_t S = num_splits_for(max_seq_len, chunk);
+  DecodeArgs a;
+  a.out = out; a.q = q; a.kbuf = (const char*)k_buffer; a.vbuf = (const char*)v_buffer;
+  a.r2t = req_to_token; a.r2t_stride = req_to_token_stride; a.req_idx = req_pool_indices;
+  a.seq_lens = seq_lens; a.kv_start = kv_start; a.idx64 = idx64; a.bs = batch_size;
+  a.Hq = num_q_heads; a.Hkv = num_kv_heads; a.q_stride = q_stride; a.o_stride = out_stride;
+  a.kv_stride = kv_buffer_stride; a.sm_scale = sm_scale; a.logit_cap = logit_cap;
+  a.chunk = chunk; a.num_splits = (int)S;
+  a.hh_shift = decode_heads_per_load_shift(num_kv_heads, head_dim, dtype, &a.head_groups);
+  a.part_o = nullptr; a.part_lse = nullptr;
+  if (S > 1) {
+    const size_t need = sp_decode_attention_workspace_bytes(batch_size, num_q_heads, head_dim,
+                                                            max_seq_len, chunk);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) return SP_ERR_WORKSPACE;
+    a.part_o = (float*)workspace;
+    a.part_lse = a.part_o + (size_t)batch_size * num_q_heads * S * head_dim;
+  }
+  if ((int64_t)batch_size * S * a.head_groups > 0x7fffffffLL) return SP_ERR_INVALID_ARG;
+  if (dtype != SP_F32 && dtype != SP_F16 && dtype != SP_BF16) return SP_ERR_UNSUPPORTED;
+  return run_decode(a, head_dim, Gk, dtype, (hipStream_t)stream);
+}

@@ -1,0 +1,103 @@
+// Ragged extend (prefill with cached prefix) attention for gfx950.
+//
+// Replaces extend_attention_fwd (nn/attention/triton_attn/extend_attention.py:16-327) and the
+// flashinfer ragged + paged + merge_state path (nn/attention/flashinfer_backend.py:400-444).
+//
+// Path in this file (all dtypes, every supported head shape): "row-streams".  New token t of
+// request b is an independent softmax stream over kv positions [0, prefix_b + t] (causal) or
+// [0, seq_b) (cross-attention), i.e. exactly one decode-attention row whose request index,
+// length and kv offset are per token.  A tiny expand kernel writes those three int32 arrays
+// and the decode kernel (decode_attention.hip: coalesced full-row gathers, G query heads per
+// KV read) does the rest.  KV traffic is O(sum L^2) instead of O(sum L^2 / BLOCK_M); the MFMA
+// tile kernel for long 16-bit prompts replaces it where that matters.
+#include "attention_internal.h"
+
+namespace sp {
+
+// per new token: request row, visible kv length, kv offset
+__global__ __launch_bounds__(256) void expand_rows_kernel(
+    int32_t* __restrict__ row_req, int32_t* __restrict__ row_len, int32_t* __restrict__ row_kv0,
+    const void* __restrict__ req_pool_indices, const void* __restrict__ seq_lens,
+    const void* __restrict__ kv_start, int idx64, const int32_t* __restrict__ extend_seq_lens,
+    const int32_t* __restrict__ extend_start_loc, int causal, int64_t num_tokens) {
+  const int b = blockIdx.x;
+  const int e = extend_seq_lens[b];
+  const int64_t s0 = extend_start_loc[b];
+  const int seq = (int)load_idx(seq_lens, b, idx64);
+  const int req = (int)load_idx(req_pool_indices, b, idx64);
+  const int kv0 = kv_start ? (int)load_idx(kv_start, b, idx64) : 0;
+  const int prefix = seq - e;
+  for (int i = threadIdx.x; i < e; i += 256) {
+    const int64_t t = s0 + i;
+    if (t >= num_tokens) break;  // never write beyond the caller's buffers
+    row_req[t] = req;
+    row_len[t] = causal ? prefix + i + 1 : seq;
+    row_kv0[t] = kv0;
+  }
+}
+
+}  // namespace sp
+
+using namespace sp;
+
+extern "C" size_t sp_extend_attention_workspace_bytes(int64_t num_tokens, int batch_size,
+                                                      int num_q_heads, int head_dim, int dtype) {
+  (void)batch_size; (void)num_q_heads; (void)head_dim; (void)dtype;
+  if (num_tokens <= 0) return 16;
+  return (size_t)num_tokens * 3 * sizeof(int32_t) + 64;
+}
+
+extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffer,
+                                   const void* v_buffer, const int32_t* req_to_token,
+                                   int64_t req_to_token_stride, const void* req_pool_indices,
+                                   const void* seq_lens, const void* kv_start, int idx64,
+                                   const int32_t* extend_seq_lens,
+                                   const int32_t* extend_start_loc, int batch_size,
+                                   int64_t num_tokens, int num_q_heads, int num_kv_heads,
+                                   int head_dim, int64_t q_stride, int64_t out_stride,
+                                   int64_t kv_buffer_stride, float sm_scale, float logit_cap,
+                                   int causal, int max_extend_len, int64_t max_seq_len,
+                                   void* workspace, size_t workspace_bytes, int dtype,
+                                   void* stream) {
+  SP_CHECK_ARG(out && q && k_buffer && v_buffer && req_to_token && req_pool_indices && seq_lens);
+  SP_CHECK_ARG(extend_seq_lens && extend_start_loc && batch_size >= 0 && num_tokens >= 0);
+  SP_CHECK_ARG(num_q_heads > 0 && num_kv_heads > 0 && num_q_heads % num_kv_heads == 0);
+  SP_CHECK_ARG(max_extend_len >= 0 && max_seq_len >= 0);
+  SP_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)k_buffer & 15) == 0 &&
+               ((uintptr_t)v_buffer & 15) == 0);
+  if (dtype != SP_F32 && dtype != SP_F16 && dtype != SP_BF16) return SP_ERR_UNSUPPORTED;
+  if (batch_size == 0 || num_tokens == 0) return SP_OK;
+  if (head_dim != 64 && head_dim != 128) return SP_ERR_UNSUPPORTED;
+  const int G = num_q_heads / num_kv_heads;
+  if (G != 1 && G != 2 && G != 4 && G != 8) return SP_ERR_UNSUPPORTED;
+  const int vec = dtype == SP_F32 ? 4 : 8;
+  SP_CHECK_ARG(q_stride % vec == 0 && kv_buffer_stride % vec == 0);
+  if (num_tokens > 0x7fffffffLL / 64) return SP_ERR_INVALID_ARG;
+  const size_t need =
+      sp_extend_attention_workspace_bytes(num_tokens, batch_size, num_q_heads, head_dim, dtype);
+  if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) return SP_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+
+  int32_t* row_req = (int32_t*)workspace;
+  int32_t* row_len = row_req + num_tokens;
+  int32_t* row_kv0 = row_len + num_tokens;
+  expand_rows_kernel<<<dim3(batch_size), 256, 0, st>>>(row_req, row_len, row_kv0, req_pool_indices,
+                                                       seq_lens, kv_start, idx64, extend_seq_lens,
+                                                       extend_start_loc, causal, num_tokens);
+  SP_LAUNCH_CHECK();
+
+  DecodeArgs a;
+  a.out = out; a.q = q; a.kbuf = (const char*)k_buffer; a.vbuf = (const char*)v_buffer;
+  a.r2t = req_to_token; a.r2t_stride = req_to_token_stride;
+  a.req_idx = row_req; a.seq_lens = row_len; a.kv_start = row_kv0; a.idx64 = 0;
+  a.bs = (int)num_tokens; a.Hq = num_q_heads; a.Hkv = num_kv_heads;
+  a.q_stride = q_stride; a.o_stride = out_stride; a.kv_stride = kv_buffer_stride;
+  a.sm_scale = sm_scale; a.logit_cap = logit_cap;
+  // one split per row: every row-stream is reduced inside one workgroup, no partials
+  int64_t chunk = ((max_seq_len > 0 ? max_seq_len : 1) + 3) / 4 * 4;
+  if (chunk > 0x7ffffff0LL) return SP_ERR_INVALID_ARG;
+  a.chunk = (int)chunk; a.num_splits = 1;
+  a.hh_shift = decode_heads_per_load_shift(num_kv_heads, head_dim, dtype, &a.head_groups);
+  a.part_o = nullptr; a.part_lse = nullptr;
+  return run_decode(a, head_dim, G, dtype, st);
+}

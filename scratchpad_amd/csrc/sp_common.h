@@ -1,0 +1,167 @@
+// Shared device helpers for the gfx950 kernels.  Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/scratchpad_hip.h"
+
+namespace sp {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+
+struct f16_tag {};
+struct bf16_tag {};
+struct f32_tag {};
+
+// ---- scalar conversions -------------------------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t lo16) {
+  return __builtin_bit_cast(float, lo16 << 16);
+}
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
+  __bf16 b = (__bf16)f;
+  return (uint32_t)__builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint32_t lo16) {
+  return (float)__builtin_bit_cast(_Float16, (uint16_t)lo16);
+}
+__device__ __forceinline__ uint32_t f32_to_f16_bits(float f) {
+  _Float16 h = (_Float16)f;
+  return (uint32_t)__builtin_bit_cast(uint16_t, h);
+}
+
+template <typename Tag>
+struct Elem;
+template <>
+struct Elem<f32_tag> {
+  static constexpr int kBytes = 4;
+  static constexpr int kVec = 4;  // elements per 16-byte lane access
+  typedef float storage;
+  static __device__ __forceinline__ float load(const void* p, int64_t i) { return ((const float*)p)[i]; }
+  static __device__ __forceinline__ void store(void* p, int64_t i, float v) { ((float*)p)[i] = v; }
+  static __device__ __forceinline__ float round(float v) { return v; }
+};
+template <>
+struct Elem<f16_tag> {
+  static constexpr int kBytes = 2;
+  static constexpr int kVec = 8;
+  typedef uint16_t storage;
+  static __device__ __forceinline__ float load(const void* p, int64_t i) {
+    return f16_bits_to_f32(((const uint16_t*)p)[i]);
+  }
+  static __device__ __forceinline__ void store(void* p, int64_t i, float v) {
+    ((uint16_t*)p)[i] = (uint16_t)f32_to_f16_bits(v);
+  }
+  static __device__ __forceinline__ float round(float v) { return (float)(_Float16)v; }
+};
+template <>
+struct Elem<bf16_tag> {
+  static constexpr int kBytes = 2;
+  static constexpr int kVec = 8;
+  typedef uint16_t storage;
+  static __device__ __forceinline__ float load(const void* p, int64_t i) {
+    return bf16_bits_to_f32(((const uint16_t*)p)[i]);
+  }
+  static __device__ __forceinline__ void store(void* p, int64_t i, float v) {
+    ((uint16_t*)p)[i] = (uint16_t)f32_to_bf16_bits(v);
+  }
+  static __device__ __forceinline__ float round(float v) { return (float)(__bf16)v; }
+};
+
+// ---- 16-byte vector <-> fp32 lanes --------------------------------------------------------
+template <typename Tag>
+__device__ __forceinline__ void unpack16(const u32x4& v, float* f);
+template <>
+__device__ __forceinline__ void unpack16<f32_tag>(const u32x4& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(float, v[i]);
+}
+template <>
+__device__ __forceinline__ void unpack16<bf16_tag>(const u32x4& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
+    f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+  }
+}
+template <>
+__device__ __forceinline__ void unpack16<f16_tag>(const u32x4& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f16x2_t h = __builtin_bit_cast(f16x2_t, v[i]);
+    f[2 * i] = (float)h[0];
+    f[2 * i + 1] = (float)h[1];
+  }
+}
+
+template <typename Tag>
+__device__ __forceinline__ u32x4 pack16(const float* f);
+template <>
+__device__ __forceinline__ u32x4 pack16<f32_tag>(const float* f) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(uint32_t, f[i]);
+  return v;
+}
+template <>
+__device__ __forceinline__ u32x4 pack16<bf16_tag>(const float* f) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bf16x2_t b;
+    b[0] = (__bf16)f[2 * i];
+    b[1] = (__bf16)f[2 * i + 1];
+    v[i] = __builtin_bit_cast(uint32_t, b);
+  }
+  return v;
+}
+template <>
+__device__ __forceinline__ u32x4 pack16<f16_tag>(const float* f) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f16x2_t h;
+    h[0] = (_Float16)f[2 * i];
+    h[1] = (_Float16)f[2 * i + 1];
+    v[i] = __builtin_bit_cast(uint32_t, h);
+  }
+  return v;
+}
+
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *(const u32x4*)p; }
+__device__ __forceinline__ void st16(void* p, const u32x4& v) { *(u32x4*)p = v; }
+
+// ---- wave reductions ------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// index arrays that are int64 in eager mode and int32 under graph replay
+__device__ __forceinline__ int64_t load_idx(const void* p, int i, int idx64) {
+  return idx64 ? ((const int64_t*)p)[i] : (int64_t)((const int32_t*)p)[i];
+}
+
+}  // namespace sp
+
+#define SP_CHECK_ARG(cond) \
+  do {                     \
+    if (!(cond)) return SP_ERR_INVALID_ARG; \
+  } while (0)
+
+#define SP_LAUNCH_CHECK()                              \
+  do {                                                 \
+    if (hipGetLastError() != hipSuccess) return SP_ERR_LAUNCH; \
+  } while (0)
+
+#define SP_DISPATCH_DTYPE(dtype, ...)                                   \
+  do {                                                                  \
+    if ((dtype) == SP_F32) { typedef sp::f32_tag Tag; __VA_ARGS__; }    \
+    else if ((dtype) == SP_F16) { typedef sp::f16_tag Tag; __VA_ARGS__; } \
+    else if ((dtype) == SP_BF16) { typedef sp::bf16_tag Tag; __VA_ARGS__; } \
+    else return SP_ERR_UNSUPPORTED;                                     \
+  } while (0)

@@ -1,0 +1,173 @@
+"""Tensor-parallel group + collectives: one process per GPU over RCCL / xGMI.
+
+Mirrors the parts of distributed/parallel_state.py the hot path uses - GroupCoordinator
+(122-221), all_reduce/_all_reduce (304-353) with the custom all-reduce slot ``ca_comm``
+(266-267, 326-347), all_gather (355-381), init_distributed_environment /
+initialize_model_parallel (881-997) - and distributed/communication_op.py:9-33.
+
+``backend="nccl"`` IS RCCL on ROCm; ``backend="gloo"`` runs the same code on CPU (tests).
+PP groups are not built: no reference model uses them.
+"""
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GroupCoordinator:
+    """A process group + its collectives (parallel_state.py:122-221, 304-381)."""
+
+    def __init__(self, group_ranks, local_rank: int, backend: str):
+        self.rank = dist.get_rank()
+        self.local_rank = local_rank
+        self.device_group = None
+        self.cpu_group = None
+        for ranks in group_ranks:
+            device_group = dist.new_group(ranks, backend=backend)
+            # a gloo twin for host-side object broadcast (parallel_state.py:176-187)
+            cpu_group = dist.new_group(ranks, backend="gloo")
+            if self.rank in ranks:
+                self.ranks = ranks
+                self.world_size = len(ranks)
+                self.rank_in_group = ranks.index(self.rank)
+                self.device_group = device_group
+                self.cpu_group = cpu_group
+        assert self.device_group is not None
+        # custom all-reduce slot: an object with should_custom_ar(t) / custom_all_reduce(t)
+        # (never constructed by the reference: parallel_state.py:174, 266); the direct xGMI
+        # all-reduce plugs in here
+        self.ca_comm = None
+
+    @property
+    def first_rank(self):
+        return self.ranks[0]
+
+    @property
+    def is_first_rank(self):
+        return self.rank == self.first_rank
+
+    def all_reduce(self, input_: torch.Tensor) -> torch.Tensor:
+        """SUM all-reduce; applied in place or out of place - always use the return value."""
+        if self.world_size == 1:
+            return input_
+        return self._all_reduce(input_)
+
+    def _all_reduce(self, input_: torch.Tensor) -> torch.Tensor:
+        ca_comm = self.ca_comm
+        if ca_comm is not None and ca_comm.should_custom_ar(input_):
+            out = ca_comm.custom_all_reduce(input_)
+            if out is not None:
+                return out
+        dist.all_reduce(input_, group=self.device_group)
+        return input_
+
+    def all_gather(self, input_: torch.Tensor, dim: int = -1) -> torch.Tensor:
+        world_size = self.world_size
+        if world_size == 1:
+            return input_
+        assert -input_.dim() <= dim < input_.dim(), f"Invalid dim ({dim}) for shape {input_.size()}"
+        if dim < 0:
+            dim += input_.dim()
+        input_size = input_.size()
+        output = torch.empty((world_size,) + input_size, dtype=input_.dtype, device=input_.device)
+        dist.all_gather_into_tensor(output, input_.contiguous(), group=self.device_group)
+        output = output.movedim(0, dim)
+        return output.reshape(input_size[:dim] + (world_size * input_size[dim],) + input_size[dim + 1:])
+
+    def broadcast_object(self, obj=None, src: int = 0):
+        if self.world_size == 1:
+            return obj
+        box = [obj]
+        dist.broadcast_object_list(box, src=self.ranks[src], group=self.cpu_group)
+        return box[0]
+
+    def barrier(self):
+        dist.barrier(group=self.cpu_group)
+
+
+_TP: Optional[GroupCoordinator] = None
+
+
+def init_distributed_environment(world_size: int = 1, rank: int = 0,
+                                 distributed_init_method: str = "env://", local_rank: int = 0,
+                                 backend: str = "nccl"):
+    """parallel_state.py:881-930."""
+    if not dist.is_initialized():
+        kwargs = {}
+        if backend == "nccl":
+            kwargs["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, init_method=distributed_init_method,
+                                world_size=world_size, rank=rank, **kwargs)
+
+
+def initialize_model_parallel(tensor_model_parallel_size: int = 1, backend: Optional[str] = None,
+                              local_rank: int = 0) -> None:
+    """parallel_state.py:933-997 (TP groups only): consecutive ranks form a TP group."""
+    global _TP
+    world_size = dist.get_world_size() if dist.is_initialized() else 1
+    backend = backend or (dist.get_backend() if dist.is_initialized() else "gloo")
+    assert world_size % tensor_model_parallel_size == 0
+    if not dist.is_initialized():
+        assert tensor_model_parallel_size == 1
+        _TP = _SingleRankGroup()
+        return
+    n = world_size // tensor_model_parallel_size
+    group_ranks = [list(range(i * tensor_model_parallel_size, (i + 1) * tensor_model_parallel_size))
+                   for i in range(n)]
+    _TP = GroupCoordinator(group_ranks, local_rank, backend)
+
+
+class _SingleRankGroup:
+    """TP=1 without a process group (single-GPU engine): every collective is the identity."""
+    world_size = 1
+    rank_in_group = 0
+    ca_comm = None
+
+    def all_reduce(self, input_):
+        return input_
+
+    def all_gather(self, input_, dim: int = -1):
+        return input_
+
+    def broadcast_object(self, obj=None, src: int = 0):
+        return obj
+
+    def barrier(self):
+        pass
+
+
+def model_parallel_is_initialized() -> bool:
+    return _TP is not None
+
+
+def destroy_model_parallel():
+    global _TP
+    _TP = None
+
+
+def get_tp_group():
+    assert _TP is not None, "tensor model parallel group is not initialized"
+    return _TP
+
+
+def get_tensor_model_parallel_world_size() -> int:
+    return get_tp_group().world_size
+
+
+def get_tensor_model_parallel_rank() -> int:
+    return get_tp_group().rank_in_group
+
+
+def tensor_model_parallel_all_reduce(input_: torch.Tensor) -> torch.Tensor:
+    """communication_op.py:9-11."""
+    return get_tp_group().all_reduce(input_)
+
+
+def tensor_model_parallel_all_gather(input_: torch.Tensor, dim: int = -1) -> torch.Tensor:
+    """communication_op.py:14-18."""
+    return get_tp_group().all_gather(input_, dim)
+
+
+def divide(numerator: int, denominator: int) -> int:
+    assert numerator % denominator == 0, f"{numerator} is not divisible by {denominator}"
+    return numerator // denominator

@@ -1,0 +1,348 @@
+"""Llama decoder hosted on the HIP hot path.
+
+Re-hosts nn/models/llama/llama.py (LlamaMLP 31-66, LlamaAttention 69-154, LlamaDecoderLayer
+157-224, LlamaModel 227-272, LlamaForCausalLM 275-311): same module tree and parameter names
+(so reference checkpoints / state_dicts map 1:1), same op order and residual protocol.  The
+callers of the hot path keep the reference's tensor-parallel shard math:
+QKVParallelLinear (nn/layers/linear.py:696-760), MergedColumnParallelLinear (423-470),
+RowParallelLinear + all-reduce (1033-1155), VocabParallelEmbedding + all-reduce
+(nn/layers/vocab_parallel_embedding.py:452-472), LogitsProcessor pruning + all-gather
+(nn/layers/logits_processor.py:179-203, 344-376).  GEMMs stay on torch (hipBLASLt/rocBLAS):
+they are outside the path this package re-kernels.
+"""
+from dataclasses import dataclass
+from typing import Any, Dict, Iterable, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .attention import RadixAttention
+from .distributed import (divide, get_tensor_model_parallel_rank,
+                          get_tensor_model_parallel_world_size, tensor_model_parallel_all_gather,
+                          tensor_model_parallel_all_reduce)
+from .forward_info import ForwardBatch
+from .layers import RMSNorm, SiluAndMul, get_rope
+
+
+@dataclass
+class LogitsProcessorOutput:
+    next_token_logits: torch.Tensor
+    hidden_states: Optional[torch.Tensor] = None
+
+
+# --------------------------------------------------------------------------- sharded linears
+class _ShardedLinear(nn.Module):
+    def __init__(self, in_features: int, out_features: int, dtype=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_features, in_features, dtype=dtype),
+                                   requires_grad=False)
+
+
+class QKVParallelLinear(_ShardedLinear):
+    """linear.py:696-760: per-rank output = [q (Hq/tp*D) | k (Hkv_l*D) | v (Hkv_l*D)]; KV heads
+    are replicated when tp >= total_kv_heads."""
+
+    def __init__(self, hidden_size: int, head_size: int, total_num_heads: int,
+                 total_num_kv_heads: Optional[int] = None, dtype=None):
+        tp = get_tensor_model_parallel_world_size()
+        self.head_size = head_size
+        self.total_num_heads = total_num_heads
+        self.total_num_kv_heads = total_num_kv_heads or total_num_heads
+        self.num_heads = divide(total_num_heads, tp)
+        if tp >= self.total_num_kv_heads:
+            self.num_kv_heads = 1
+            self.num_kv_head_replicas = divide(tp, self.total_num_kv_heads)
+        else:
+            self.num_kv_heads = divide(self.total_num_kv_heads, tp)
+            self.num_kv_head_replicas = 1
+        super().__init__(hidden_size, (self.num_heads + 2 * self.num_kv_heads) * head_size, dtype)
+
+    def shard_from_full(self, full: torch.Tensor) -> torch.Tensor:
+        """Slice this rank's rows out of the tp=1 merged [q|k|v] weight."""
+        rank = get_tensor_model_parallel_rank()
+        D = self.head_size
+        qn, kn = self.total_num_heads * D, self.total_num_kv_heads * D
+        q, k, v = full[:qn], full[qn:qn + kn], full[qn + kn:qn + 2 * kn]
+        qs = q[rank * self.num_heads * D:(rank + 1) * self.num_heads * D]
+        kv_rank = rank // self.num_kv_head_replicas
+        ks = k[kv_rank * self.num_kv_heads * D:(kv_rank + 1) * self.num_kv_heads * D]
+        vs = v[kv_rank * self.num_kv_heads * D:(kv_rank + 1) * self.num_kv_heads * D]
+        return torch.cat((qs, ks, vs), 0)
+
+    def forward(self, x):
+        return F.linear(x, self.weight), None
+
+
+class MergedColumnParallelLinear(_ShardedLinear):
+    """linear.py:423-470: gate and up projections merged, each sharded along its output dim."""
+
+    def __init__(self, input_size: int, output_sizes, dtype=None):
+        tp = get_tensor_model_parallel_world_size()
+        self.output_sizes = list(output_sizes)
+        self.shard_sizes = [divide(s, tp) for s in self.output_sizes]
+        super().__init__(input_size, sum(self.shard_sizes), dtype)
+
+    def shard_from_full(self, full: torch.Tensor) -> torch.Tensor:
+        rank = get_tensor_model_parallel_rank()
+        parts, off = [], 0
+        for size, shard in zip(self.output_sizes, self.shard_sizes):
+            parts.append(full[off + rank * shard: off + (rank + 1) * shard])
+            off += size
+        return torch.cat(parts, 0)
+
+    def forward(self, x):
+        return F.linear(x, self.weight), None
+
+
+class RowParallelLinear(_ShardedLinear):
+    """linear.py:1033-1155: input dim sharded; SUM all-reduce of the partial outputs (in place)."""
+
+    def __init__(self, input_size: int, output_size: int, dtype=None, reduce_results: bool = True):
+        tp = get_tensor_model_parallel_world_size()
+        self.tp_size = tp
+        self.input_size_per_partition = divide(input_size, tp)
+        self.reduce_results = reduce_results
+        super().__init__(self.input_size_per_partition, output_size, dtype)
+
+    def shard_from_full(self, full: torch.Tensor) -> torch.Tensor:
+        rank = get_tensor_model_parallel_rank()
+        n = self.input_size_per_partition
+        return full[:, rank * n:(rank + 1) * n]
+
+    def forward(self, x):
+        out = F.linear(x, self.weight)
+        if self.reduce_results and self.tp_size > 1:
+            out = tensor_model_parallel_all_reduce(out)
+        return out, None
+
+
+class VocabParallelEmbedding(nn.Module):
+    """vocab_parallel_embedding.py:172, 452-472: vocab rows sharded; masked lookup + all-reduce."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, dtype=None, padding_size: int = 64):
+        super().__init__()
+        tp = get_tensor_model_parallel_world_size()
+        self.tp_size = tp
+        self.org_vocab_size = num_embeddings
+        padded = (num_embeddings + padding_size - 1) // padding_size * padding_size
+        while padded % tp:
+            padded += padding_size
+        self.num_embeddings_padded = padded
+        self.num_embeddings_per_partition = padded // tp
+        rank = get_tensor_model_parallel_rank()
+        self.vocab_start_index = rank * self.num_embeddings_per_partition
+        self.vocab_end_index = self.vocab_start_index + self.num_embeddings_per_partition
+        self.weight = nn.Parameter(
+            torch.zeros(self.num_embeddings_per_partition, embedding_dim, dtype=dtype),
+            requires_grad=False)
+
+    def shard_from_full(self, full: torch.Tensor) -> torch.Tensor:
+        out = torch.zeros_like(self.weight, device=full.device)
+        hi = min(self.vocab_end_index, full.shape[0])
+        if hi > self.vocab_start_index:
+            out[: hi - self.vocab_start_index] = full[self.vocab_start_index:hi]
+        return out
+
+    def forward(self, input_):
+        if self.tp_size > 1:
+            mask = (input_ < self.vocab_start_index) | (input_ >= self.vocab_end_index)
+            masked = (input_ - self.vocab_start_index).masked_fill(mask, 0)
+            out = F.embedding(masked, self.weight)
+            out.masked_fill_(mask.unsqueeze(-1), 0)
+            return tensor_model_parallel_all_reduce(out)
+        return F.embedding(input_, self.weight)
+
+
+class ParallelLMHead(VocabParallelEmbedding):
+    pass
+
+
+class LogitsProcessor(nn.Module):
+    """logits_processor.py:140-376 for the greedy/throughput path: keep the last token of every
+    sequence on extend, matmul with the (vocab-sharded) head, all-gather, slice, fp32."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.do_tensor_parallel_all_gather = get_tensor_model_parallel_world_size() > 1
+
+    def forward(self, input_ids, hidden_states, lm_head, forward_batch: ForwardBatch):
+        if forward_batch.forward_mode.is_decode_or_idle():
+            pruned = hidden_states
+        else:
+            last_index = torch.cumsum(forward_batch.extend_seq_lens, dim=0) - 1
+            pruned = hidden_states[last_index]
+        logits = torch.matmul(pruned.to(lm_head.weight.dtype), lm_head.weight.T)
+        if self.do_tensor_parallel_all_gather:
+            logits = tensor_model_parallel_all_gather(logits)
+        logits = logits[:, : self.config.vocab_size].float()
+        return LogitsProcessorOutput(next_token_logits=logits)
+
+
+# --------------------------------------------------------------------------- decoder
+class LlamaMLP(nn.Module):
+    def __init__(self, hidden_size: int, intermediate_size: int, hidden_act: str, dtype=None):
+        super().__init__()
+        self.gate_up_proj = MergedColumnParallelLinear(hidden_size, [intermediate_size] * 2, dtype)
+        self.down_proj = RowParallelLinear(intermediate_size, hidden_size, dtype)
+        if hidden_act != "silu":
+            raise ValueError(f"Unsupported activation: {hidden_act}. Only silu is supported for now.")
+        self.act_fn = SiluAndMul()
+
+    def forward(self, x):
+        gate_up, _ = self.gate_up_proj(x)
+        x = self.act_fn(gate_up)
+        x, _ = self.down_proj(x)
+        return x
+
+
+class LlamaAttention(nn.Module):
+    def __init__(self, config, hidden_size: int, num_heads: int, num_kv_heads: int,
+                 layer_id: int = 0, rope_theta: float = 10000,
+                 rope_scaling: Optional[Dict[str, Any]] = None, rope_is_neox_style: bool = True,
+                 max_position_embeddings: int = 8192, dtype=None):
+        super().__init__()
+        self.hidden_size = hidden_size
+        tp_size = get_tensor_model_parallel_world_size()
+        self.total_num_heads = num_heads
+        assert self.total_num_heads % tp_size == 0
+        self.num_heads = self.total_num_heads // tp_size
+        self.total_num_kv_heads = num_kv_heads
+        if self.total_num_kv_heads >= tp_size:
+            assert self.total_num_kv_heads % tp_size == 0
+        else:
+            assert tp_size % self.total_num_kv_heads == 0
+        self.num_kv_heads = max(1, self.total_num_kv_heads // tp_size)
+        self.head_dim = getattr(config, "head_dim", None) or self.hidden_size // self.total_num_heads
+        self.q_size = self.num_heads * self.head_dim
+        self.kv_size = self.num_kv_heads * self.head_dim
+        self.scaling = self.head_dim ** -0.5
+        self.rope_theta = rope_theta
+        self.max_position_embeddings = max_position_embeddings
+        self.qkv_proj = QKVParallelLinear(hidden_size, self.head_dim, self.total_num_heads,
+                                          self.total_num_kv_heads, dtype)
+        self.o_proj = RowParallelLinear(self.total_num_heads * self.head_dim, hidden_size, dtype)
+        self.rotary_emb = get_rope(self.head_dim, rotary_dim=self.head_dim,
+                                   max_position=max_position_embeddings, base=rope_theta,
+                                   rope_scaling=rope_scaling, is_neox_style=rope_is_neox_style,
+                                   dtype=dtype)
+        self.attn = RadixAttention(self.num_heads, self.head_dim, self.scaling,
+                                   num_kv_heads=self.num_kv_heads, layer_id=layer_id)
+
+    def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor,
+                forward_batch: ForwardBatch) -> torch.Tensor:
+        qkv, _ = self.qkv_proj(hidden_states)
+        q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+        q, k = self.rotary_emb(positions, q, k)       # in place on the qkv views
+        attn_output = self.attn(q, k, v, forward_batch)
+        output, _ = self.o_proj(attn_output)
+        return output
+
+
+class LlamaDecoderLayer(nn.Module):
+    def __init__(self, config, layer_id: int = 0, dtype=None):
+        super().__init__()
+        self.hidden_size = config.hidden_size
+        rope_theta = getattr(config, "rope_theta", 10000)
+        rope_scaling = getattr(config, "rope_scaling", None)
+        rope_is_neox_style = getattr(config, "rope_is_neox_style", True)
+        max_position_embeddings = getattr(config, "max_position_embeddings", 8192)
+        self.self_attn = LlamaAttention(
+            config=config, hidden_size=self.hidden_size, num_heads=config.num_attention_heads,
+            num_kv_heads=config.num_key_value_heads, layer_id=layer_id, rope_theta=rope_theta,
+            rope_scaling=rope_scaling, rope_is_neox_style=rope_is_neox_style,
+            max_position_embeddings=max_position_embeddings, dtype=dtype)
+        self.mlp = LlamaMLP(self.hidden_size, config.intermediate_size, config.hidden_act, dtype)
+        self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, positions, hidden_states, forward_batch: ForwardBatch,
+                residual: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions=positions, hidden_states=hidden_states,
+                                       forward_batch=forward_batch)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        hidden_states = self.mlp(hidden_states)
+        return hidden_states, residual
+
+
+class LlamaModel(nn.Module):
+    def __init__(self, config, dtype=None):
+        super().__init__()
+        self.config = config
+        self.vocab_size = config.vocab_size
+        self.embed_tokens = VocabParallelEmbedding(config.vocab_size, config.hidden_size, dtype)
+        self.layers = nn.ModuleList(
+            [LlamaDecoderLayer(config, i, dtype) for i in range(config.num_hidden_layers)])
+        self.norm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, input_ids, positions, forward_batch: ForwardBatch,
+                input_embeds: torch.Tensor = None) -> torch.Tensor:
+        hidden_states = self.embed_tokens(input_ids) if input_embeds is None else input_embeds
+        residual = None
+        for layer in self.layers:
+            hidden_states, residual = layer(positions, hidden_states, forward_batch, residual)
+        hidden_states, _ = self.norm(hidden_states, residual)
+        return hidden_states
+
+
+class LlamaForCausalLM(nn.Module):
+    def __init__(self, config, dtype=None):
+        super().__init__()
+        self.config = config
+        self.model = LlamaModel(config, dtype)
+        if getattr(config, "tie_word_embeddings", False):
+            self.lm_head = self.model.embed_tokens
+        else:
+            self.lm_head = ParallelLMHead(config.vocab_size, config.hidden_size, dtype)
+        self.logits_processor = LogitsProcessor(config)
+
+    @torch.no_grad()
+    def forward(self, input_ids, positions, forward_batch: ForwardBatch,
+                input_embeds: torch.Tensor = None) -> LogitsProcessorOutput:
+        hidden_states = self.model(input_ids, positions, forward_batch, input_embeds)
+        return self.logits_processor(input_ids, hidden_states, self.lm_head, forward_batch)
+
+    # ---- weights ------------------------------------------------------------------------
+    def load_full_state_dict(self, full: Dict[str, torch.Tensor]) -> None:
+        """Load a tp=1 state_dict in the reference's parameter naming (merged qkv_proj /
+        gate_up_proj), slicing this rank's shard of every tensor-parallel parameter."""
+        own = dict(self.named_parameters())
+        mods = dict(self.named_modules())
+        for name, param in own.items():
+            src = full[name]
+            mod = mods[name.rsplit(".", 1)[0]]
+            if hasattr(mod, "shard_from_full"):
+                src = mod.shard_from_full(src)
+            if src.shape != param.shape:
+                raise RuntimeError(f"{name}: shard shape {tuple(src.shape)} != {tuple(param.shape)}")
+            param.data.copy_(src.to(param.dtype))
+
+    def load_weights(self, weights: Iterable[Tuple[str, torch.Tensor]]) -> None:
+        """HF checkpoint names (q_proj/k_proj/v_proj, gate_proj/up_proj) -> merged parameters
+        (llama.py:364-405); builds the tp=1 merged dict, then shards."""
+        cfg = self.config
+        D = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
+        staged: Dict[str, Dict[str, torch.Tensor]] = {}
+        full: Dict[str, torch.Tensor] = {}
+        for name, w in weights:
+            if "rotary_emb.inv_freq" in name or "rotary_emb.cos_cached" in name or \
+                    "rotary_emb.sin_cached" in name:
+                continue
+            for tag, merged in (("q_proj", "qkv_proj"), ("k_proj", "qkv_proj"), ("v_proj", "qkv_proj"),
+                                ("gate_proj", "gate_up_proj"), ("up_proj", "gate_up_proj")):
+                if "." + tag + "." in name:
+                    staged.setdefault(name.replace(tag, merged), {})[tag] = w
+                    break
+            else:
+                full[name] = w
+        for name, parts in staged.items():
+            order = ("q_proj", "k_proj", "v_proj") if "qkv_proj" in name else ("gate_proj", "up_proj")
+            full[name] = torch.cat([parts[t] for t in order], 0)
+        del D
+        self.load_full_state_dict(full)

@@ -1,0 +1,290 @@
+"""Forward-batch runner: pools, attention backend, eager + HIP-graph decode, greedy sampling.
+
+Mirrors the hot-path parts of model_executor/model_runner.py (init_memory_pool 360-442,
+init_attention_backend 453-470, forward/forward_decode/forward_extend 506-537, sample 539-563),
+model_executor/cuda_graph_runner.py:144-521 (static-buffer capture / padded replay) and
+managers/tp_worker.py:164-169 (forward_batch_generation).  Weight loading, offload, toppings,
+speculative decoding and the NVML/zmq control plane are out of scope.
+"""
+import bisect
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+from . import distributed as dist_
+from .attention import HipAttnBackend
+from .forward_info import CaptureHiddenMode, ForwardBatch, ForwardMode, ModelWorkerBatch
+from .llama import LlamaForCausalLM, LogitsProcessorOutput
+from .pool import MHATokenToKVPool, ReqToTokenPool, TokenToKVPoolAllocator
+
+
+@dataclass
+class ModelConfig:
+    """The head/shape math of config/model_config.py:47-99, 155-163 (read-only use)."""
+    hidden_size: int
+    intermediate_size: int
+    num_hidden_layers: int
+    num_attention_heads: int
+    num_key_value_heads: int
+    vocab_size: int
+    context_len: int = 4096
+    head_dim: Optional[int] = None
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    rope_scaling: Optional[dict] = None
+    max_position_embeddings: int = 8192
+    tie_word_embeddings: bool = False
+    hidden_act: str = "silu"
+    is_encoder_decoder: bool = False
+
+    def __post_init__(self):
+        if self.head_dim is None:
+            self.head_dim = self.hidden_size // self.num_attention_heads
+
+    def get_num_kv_heads(self, tp_size: int) -> int:
+        # model_config.py:155-163: replicate KV heads when tp > total_kv
+        return max(1, self.num_key_value_heads // tp_size)
+
+    @classmethod
+    def llama3_8b(cls, context_len: int = 8192):
+        return cls(4096, 14336, 32, 32, 8, 128256, context_len=context_len,
+                   max_position_embeddings=max(8192, context_len))
+
+    @classmethod
+    def llama32_1b(cls, context_len: int = 4096):
+        return cls(2048, 8192, 16, 32, 8, 128256, context_len=context_len, tie_word_embeddings=True,
+                   rope_scaling={"rope_type": "llama3", "factor": 32.0, "low_freq_factor": 1.0,
+                                 "high_freq_factor": 4.0, "original_max_position_embeddings": 8192},
+                   max_position_embeddings=max(8192, context_len))
+
+    @classmethod
+    def llama3_70b(cls, context_len: int = 8192):
+        return cls(8192, 28672, 80, 64, 8, 128256, context_len=context_len,
+                   max_position_embeddings=max(8192, context_len))
+
+
+@dataclass
+class ServerArgs:
+    """The path-shaping flags of server/args.py (defaults listed in SURVEY.md section 5)."""
+    attention_backend: str = "hip"
+    mem_fraction_static: float = 0.8
+    max_running_requests: Optional[int] = None
+    max_total_tokens: Optional[int] = None
+    disable_cuda_graph: bool = False
+    # the reference caps graphs at bs 160 (args.py:186-187); bs=256 is the headline config here
+    cuda_graph_max_bs: int = 256
+    cuda_graph_bs: Optional[List[int]] = None
+    kv_cache_dtype: str = "auto"
+
+
+def get_batch_sizes_to_capture(server_args: ServerArgs, max_reqs: int) -> List[int]:
+    """cuda_graph_runner.py:92-128 with the bucket list extended to cuda_graph_max_bs."""
+    bs = server_args.cuda_graph_bs
+    if bs is None:
+        bs = [1, 2, 4, 8] + list(range(16, server_args.cuda_graph_max_bs + 1, 8))
+    return sorted({b for b in bs if b <= max_reqs and b <= server_args.cuda_graph_max_bs})
+
+
+class ModelRunner:
+    def __init__(self, model_config: ModelConfig, server_args: Optional[ServerArgs] = None,
+                 tp_rank: int = 0, tp_size: int = 1, device: str = "cuda",
+                 dtype: torch.dtype = torch.bfloat16, gpu_id: int = 0, seed: int = 0,
+                 init_weights: bool = True):
+        self.model_config = model_config
+        self.server_args = server_args or ServerArgs()
+        self.tp_rank, self.tp_size = tp_rank, tp_size
+        self.dtype = dtype
+        self.kv_cache_dtype = dtype
+        self.gpu_id = gpu_id
+        if device == "cuda":
+            if not torch.cuda.is_available():
+                raise RuntimeError("ModelRunner needs a GPU: the hot path has no CPU fallback")
+            torch.cuda.set_device(gpu_id)
+            self.device = f"cuda:{gpu_id}"
+        else:
+            raise RuntimeError(f"unsupported device {device!r} (reference: model_runner.py:136-140)")
+        if not dist_.model_parallel_is_initialized():
+            dist_.initialize_model_parallel(tp_size, local_rank=gpu_id)
+        assert dist_.get_tensor_model_parallel_world_size() == tp_size
+        self.sliding_window_size = None
+        self.load_model(seed, init_weights)
+        self.init_memory_pool()
+        self.init_attention_backend()
+        self.graph_runner: Optional[HipGraphRunner] = None
+
+    # ------------------------------------------------------------------ model
+    def load_model(self, seed: int, init_weights: bool):
+        with torch.device(self.device):
+            self.model = LlamaForCausalLM(self.model_config, dtype=self.dtype).eval()
+        for p in self.model.parameters():
+            if p.dtype != self.dtype:
+                p.data = p.data.to(self.dtype)
+        if init_weights:
+            g = torch.Generator(device=self.device).manual_seed(seed + 1000 * self.tp_rank)
+            for name, p in self.model.named_parameters():
+                if "norm" in name:
+                    p.data.fill_(1.0)
+                else:
+                    p.data.normal_(0.0, 0.02, generator=g)
+
+    # ------------------------------------------------------------------ memory
+    def profile_max_num_token(self) -> int:
+        """model_runner.py:325-358: tokens that fit in mem_fraction_static of the free memory."""
+        free, _total = torch.cuda.mem_get_info()
+        cell = (self.model_config.get_num_kv_heads(self.tp_size) * self.model_config.head_dim *
+                self.model_config.num_hidden_layers * 2 * torch.finfo(self.kv_cache_dtype).bits // 8)
+        return int(free * self.server_args.mem_fraction_static // cell)
+
+    def init_memory_pool(self):
+        a = self.server_args
+        self.max_total_num_tokens = a.max_total_tokens or self.profile_max_num_token()
+        if self.max_total_num_tokens <= 0:
+            raise RuntimeError("Not enough memory. Please try to increase --mem-fraction-static.")
+        max_reqs = a.max_running_requests
+        if max_reqs is None:
+            max_reqs = min(max(int(self.max_total_num_tokens / self.model_config.context_len * 512),
+                               2048), 4096)
+        self.max_running_requests = max_reqs
+        self.req_to_token_pool = ReqToTokenPool(max_reqs + 1, self.model_config.context_len + 4,
+                                                self.device)
+        self.token_to_kv_pool = MHATokenToKVPool(
+            self.max_total_num_tokens, 1, self.kv_cache_dtype,
+            self.model_config.get_num_kv_heads(self.tp_size), self.model_config.head_dim,
+            self.model_config.num_hidden_layers, self.device)
+        self.token_to_kv_pool_allocator = TokenToKVPoolAllocator(
+            self.max_total_num_tokens, self.kv_cache_dtype, self.device, self.token_to_kv_pool)
+
+    def init_attention_backend(self):
+        if self.server_args.attention_backend != "hip":
+            raise ValueError(f"Invalid attention backend: {self.server_args.attention_backend}")
+        self.attn_backend = HipAttnBackend(self)
+
+    def init_cuda_graphs(self):
+        """model_runner.py:490-504."""
+        if self.server_args.disable_cuda_graph:
+            return
+        self.graph_runner = HipGraphRunner(self)
+
+    # ------------------------------------------------------------------ forward
+    def forward_decode(self, forward_batch: ForwardBatch) -> LogitsProcessorOutput:
+        self.attn_backend.init_forward_metadata(forward_batch)
+        return self.model.forward(forward_batch.input_ids, forward_batch.positions, forward_batch)
+
+    def forward_extend(self, forward_batch: ForwardBatch) -> LogitsProcessorOutput:
+        self.attn_backend.init_forward_metadata(forward_batch)
+        return self.model.forward(forward_batch.input_ids, forward_batch.positions, forward_batch)
+
+    def forward(self, forward_batch: ForwardBatch) -> LogitsProcessorOutput:
+        if (forward_batch.forward_mode.is_cuda_graph() and self.graph_runner is not None
+                and self.graph_runner.can_run(forward_batch)):
+            return self.graph_runner.replay(forward_batch)
+        if forward_batch.forward_mode.is_decode():
+            return self.forward_decode(forward_batch)
+        if forward_batch.forward_mode.is_extend():
+            return self.forward_extend(forward_batch)
+        raise ValueError(f"Invalid forward mode: {forward_batch.forward_mode}")
+
+    def sample(self, logits_output: LogitsProcessorOutput, forward_batch: ForwardBatch) -> torch.Tensor:
+        """Greedy path of nn/layers/sampler.py:63-67."""
+        return torch.argmax(logits_output.next_token_logits, dim=-1)
+
+
+class HipGraphRunner:
+    """HIP-graph capture/replay of the decode step (cuda_graph_runner.py:144-521): static input
+    buffers, one graph per batch-size bucket, padded replay (padded rows: seq_len = fill value,
+    out_cache_loc = 0 = the dummy slot)."""
+
+    def __init__(self, model_runner: ModelRunner):
+        self.model_runner = model_runner
+        self.graphs: Dict[int, torch.cuda.CUDAGraph] = {}
+        self.output_buffers: Dict[int, LogitsProcessorOutput] = {}
+        self.capture_bs = get_batch_sizes_to_capture(model_runner.server_args,
+                                                     model_runner.req_to_token_pool.size)
+        self.max_bs = max(self.capture_bs)
+        backend = model_runner.attn_backend
+        backend.init_cuda_graph_state(self.max_bs)
+        self.seq_len_fill_value = backend.get_cuda_graph_seq_len_fill_value()
+        dev = model_runner.device
+        # graph inputs (cuda_graph_runner.py:191-199): int32 indices under graph replay
+        self.input_ids = torch.zeros((self.max_bs,), dtype=torch.int64, device=dev)
+        self.req_pool_indices = torch.zeros((self.max_bs,), dtype=torch.int32, device=dev)
+        self.seq_lens = torch.full((self.max_bs,), self.seq_len_fill_value, dtype=torch.int32, device=dev)
+        self.out_cache_loc = torch.zeros((self.max_bs,), dtype=torch.int64, device=dev)
+        self.positions = torch.zeros((self.max_bs,), dtype=torch.int64, device=dev)
+        self.pool = None
+        self.capture()
+
+    def can_run(self, forward_batch: ForwardBatch) -> bool:
+        return forward_batch.batch_size <= self.max_bs
+
+    def capture(self):
+        for bs in reversed(self.capture_bs):
+            graph, out = self.capture_one_batch_size(bs)
+            self.graphs[bs] = graph
+            self.output_buffers[bs] = out
+
+    def capture_one_batch_size(self, bs: int):
+        mr = self.model_runner
+        fb = ForwardBatch(
+            forward_mode=ForwardMode.DECODE, batch_size=bs, input_ids=self.input_ids[:bs],
+            req_pool_indices=self.req_pool_indices[:bs], seq_lens=self.seq_lens[:bs],
+            out_cache_loc=self.out_cache_loc[:bs], seq_lens_sum=int(self.seq_len_fill_value) * bs,
+            positions=self.positions[:bs], req_to_token_pool=mr.req_to_token_pool,
+            token_to_kv_pool=mr.token_to_kv_pool, attn_backend=mr.attn_backend,
+            capture_hidden_mode=CaptureHiddenMode.NULL)
+        mr.attn_backend.init_forward_metadata_capture_cuda_graph(
+            bs, bs, fb.req_pool_indices, fb.seq_lens, None, ForwardMode.DECODE, None)
+
+        def run_once():
+            return mr.model.forward(fb.input_ids, fb.positions, fb)
+
+        # warm up on a side stream before capturing (cuda_graph_runner.py:400-412)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                run_once()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, pool=self.pool):
+            out = run_once()
+        self.pool = graph.pool()
+        return graph, out
+
+    def replay(self, forward_batch: ForwardBatch) -> LogitsProcessorOutput:
+        raw_bs = forward_batch.batch_size
+        index = bisect.bisect_left(self.capture_bs, raw_bs)
+        bs = self.capture_bs[index]
+        if bs != raw_bs:
+            self.seq_lens.fill_(self.seq_len_fill_value)
+            self.out_cache_loc.zero_()
+        self.input_ids[:raw_bs].copy_(forward_batch.input_ids)
+        self.req_pool_indices[:raw_bs].copy_(forward_batch.req_pool_indices)
+        self.seq_lens[:raw_bs].copy_(forward_batch.seq_lens)
+        self.out_cache_loc[:raw_bs].copy_(forward_batch.out_cache_loc)
+        self.positions[:raw_bs].copy_(forward_batch.positions)
+        self.model_runner.attn_backend.init_forward_metadata_replay_cuda_graph(
+            bs, self.req_pool_indices, self.seq_lens,
+            forward_batch.seq_lens_sum + (bs - raw_bs) * self.seq_len_fill_value, None,
+            ForwardMode.DECODE, None, forward_batch.seq_lens_cpu)
+        self.graphs[bs].replay()
+        out = self.output_buffers[bs]
+        return LogitsProcessorOutput(next_token_logits=out.next_token_logits[:raw_bs])
+
+
+class TpModelWorker:
+    """managers/tp_worker.py:25-184, the forward entry point only."""
+
+    def __init__(self, model_runner: ModelRunner):
+        self.model_runner = model_runner
+
+    def forward_batch_generation(self, model_worker_batch: ModelWorkerBatch, skip_sample: bool = False):
+        forward_batch = ForwardBatch.init_new(model_worker_batch, self.model_runner)
+        logits_output = self.model_runner.forward(forward_batch)
+        if model_worker_batch.launch_done is not None:
+            model_worker_batch.launch_done.set()
+        if skip_sample:
+            return logits_output, None
+        return logits_output, self.model_runner.sample(logits_output, forward_batch)

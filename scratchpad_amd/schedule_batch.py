@@ -1,0 +1,152 @@
+"""Scheduler-side producer of the hot path's inputs (boundary, not the scheduler itself).
+
+Mirrors the slot/table bookkeeping of scheduler/schedule_batch.py: ``prepare_for_extend``
+(901-1071: request rows, cached-prefix copy, slot allocation, req_to_token scatter by the HIP twin
+of write_req_to_token_pool_triton), ``prepare_for_decode`` (1230-1308: seq_lens += 1, alloc(bs),
+req_to_token[req, seq_len-1] = slot), ``mix_with_running`` (1073-1101) and
+``get_model_worker_batch`` (1399-1459).  Policy, radix cache, retraction, sampling params,
+grammars and multimodal bookkeeping stay with the reference's scheduler (out of scope).
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import _native
+from .forward_info import CaptureHiddenMode, ForwardMode, ModelWorkerBatch
+from .pool import ReqToTokenPool, TokenToKVPoolAllocator
+
+_bid = 0
+
+
+@dataclass
+class Req:
+    """The fields of scheduler/schedule_batch.py:Req that the producers below read."""
+    rid: str
+    origin_input_ids: List[int]
+    output_ids: List[int] = field(default_factory=list)
+    prefix_indices: Optional[torch.Tensor] = None   # cached KV slots (radix-cache hit), int
+    req_pool_idx: Optional[int] = None
+
+    @property
+    def fill_ids(self) -> List[int]:
+        return self.origin_input_ids + self.output_ids
+
+    @property
+    def extend_input_len(self) -> int:
+        return len(self.fill_ids) - self.prefix_len
+
+    @property
+    def prefix_len(self) -> int:
+        return 0 if self.prefix_indices is None else len(self.prefix_indices)
+
+
+class ScheduleBatch:
+    def __init__(self, reqs: List[Req], req_to_token_pool: ReqToTokenPool,
+                 token_to_kv_pool_allocator: TokenToKVPoolAllocator, device: str):
+        self.reqs = reqs
+        self.req_to_token_pool = req_to_token_pool
+        self.token_to_kv_pool_allocator = token_to_kv_pool_allocator
+        self.device = device
+        self.forward_mode: Optional[ForwardMode] = None
+        self.input_ids = self.req_pool_indices = self.seq_lens = self.out_cache_loc = None
+        self.output_ids = None
+        self.seq_lens_sum = 0
+        self.extend_num_tokens = None
+        self.prefix_lens = self.extend_lens = None
+
+    def batch_size(self):
+        return len(self.reqs)
+
+    def alloc_req_slots(self, num_reqs: int):
+        idx = self.req_to_token_pool.alloc(num_reqs)
+        if idx is None:
+            raise RuntimeError("Out of memory. Please set a smaller number for "
+                               "`--max-running-requests`.")
+        return idx
+
+    def alloc_token_slots(self, num_tokens: int):
+        out = self.token_to_kv_pool_allocator.alloc(num_tokens)
+        if out is None:
+            raise RuntimeError(f"Out of memory. Try to lower your batch size.\n"
+                               f"Try to allocate {num_tokens} tokens.\n"
+                               f"Avaliable tokens: {self.token_to_kv_pool_allocator.available_size()}\n")
+        return out
+
+    def prepare_for_extend(self):
+        self.forward_mode = ForwardMode.EXTEND
+        reqs = self.reqs
+        bs = len(reqs)
+        req_pool_indices = self.alloc_req_slots(bs)
+        input_ids = [r.fill_ids[r.prefix_len:] for r in reqs]
+        extend_num_tokens = sum(len(ids) for ids in input_ids)
+        seq_lens = [len(r.fill_ids) for r in reqs]
+        prefix_lens = [r.prefix_len for r in reqs]
+        extend_lens = [r.extend_input_len for r in reqs]
+
+        dev = self.device
+        req_pool_indices_tensor = torch.tensor(req_pool_indices, dtype=torch.int64).to(dev, non_blocking=True)
+        input_ids_tensor = torch.tensor(sum(input_ids, []), dtype=torch.int64).to(dev, non_blocking=True)
+        seq_lens_tensor = torch.tensor(seq_lens, dtype=torch.int64).to(dev, non_blocking=True)
+        prefix_lens_tensor = torch.tensor(prefix_lens, dtype=torch.int64, device=dev)
+        extend_lens_tensor = seq_lens_tensor - prefix_lens_tensor
+        for i, req in enumerate(reqs):
+            req.req_pool_idx = req_pool_indices[i]
+            if prefix_lens[i] > 0:
+                self.req_to_token_pool.write((req.req_pool_idx, slice(0, prefix_lens[i])),
+                                             req.prefix_indices.to(torch.int32))
+        out_cache_loc = self.alloc_token_slots(extend_num_tokens)
+        self.input_ids = input_ids_tensor
+        self.req_pool_indices = req_pool_indices_tensor
+        self.seq_lens = seq_lens_tensor
+        self.out_cache_loc = out_cache_loc
+        self.seq_lens_sum = sum(seq_lens)
+        self.extend_num_tokens = extend_num_tokens
+        self.prefix_lens = prefix_lens
+        self.extend_lens = extend_lens
+        _native.write_req_to_token(self.req_to_token_pool.req_to_token, req_pool_indices_tensor,
+                                   prefix_lens_tensor, seq_lens_tensor, extend_lens_tensor,
+                                   out_cache_loc)
+
+    def mix_with_running(self, running_batch: "ScheduleBatch"):
+        """Chunked prefill + running decodes in one extend batch: the decode rows become
+        extend rows of length 1 (schedule_batch.py:1073-1101)."""
+        self.forward_mode = ForwardMode.MIXED
+        running_bs = running_batch.batch_size()
+        input_ids = torch.cat([self.input_ids, running_batch.input_ids])
+        out_cache_loc = torch.cat([self.out_cache_loc, running_batch.out_cache_loc])
+        self.reqs = self.reqs + running_batch.reqs
+        self.req_pool_indices = torch.cat([self.req_pool_indices, running_batch.req_pool_indices])
+        self.seq_lens = torch.cat([self.seq_lens, running_batch.seq_lens])
+        self.seq_lens_sum += running_batch.seq_lens_sum
+        self.input_ids = input_ids
+        self.out_cache_loc = out_cache_loc
+        self.extend_num_tokens += running_bs
+        self.prefix_lens = self.prefix_lens + [len(r.fill_ids) - 1 for r in running_batch.reqs]
+        self.extend_lens = self.extend_lens + [1] * running_bs
+
+    def prepare_for_decode(self):
+        self.forward_mode = ForwardMode.DECODE
+        bs = len(self.reqs)
+        self.input_ids = self.output_ids
+        self.output_ids = None
+        locs = self.seq_lens.clone()
+        # overlap-safe (no in-place op): schedule_batch.py:1287-1292
+        self.seq_lens = self.seq_lens + 1
+        self.seq_lens_sum += bs
+        self.out_cache_loc = self.alloc_token_slots(bs)
+        self.req_to_token_pool.write((self.req_pool_indices, locs), self.out_cache_loc.to(torch.int32))
+
+    def get_model_worker_batch(self) -> ModelWorkerBatch:
+        global _bid
+        _bid += 1
+        if self.forward_mode.is_decode_or_idle():
+            extend_seq_lens = extend_prefix_lens = None
+        else:
+            extend_seq_lens, extend_prefix_lens = self.extend_lens, self.prefix_lens
+        return ModelWorkerBatch(
+            bid=_bid, forward_mode=self.forward_mode, input_ids=self.input_ids,
+            req_pool_indices=self.req_pool_indices, seq_lens=self.seq_lens,
+            out_cache_loc=self.out_cache_loc, seq_lens_sum=self.seq_lens_sum,
+            extend_num_tokens=self.extend_num_tokens, extend_seq_lens=extend_seq_lens,
+            extend_prefix_lens=extend_prefix_lens, capture_hidden_mode=CaptureHiddenMode.NULL)

@@ -1,0 +1,69 @@
+"""Shared test helpers: tolerances, golden loading, random paged-KV problems."""
+import numpy as np
+import torch
+
+from tests import golden
+
+DTYPES = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+
+
+def T(a, device="cpu", dtype=None):
+    t = torch.from_numpy(np.asarray(a))
+    if dtype is not None and t.is_floating_point():
+        t = t.to(dtype)
+    return t.to(device)
+
+
+def tol(dtype, kind="attn"):
+    """(rtol, atol_scale): |hip - ref| <= rtol*|ref| + atol_scale*max|ref|.
+
+    North-star bar: <= 1e-3 relative at fp16.  bf16 outputs carry 8 significant bits, so one
+    output rounding alone is up to 2^-8 relative: bf16 bar = 2^-8 (output quantisation) + 1e-3.
+    fp32 bar: 2e-5 (summation order / v_exp_f32 differ from the CPU libm path)."""
+    if dtype == torch.float32:
+        return (2e-5, 2e-5) if kind == "attn" else (2e-6, 2e-6)
+    if dtype == torch.float16:
+        return 1e-3, 1e-3
+    return 2.0 ** -8 + 1e-3, 1e-3
+
+
+def assert_close(hip, ref, dtype, kind="attn", what=""):
+    hip = hip.detach().float().cpu().double()
+    ref = ref.detach().float().cpu().double()
+    assert hip.shape == ref.shape, (hip.shape, ref.shape)
+    assert torch.isfinite(hip).all(), f"{what}: non-finite output"
+    rtol, ascale = tol(dtype, kind)
+    scale = float(ref.abs().max()) if ref.numel() else 0.0
+    err = (hip - ref).abs()
+    bound = rtol * ref.abs() + ascale * scale
+    bad = err > bound
+    assert not bool(bad.any()), (
+        f"{what}: {int(bad.sum())}/{bad.numel()} out of tolerance, max err {float(err.max()):.3e} "
+        f"(scale {scale:.3e}, rtol {rtol:.2e})")
+
+
+def paged_problem(seed, bs, Hq, Hkv, D, seq_lens, dtype, device, extra_slots=7, extra_rows=3,
+                  ctx_pad=4, scale=1.0):
+    """Random KV pool with a random slot permutation (fragmented free-list) + q."""
+    g = torch.Generator().manual_seed(seed)
+    seq = torch.as_tensor(seq_lens, dtype=torch.int64)
+    total = int(seq.sum())
+    P = total + extra_slots
+    k_buf = (torch.randn(P + 1, Hkv, D, generator=g) * scale).to(dtype)
+    v_buf = (torch.randn(P + 1, Hkv, D, generator=g) * scale).to(dtype)
+    r2t = torch.zeros(bs + extra_rows, int(seq.max()) + ctx_pad, dtype=torch.int32)
+    req = torch.randperm(bs + extra_rows, generator=g)[:bs].to(torch.int64)
+    perm = torch.randperm(P, generator=g) + 1
+    off = 0
+    for b in range(bs):
+        L = int(seq[b])
+        r2t[req[b], :L] = perm[off:off + L].to(torch.int32)
+        off += L
+    q = (torch.randn(bs, Hq, D, generator=g) * scale).to(dtype)
+    d = lambda t: t.to(device)
+    return dict(q=d(q), k_buffer=d(k_buf), v_buffer=d(v_buf), req_to_token=d(r2t),
+                req_pool_indices=d(req), seq_lens=d(seq))
+
+
+def cpu(d):
+    return {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in d.items()}

@@ -1,0 +1,257 @@
+"""GPU parity (through the C ABI) of paged decode attention and ragged extend attention.
+
+Bars (tests/helpers.py `tol`): fp32 2e-5, fp16 1e-3 relative (the north-star bar), bf16 1e-3 +
+2^-8 output quantisation; KV slot indexing is checked bit-exactly through permutation tests."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops
+from tests import golden
+from tests.helpers import DTYPES, T, assert_close, cpu, paged_problem
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from scratchpad_amd import _native
+    _native.load()
+    return _native
+
+
+def run_decode(nat, p, scale, cap=0.0, chunk=64, max_len=None, kv_start=None, idx_dtype=None):
+    q = p["q"]
+    bs, Hq, D = q.shape
+    seq, req = p["seq_lens"], p["req_pool_indices"]
+    if idx_dtype is not None:
+        seq, req = seq.to(idx_dtype), req.to(idx_dtype)
+    if max_len is None:
+        max_len = int(p["seq_lens"].max())
+    ws = torch.empty(nat.decode_workspace_bytes(bs, Hq, D, max_len, chunk), dtype=torch.uint8, device=DEV)
+    o = torch.full_like(q, float("nan"))
+    nat.decode_attention(o, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], req, seq, scale, cap,
+                         max_len, chunk, ws, kv_start)
+    return o
+
+
+def oracle_decode(p, scale, cap=0.0, kv_start=None):
+    c = cpu(p)
+    return ops.decode_attention(c["q"].float(), c["k_buffer"].float(), c["v_buffer"].float(),
+                                c["req_to_token"], c["req_pool_indices"], c["seq_lens"], scale, cap,
+                                None if kv_start is None else kv_start.cpu())
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("chunk", [16, 64, 512])
+def test_decode_golden(nat, dt, chunk):
+    """the reference's own Triton decode outputs; inputs are exact in every dtype"""
+    dtype = DTYPES[dt]
+    g = golden.load("decode_attention")
+    for i in range(int(g["num_cases"])):
+        p = dict(q=T(g[f"c{i}_q"], DEV, dtype), k_buffer=T(g[f"c{i}_k_buffer"], DEV, dtype),
+                 v_buffer=T(g[f"c{i}_v_buffer"], DEV, dtype), req_to_token=T(g[f"c{i}_req_to_token"], DEV),
+                 req_pool_indices=T(g[f"c{i}_req_pool_indices"], DEV), seq_lens=T(g[f"c{i}_seq_lens"], DEV))
+        o = run_decode(nat, p, float(g[f"c{i}_sm_scale"]), float(g[f"c{i}_logit_cap"]), chunk)
+        assert_close(o, T(g[f"c{i}_o"]), dtype, what=f"decode golden c{i} {dt} chunk={chunk}")
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (8, 1, 128), (32, 8, 64), (8, 8, 128), (4, 2, 64),
+                                      (16, 2, 128), (6, 6, 64)])
+def test_decode_vs_oracle_ragged(nat, dt, Hq, Hkv, D):
+    dtype = DTYPES[dt]
+    lens = [1, 2, 63, 64, 65, 127, 128, 129, 255, 257, 300, 511, 513, 1000, 5, 17]
+    p = paged_problem(11, len(lens), Hq, Hkv, D, lens, dtype, DEV)
+    scale = 1.0 / math.sqrt(D)
+    ref = oracle_decode(p, scale)
+    for chunk in (64, 128, 512):
+        assert_close(run_decode(nat, p, scale, chunk=chunk), ref, dtype, what=f"chunk {chunk}")
+    # graph-mode calling convention: int32 indices, max_seq_len = context length (over-estimate)
+    o = run_decode(nat, p, scale, chunk=128, max_len=4096, idx_dtype=torch.int32)
+    assert_close(o, ref, dtype, what="int32 idx / static max_len")
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_decode_properties_production_shape(nat, dt):
+    """Llama-3-8B head shape at batch 64 with contexts up to 4096: size-independent properties."""
+    dtype = DTYPES[dt]
+    gen = torch.Generator().manual_seed(5)
+    bs = 64
+    lens = torch.randint(128, 4097, (bs,), generator=gen).tolist()
+    lens[0], lens[1] = 4096, 128
+    p = paged_problem(6, bs, 32, 8, 128, lens, dtype, DEV)
+    scale = 128 ** -0.5
+    o512 = run_decode(nat, p, scale, chunk=512)
+    # (a) split invariance: any chunking gives the same softmax
+    for chunk in (64, 256):
+        assert_close(run_decode(nat, p, scale, chunk=chunk), o512.float(), dtype, what=f"split {chunk}")
+    # (b) spot-check 6 rows against the oracle
+    rows = [0, 1, 7, 20, 41, 63]
+    sub = {k: (v[rows] if k in ("q", "req_pool_indices", "seq_lens") else v) for k, v in p.items()}
+    assert_close(o512[rows], oracle_decode(sub, scale), dtype, what="rows vs oracle")
+    # (c) slot-permutation invariance: relocating every KV row (and the table) changes nothing, bit for bit
+    P1 = p["k_buffer"].shape[0]
+    perm = torch.randperm(P1 - 1, generator=gen).to(DEV) + 1
+    perm = torch.cat([torch.zeros(1, dtype=torch.int64, device=DEV), perm])     # slot 0 stays the dummy
+    p2 = dict(p)
+    p2["k_buffer"] = torch.empty_like(p["k_buffer"]); p2["k_buffer"][perm] = p["k_buffer"]
+    p2["v_buffer"] = torch.empty_like(p["v_buffer"]); p2["v_buffer"][perm] = p["v_buffer"]
+    p2["req_to_token"] = perm[p["req_to_token"].long()].to(torch.int32)
+    assert torch.equal(run_decode(nat, p2, scale, chunk=512), o512), "KV page indexing must be bit-exact"
+    # (d) convexity: every output lies inside the range of the V rows it attends to
+    vmax = p["v_buffer"].float().abs().max()
+    assert float(o512.float().abs().max()) <= float(vmax) * (1 + 1e-2)
+    # (e) V-linearity: attention(q, K, a*V) == a*attention(q, K, V)  (a = 2: exact in binary fp)
+    p3 = dict(p); p3["v_buffer"] = p["v_buffer"] * 2
+    assert torch.equal(run_decode(nat, p3, scale, chunk=512), o512 * 2)
+
+
+def test_decode_edge_cases(nat):
+    dtype = torch.bfloat16
+    scale = 0.1
+    # padded graph rows: seq_len = fill value 1 pointing at the dummy slot 0 (req row all zeros)
+    p = paged_problem(7, 4, 8, 2, 128, [9, 1, 1, 33], dtype, DEV)
+    p["req_to_token"][p["req_pool_indices"][1]] = 0
+    p["req_to_token"][p["req_pool_indices"][2]] = 0
+    o = run_decode(nat, p, scale, chunk=64)
+    assert torch.isfinite(o.float()).all()
+    assert_close(o, oracle_decode(p, scale), dtype, what="padded rows")
+    # a zero-length row is left untouched and must not disturb its neighbours
+    p = paged_problem(8, 3, 8, 2, 128, [40, 5, 70], dtype, DEV)
+    p["seq_lens"][1] = 0
+    o = run_decode(nat, p, scale, chunk=64)
+    ref = oracle_decode(p, scale)
+    assert_close(o[[0, 2]], ref[[0, 2]], dtype, what="neighbours of empty row")
+    assert torch.isnan(o[1].float()).all(), "empty row: output untouched (caller pre-filled NaN)"
+    # batch of one, one token
+    p = paged_problem(9, 1, 32, 8, 128, [1], dtype, DEV)
+    o = run_decode(nat, p, scale)
+    assert_close(o, oracle_decode(p, scale), dtype, what="bs=1 len=1")
+    # kv_start: encoder-decoder self-attention window [enc, enc+seq)
+    p = paged_problem(10, 3, 8, 2, 64, [50, 90, 20], dtype, DEV)
+    enc = torch.tensor([7, 0, 13], device=DEV)
+    p["seq_lens"] = p["seq_lens"] - enc
+    o = run_decode(nat, p, scale, kv_start=enc)
+    assert_close(o, oracle_decode(p, scale, kv_start=enc), dtype, what="kv_start")
+    # soft-cap
+    p = paged_problem(12, 3, 8, 2, 128, [50, 90, 200], dtype, DEV, scale=3.0)
+    assert_close(run_decode(nat, p, scale, cap=20.0), oracle_decode(p, scale, 20.0), dtype, what="cap")
+    # large-magnitude scores: online-softmax rescale path (scores jump by > 100 between batches)
+    p = paged_problem(13, 2, 4, 1, 128, [300, 77], torch.float32, DEV)
+    p["k_buffer"][p["req_to_token"][p["req_pool_indices"][0], 200].long()] *= 40
+    assert_close(run_decode(nat, p, 1.0, chunk=512), oracle_decode(p, 1.0), torch.float32, what="spike")
+
+
+def test_decode_rejects_bad_arguments(nat):
+    p = paged_problem(14, 2, 8, 2, 128, [5, 9], torch.bfloat16, DEV)
+    with pytest.raises(RuntimeError, match="workspace"):
+        nat.decode_attention(torch.empty_like(p["q"]), p["q"], p["k_buffer"], p["v_buffer"],
+                             p["req_to_token"], p["req_pool_indices"], p["seq_lens"], 0.1, 0.0, 4096, 64,
+                             torch.empty(16, dtype=torch.uint8, device=DEV))
+    p96 = paged_problem(15, 1, 4, 4, 96, [5], torch.bfloat16, DEV)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        run_decode(nat, p96, 0.1)
+
+
+# ----------------------------------------------------------------------------------- extend
+def run_extend(nat, q, kb, vb, r2t, req, seq, ext, start, scale, cap=0.0, causal=True, kv_start=None):
+    T_, Hq, D = q.shape
+    ws = torch.empty(nat.extend_workspace_bytes(T_, len(seq), Hq, D, q.dtype), dtype=torch.uint8, device=DEV)
+    o = torch.full_like(q, float("nan"))
+    nat.extend_attention(o, q, kb, vb, r2t, req, seq, ext, start, scale, cap, causal,
+                         int(ext.max()), int(seq.max()), ws, kv_start)
+    return o
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+def test_extend_golden(nat, dt):
+    dtype = DTYPES[dt]
+    g = golden.load("extend_attention")
+    for i in range(int(g["num_cases"])):
+        args = [T(g[f"c{i}_{n}"], DEV, dtype) for n in ("q", "k_buffer", "v_buffer")]
+        idx = [T(g[f"c{i}_{n}"], DEV) for n in ("req_to_token", "req_pool_indices", "seq_lens",
+                                                "extend_seq_lens", "extend_start_loc")]
+        o = run_extend(nat, *args, *idx, float(g[f"c{i}_sm_scale"]), float(g[f"c{i}_logit_cap"]))
+        assert_close(o, T(g[f"c{i}_o"]), dtype, what=f"extend golden c{i} {dt}")
+
+
+def extend_problem(seed, Hq, Hkv, D, pre, ext, dtype):
+    bs = len(pre)
+    seq = [a + b for a, b in zip(pre, ext)]
+    p = paged_problem(seed, bs, Hq, Hkv, D, seq, dtype, DEV)
+    g = torch.Generator().manual_seed(seed + 1)
+    q = torch.randn(sum(ext), Hq, D, generator=g).to(dtype).to(DEV)
+    ext_t = torch.tensor(ext, dtype=torch.int32, device=DEV)
+    start = torch.zeros(bs, dtype=torch.int32, device=DEV)
+    start[1:] = torch.cumsum(ext_t[:-1], 0)
+    return p, q, ext_t, start
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (8, 1, 128), (8, 2, 64), (4, 4, 64)])
+def test_extend_vs_oracle(nat, dt, Hq, Hkv, D):
+    dtype = DTYPES[dt]
+    pre = [0, 64, 300, 0, 5, 129]
+    ext = [130, 1, 70, 1, 257, 33]            # includes MIXED-style rows (extend_len 1)
+    p, q, ext_t, start = extend_problem(21, Hq, Hkv, D, pre, ext, dtype)
+    scale = D ** -0.5
+    o = run_extend(nat, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"],
+                   p["seq_lens"], ext_t, start, scale)
+    c = cpu(p)
+    ref = ops.extend_attention(q.cpu().float(), c["k_buffer"].float(), c["v_buffer"].float(),
+                               c["req_to_token"], c["req_pool_indices"], c["seq_lens"], ext_t.cpu(),
+                               start.cpu(), scale)
+    assert_close(o, ref, dtype, what="extend ragged")
+
+
+def test_extend_cross_attention_and_kv_start(nat):
+    """non-causal rows over the encoder slots [0, enc) and causal rows over [enc, enc+seq)
+    (flashinfer_backend.py:792-828)"""
+    dtype = torch.bfloat16
+    Hq, Hkv, D = 8, 2, 128
+    enc = [40, 0, 77]
+    pre = [3, 10, 0]
+    ext = [20, 5, 31]
+    seq_dec = [a + b for a, b in zip(pre, ext)]
+    total = [e + s for e, s in zip(enc, seq_dec)]
+    p = paged_problem(31, 3, Hq, Hkv, D, total, dtype, DEV)
+    g = torch.Generator().manual_seed(32)
+    q = torch.randn(sum(ext), Hq, D, generator=g).to(dtype).to(DEV)
+    ext_t = torch.tensor(ext, dtype=torch.int32, device=DEV)
+    start = torch.zeros(3, dtype=torch.int32, device=DEV)
+    start[1:] = torch.cumsum(ext_t[:-1], 0)
+    enc_t = torch.tensor(enc, dtype=torch.int64, device=DEV)
+    seq_t = torch.tensor(seq_dec, dtype=torch.int64, device=DEV)
+    c = cpu(p)
+    # cross attention: lens = encoder_lens, kv_start = 0, non-causal; request 1 has no encoder tokens
+    o = run_extend(nat, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"], enc_t,
+                   ext_t, start, 0.1, causal=False)
+    ref = ops.extend_attention(q.cpu().float(), c["k_buffer"].float(), c["v_buffer"].float(),
+                               c["req_to_token"], c["req_pool_indices"], enc_t.cpu(), ext_t.cpu(),
+                               start.cpu(), 0.1, causal=False)
+    rows = torch.cat([torch.arange(0, 20), torch.arange(25, 56)])      # rows of requests with enc > 0
+    assert_close(o[rows], ref[rows], dtype, what="cross")
+    # decoder self-attention behind the encoder slots
+    o = run_extend(nat, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"], seq_t,
+                   ext_t, start, 0.1, causal=True, kv_start=enc_t)
+    ref = ops.extend_attention(q.cpu().float(), c["k_buffer"].float(), c["v_buffer"].float(),
+                               c["req_to_token"], c["req_pool_indices"], seq_t.cpu(), ext_t.cpu(),
+                               start.cpu(), 0.1, causal=True, kv_start=enc_t.cpu())
+    assert_close(o, ref, dtype, what="self behind encoder")
+
+
+def test_extend_last_row_equals_decode(nat):
+    """the last new token of a request sees exactly what a decode step at that length sees"""
+    dtype = torch.float16
+    pre, ext = [100, 0], [28, 300]
+    p, q, ext_t, start = extend_problem(41, 32, 8, 128, pre, ext, dtype)
+    o = run_extend(nat, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"],
+                   p["seq_lens"], ext_t, start, 0.09)
+    last = torch.cumsum(ext_t.long(), 0) - 1
+    pd = dict(p); pd["q"] = q[last].contiguous()
+    od = run_decode(nat, pd, 0.09, chunk=64)
+    assert_close(o[last], od.float(), dtype, what="extend last row vs decode")

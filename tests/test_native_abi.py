@@ -1,0 +1,72 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports exactly the symbols
+include/scratchpad_hip.h declares (no compute calls - there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "scratchpad_hip.h")).read()
+    return sorted(set(re.findall(r"^SP_API [^;(]*?\b(sp_\w+)\s*\(", text, flags=re.M)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from scratchpad_amd import _native, build
+    build.build_native(verbose=False)
+    return ctypes.CDLL(_native.lib_path())
+
+
+def test_header_declares_the_whole_path():
+    syms = header_symbols()
+    for s in ["sp_rmsnorm", "sp_fused_add_rmsnorm", "sp_silu_and_mul", "sp_rotary_embedding",
+              "sp_kv_store", "sp_write_req_to_token", "sp_compute_position", "sp_clamp_position",
+              "sp_decode_attention", "sp_decode_attention_workspace_bytes", "sp_extend_attention",
+              "sp_extend_attention_workspace_bytes", "sp_abi_version", "sp_status_string"]:
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for s in header_symbols():
+        assert hasattr(lib, s), f"{s} declared in the header but not exported"
+
+
+def test_python_binding_covers_every_symbol():
+    from scratchpad_amd import _native
+    assert sorted(_native.SIGNATURES) == header_symbols()
+
+
+def test_abi_version_and_status_strings(lib):
+    lib.sp_abi_version.restype = ctypes.c_int
+    assert lib.sp_abi_version() == 1
+    lib.sp_status_string.restype = ctypes.c_char_p
+    assert lib.sp_status_string(0) == b"ok"
+    assert b"unsupported" in lib.sp_status_string(-2)
+
+
+def test_host_side_argument_validation_needs_no_gpu(lib):
+    # null pointers / bad sizes are rejected before any launch
+    lib.sp_rmsnorm.restype = ctypes.c_int
+    lib.sp_rmsnorm.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
+                                                      ctypes.c_int64, ctypes.c_float, ctypes.c_int,
+                                                      ctypes.c_void_p]
+    assert lib.sp_rmsnorm(None, None, None, 4, 64, 64, 64, 1e-5, 2, None) == -1
+    lib.sp_decode_attention_workspace_bytes.restype = ctypes.c_size_t
+    lib.sp_decode_attention_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                        ctypes.c_int64, ctypes.c_int]
+    assert lib.sp_decode_attention_workspace_bytes(256, 32, 128, 4096, 512) == \
+        256 * 32 * 8 * 129 * 4 + 16
+    assert lib.sp_decode_attention_workspace_bytes(4, 8, 64, 100, 512) == 16
+
+
+def test_ops_refuse_host_tensors():
+    import torch
+    from scratchpad_amd import _native
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _native.rmsnorm(torch.zeros(2, 64), torch.ones(64), 1e-5)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _native.silu_and_mul(torch.zeros(2, 64))
