@@ -16,6 +16,9 @@ OBJ = os.path.join(ROOT, "build", "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wno-unused-value"]
+# elementwise.hip reproduces torch's per-op rounding (round16(a*b) - round16(c*d)); the default
+# -ffp-contract=fast lets the backend fuse that into v_fma_f16 whatever the source pragmas say
+PER_FILE_FLAGS = {"elementwise.hip": ["-ffp-contract=off"]}
 
 
 def _newer(target, deps):
@@ -38,7 +41,7 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
         if not force and _newer(obj, [src] + hdrs):
             return obj
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -63,23 +63,21 @@ template <>
 __device__ __forceinline__ float dot16<f32_tag>(const u32x4& a, const u32x4& b, float acc) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    acc = __builtin_fmaf(__builtin_bit_cast(float, a[i]), __builtin_bit_cast(float, b[i]), acc);
+    acc = __builtin_fmaf(as_f32(a[i]), as_f32(b[i]), acc);
   return acc;
 }
 template <>
 __device__ __forceinline__ float dot16<bf16_tag>(const u32x4& a, const u32x4& b, float acc) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a[i]),
-                                          __builtin_bit_cast(bf16x2_t, b[i]), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(as_bf16x2(a[i]), as_bf16x2(b[i]), acc, false);
   return acc;
 }
 template <>
 __device__ __forceinline__ float dot16<f16_tag>(const u32x4& a, const u32x4& b, float acc) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a[i]),
-                                 __builtin_bit_cast(f16x2_t, b[i]), acc, false);
+    acc = __builtin_amdgcn_fdot2(as_f16x2(a[i]), as_f16x2(b[i]), acc, false);
   return acc;
 }
 

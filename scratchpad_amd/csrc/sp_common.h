@@ -16,6 +16,14 @@ struct f16_tag {};
 struct bf16_tag {};
 struct f32_tag {};
 
+// ---- bit casts of 32-bit lanes.  NOTE: never apply __builtin_bit_cast directly to an
+// ext_vector element expression (`v[i]`): hipcc (ROCm 7.2) then reads element 0 for every i.
+// These helpers take the lane BY VALUE.
+__device__ __forceinline__ float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t as_u32(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ __forceinline__ bf16x2_t as_bf16x2(uint32_t u) { return __builtin_bit_cast(bf16x2_t, u); }
+__device__ __forceinline__ f16x2_t as_f16x2(uint32_t u) { return __builtin_bit_cast(f16x2_t, u); }
+
 // ---- scalar conversions -------------------------------------------------------------------
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t lo16) {
   return __builtin_bit_cast(float, lo16 << 16);
@@ -77,21 +85,21 @@ __device__ __forceinline__ void unpack16(const u32x4& v, float* f);
 template <>
 __device__ __forceinline__ void unpack16<f32_tag>(const u32x4& v, float* f) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(float, v[i]);
+  for (int i = 0; i < 4; ++i) f[i] = as_f32(v[i]);
 }
 template <>
 __device__ __forceinline__ void unpack16<bf16_tag>(const u32x4& v, float* f) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
-    f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+    f[2 * i] = as_f32(v[i] << 16);
+    f[2 * i + 1] = as_f32(v[i] & 0xffff0000u);
   }
 }
 template <>
 __device__ __forceinline__ void unpack16<f16_tag>(const u32x4& v, float* f) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    f16x2_t h = __builtin_bit_cast(f16x2_t, v[i]);
+    const f16x2_t h = as_f16x2(v[i]);
     f[2 * i] = (float)h[0];
     f[2 * i + 1] = (float)h[1];
   }
@@ -103,7 +111,7 @@ template <>
 __device__ __forceinline__ u32x4 pack16<f32_tag>(const float* f) {
   u32x4 v;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(uint32_t, f[i]);
+  for (int i = 0; i < 4; ++i) v[i] = as_u32(f[i]);
   return v;
 }
 template <>

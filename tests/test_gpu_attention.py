@@ -107,7 +107,10 @@ def test_decode_properties_production_shape(nat, dt):
     assert float(o512.float().abs().max()) <= float(vmax) * (1 + 1e-2)
     # (e) V-linearity: attention(q, K, a*V) == a*attention(q, K, V)  (a = 2: exact in binary fp)
     p3 = dict(p); p3["v_buffer"] = p["v_buffer"] * 2
-    assert torch.equal(run_decode(nat, p3, scale, chunk=512), o512 * 2)
+    o2 = run_decode(nat, p3, scale, chunk=512)
+    normal = o512.float().abs() >= 2.0 ** -13          # fp16 subnormals do not scale exactly
+    assert torch.equal(o2[normal], (o512 * 2)[normal])
+    assert float((o2.float() - 2 * o512.float()).abs().max()) <= 2.0 ** -23
 
 
 def test_decode_edge_cases(nat):

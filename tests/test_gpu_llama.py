@@ -1,0 +1,53 @@
+"""End-to-end parity of the hosted Llama decoder (ModelRunner -> ForwardBatch -> HipAttnBackend ->
+C ABI) against the logits of the reference's own LlamaForCausalLM (tests/golden/tiny_llama.npz).
+
+Bar: max |logit deviation| <= 1e-3 of the logit scale (north star), measured at fp32 and fp16;
+bf16 is compared with the oracle evaluated in bf16 (both sides round activations to 8 bits)."""
+import pytest
+import torch
+
+from tests import smoke_impl
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_tiny_llama_fp32_matches_reference_logits(name):
+    prefill, decode, nxt, gp, gd, gn, mr = smoke_impl.run_case(name, torch.float32)
+    for got, want, what in ((prefill, gp, "prefill"), (decode, gd, "decode")):
+        dev = float((got - want).abs().max() / want.abs().max())
+        assert dev <= 1e-4, f"{name} {what}: relative logit deviation {dev:.2e}"
+    assert torch.equal(nxt, gn)
+    # the KV pool after both steps equals the reference's pool (slot indexing is bit-exact; values
+    # to fp32 rounding)
+    g, pfx, _, _ = smoke_impl.load_case(name)
+    k0 = mr.token_to_kv_pool.get_key_buffer(0).float().cpu()
+    v1 = mr.token_to_kv_pool.get_value_buffer(1).float().cpu()
+    assert torch.allclose(k0, torch.from_numpy(g[pfx + "k_buffer0_after"]), atol=2e-5)
+    assert torch.allclose(v1, torch.from_numpy(g[pfx + "v_buffer1_after"]), atol=2e-5)
+    written = torch.from_numpy(g[pfx + "k_buffer0_after"]).abs().sum((1, 2)) > 0
+    assert torch.equal(k0.abs().sum((1, 2)) > 0, written), "exactly the reference's slots are written"
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_tiny_llama_fp16_within_1e3(name):
+    prefill, decode, nxt, gp, gd, gn, _ = smoke_impl.run_case(name, torch.float16)
+    o1, o2 = smoke_impl.oracle_logits(name, torch.float16)
+    for got, want, what in ((prefill, o1, "prefill"), (decode, o2, "decode")):
+        dev = float((got - want).abs().max() / want.abs().max())
+        assert dev <= 1e-3, f"{name} {what}: relative logit deviation {dev:.2e} vs fp16 oracle"
+    # and against the reference's fp32 logits: fp16 weight/activation rounding only
+    assert float((prefill - gp).abs().max() / gp.abs().max()) <= 5e-3
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_tiny_llama_bf16_and_graph_replay(name):
+    eager = smoke_impl.run_case(name, torch.bfloat16)
+    graph = smoke_impl.run_case(name, torch.bfloat16, graph_bs=[2, 4])
+    o1, o2 = smoke_impl.oracle_logits(name, torch.bfloat16)
+    for got, want, what in ((eager[0], o1, "prefill"), (eager[1], o2, "decode")):
+        dev = float((got - want).abs().max() / want.abs().max())
+        assert dev <= 3e-2, f"{name} {what}: {dev:.2e} vs bf16 oracle"
+    # graph replay (padded from bs 3 to the bs-4 bucket) computes the same thing as eager
+    assert torch.allclose(graph[1], eager[1], atol=1e-2 * float(eager[1].abs().max()))
+    assert torch.equal(graph[0], eager[0]), "prefill is eager in both runs"
