@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Llama-3-8B bf16 TP=1 continuous-batching decode, bs=256, on MI355X.
+
+One "step" = one decode step of the whole hot path for one batch: the scheduler-side
+prepare_for_decode (slot allocation + req_to_token write), ForwardBatch.init_new, 32 decoder
+layers (RMSNorm -> QKV GEMM -> rotary -> KV store -> paged decode attention -> o_proj -> RMSNorm
+-> gate/up GEMM -> SiLU-mul -> down GEMM), final norm, lm_head, greedy argmax.  Weights are
+random-init (N(0, 0.02), norm weights 1), the KV pool is filled with random bf16 data, contexts
+are uniform-int [128, 4096] (seed 0) or fixed (--ctx N), KV slots are a seeded random
+permutation of the pool (a long-running server's fragmented free list).  All inputs are resident
+in HBM before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs N independent TP=1 replicas (one process per GPU, launched by torch.distributed.run);
+there is no data-path collective, ranks only meet at the timing barriers.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--bs", type=int, default=256)
+    ap.add_argument("--ctx", default="uniform", help='"uniform" = U[128,4096] seed 0, or a fixed length')
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama32-1b"])
+    ap.add_argument("--layers", type=int, default=None, help="override layer count (debug only)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=4,
+                    help="extra eager steps with HIP events around every attention launch")
+    return ap.parse_args()
+
+
+def build_engine(args, device_index, seed):
+    from scratchpad_amd.model_runner import ModelConfig, ModelRunner, ServerArgs
+    total_steps = args.warmup + args.steps + args.profile_steps + 8
+    gen = torch.Generator().manual_seed(seed)
+    if args.ctx == "uniform":
+        ctx = torch.randint(128, 4097, (args.bs,), generator=gen)
+    else:
+        ctx = torch.full((args.bs,), int(args.ctx), dtype=torch.int64)
+    context_len = int(ctx.max()) + total_steps + 4
+    cfg = (ModelConfig.llama3_8b if args.model == "llama3-8b" else ModelConfig.llama32_1b)(context_len)
+    if args.layers:
+        cfg.num_hidden_layers = args.layers
+    pool_tokens = int(ctx.sum()) + args.bs * total_steps + 64
+    sargs = ServerArgs(max_total_tokens=pool_tokens, max_running_requests=args.bs,
+                       disable_cuda_graph=args.no_graph, cuda_graph_max_bs=args.bs,
+                       cuda_graph_bs=[args.bs])
+    mr = ModelRunner(cfg, sargs, dtype=torch.bfloat16, gpu_id=device_index, seed=seed)
+    # synthetic cache contents (random, not zeros: zero operands run at a higher clock)
+    for arena in (mr.token_to_kv_pool._k_arena, mr.token_to_kv_pool._v_arena):
+        for layer in range(arena.shape[0]):
+            arena[layer].normal_(0.0, 0.5)
+    return mr, ctx, gen
+
+
+def populate_batch(mr, ctx, gen):
+    """Lay the batch out as a scheduler would have left it after prefill: request rows, slots in
+    random (fragmented) order, req_to_token rows written, last sampled token as the next input."""
+    from scratchpad_amd.forward_info import ForwardMode
+    from scratchpad_amd.schedule_batch import Req, ScheduleBatch
+    dev = mr.device
+    bs = len(ctx)
+    alloc = mr.token_to_kv_pool_allocator
+    # fragment the free list with a seeded permutation (pool.py:225-232: free() appends in
+    # arbitrary order over a server's lifetime)
+    perm = torch.randperm(alloc.size, generator=gen) + 1
+    alloc.free_slots = perm.to(torch.int64).to(dev)
+    reqs = [Req(rid=str(i), origin_input_ids=[]) for i in range(bs)]
+    batch = ScheduleBatch(reqs, mr.req_to_token_pool, alloc, dev)
+    rows = batch.alloc_req_slots(bs)
+    batch.req_pool_indices = torch.tensor(rows, dtype=torch.int64, device=dev)
+    batch.seq_lens = ctx.to(torch.int64).to(dev)
+    batch.seq_lens_sum = int(ctx.sum())
+    table = mr.req_to_token_pool.req_to_token
+    slots = alloc.alloc(int(ctx.sum()))
+    off = 0
+    for i in range(bs):
+        n = int(ctx[i])
+        table[rows[i], :n] = slots[off:off + n].to(torch.int32)
+        off += n
+    batch.forward_mode = ForwardMode.DECODE
+    batch.output_ids = torch.randint(0, mr.model_config.vocab_size, (bs,), generator=gen).to(dev)
+    return batch
+
+
+def engine_step(worker, batch):
+    batch.prepare_for_decode()
+    out, next_ids = worker.forward_batch_generation(batch.get_model_worker_batch())
+    batch.output_ids = next_ids
+    return out
+
+
+def attention_algorithmic_bytes(cfg, seq_sum, bs, elem=2):
+    """K+V rows of every context token + q,o rows + int32 slot indices, per layer."""
+    kv = seq_sum * 2 * cfg.num_key_value_heads * cfg.head_dim * elem
+    qo = 2 * bs * cfg.num_attention_heads * cfg.head_dim * elem
+    return kv + qo + 4 * seq_sum
+
+
+def cpu_baseline(bs=8, ctx=512, layers=2, seconds=12.0):
+    """The oracle's decode step (oracle/llama.py, plain torch fp32) on the host cores: Llama-3-8B
+    layer shapes, `layers` layers, bs x ctx; extrapolated to 32 layers + lm_head."""
+    from oracle import llama as ollama
+    from oracle import ops
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    shape = ollama.LlamaShape(4096, 14336, layers, 32, 8, 128256, False, 500000.0, None, 8192, 1e-5)
+    g = torch.Generator().manual_seed(0)
+    w = {"model.embed_tokens.weight": torch.randn(4096, 4096, generator=g) * 0.02,  # stand-in rows
+         "model.norm.weight": torch.ones(4096)}
+    for i in range(layers):
+        p = f"model.layers.{i}."
+        w[p + "input_layernorm.weight"] = torch.ones(4096)
+        w[p + "post_attention_layernorm.weight"] = torch.ones(4096)
+        w[p + "self_attn.qkv_proj.weight"] = torch.randn(6144, 4096, generator=g) * 0.02
+        w[p + "self_attn.o_proj.weight"] = torch.randn(4096, 4096, generator=g) * 0.02
+        w[p + "mlp.gate_up_proj.weight"] = torch.randn(28672, 4096, generator=g) * 0.02
+        w[p + "mlp.down_proj.weight"] = torch.randn(4096, 14336, generator=g) * 0.02
+    head = torch.randn(128256, 4096, generator=g) * 0.02
+    kv = ollama.OracleKV(shape, bs * (ctx + 64), bs, ctx + 64)
+    for i in range(layers):
+        kv.k[i].normal_(0, 0.5, generator=g)
+        kv.v[i].normal_(0, 0.5, generator=g)
+    slots = torch.randperm(bs * (ctx + 64), generator=g) + 1
+    for b in range(bs):
+        kv.req_to_token[b, :ctx + 64] = slots[b * (ctx + 64):(b + 1) * (ctx + 64)].to(torch.int32)
+    cos_sin = ops.rope_cos_sin_cache(ctx + 64, 500000.0, 128, None)
+    req = torch.arange(bs)
+    ids = torch.randint(0, 4096, (bs,), generator=g)
+    shape_nohead = shape
+    w["lm_head.weight"] = head[:8]           # the layer timing excludes the real head (timed below)
+    t_layers, n, seq = 0.0, 0, torch.full((bs,), ctx, dtype=torch.int64)
+    t_end = time.perf_counter() + seconds
+    while n < 2 or (time.perf_counter() < t_end and n < 32):
+        seq = seq + 1
+        loc = kv.req_to_token[req, seq - 1].long()
+        t0 = time.perf_counter()
+        ollama.forward(shape_nohead, w, kv, mode="decode", input_ids=ids, positions=ops.clamp_position(seq),
+                       req_pool_indices=req, seq_lens=seq, out_cache_loc=loc, cos_sin_cache=cos_sin)
+        dt = time.perf_counter() - t0
+        if n > 0:
+            t_layers += dt
+        n += 1
+    t_layer = t_layers / (n - 1) / layers
+    h = torch.randn(bs, 4096, generator=g)
+    t0 = time.perf_counter()
+    torch.matmul(h, head.T)
+    t_head = time.perf_counter() - t0
+    step = 32 * t_layer + t_head
+    return {"value": round(bs / step, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/llama.py decode step, fp32 torch, Llama-3-8B layer shapes, bs={bs} ctx={ctx}, "
+                      f"{layers} layers x {n - 1} timed steps ({t_layer * 1e3:.1f} ms/layer) + lm_head "
+                      f"({t_head * 1e3:.1f} ms), extrapolated to 32 layers"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from scratchpad_amd import _native
+    from scratchpad_amd.model_runner import TpModelWorker
+    _native.load()
+    mr, ctx, gen = build_engine(args, local_rank, seed=rank)
+    if not args.no_graph:
+        mr.init_cuda_graphs()
+    worker = TpModelWorker(mr)
+    batch = populate_batch(mr, ctx, gen)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        engine_step(worker, batch)
+    barrier()
+    seq_sum_start = batch.seq_lens_sum
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        engine_step(worker, batch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    seq_sum_end = batch.seq_lens_sum
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- dominant kernel: paged decode attention, timed per launch with HIP events on the
+    # stream it is launched on (eager steps continuing the same trace)
+    cfg = mr.model_config
+    roofline = None
+    if rank == 0 and args.profile_steps > 0:
+        saved = mr.graph_runner
+        mr.graph_runner = None
+        events, sums = [], []
+        orig = _native.decode_attention
+
+        def timed(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(*a, **k)
+            e1.record()
+            events.append((e0, e1))
+
+        engine_step(worker, batch)  # eager warm-up (workspace growth, autotune of nothing)
+        import scratchpad_amd.attention as att
+        att._native.decode_attention = timed
+        try:
+            for _ in range(args.profile_steps):
+                engine_step(worker, batch)
+                sums.extend([batch.seq_lens_sum] * cfg.num_hidden_layers)
+            torch.cuda.synchronize()
+        finally:
+            att._native.decode_attention = orig
+            mr.graph_runner = saved
+        ms = [a.elapsed_time(b) for a, b in events]
+        avg_ms = sum(ms) / len(ms)
+        alg = sum(attention_algorithmic_bytes(cfg, s, args.bs) for s in sums) / len(sums)
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "decode_attn_kernel+decode_merge_kernel",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": len(ms),
+                    "algorithmic_bytes_per_launch": int(alg)}
+
+    if rank != 0:
+        return
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.bs * args.steps / elapsed
+    # whole-step HBM roofline: weights once + KV of every context token + new KV
+    n_params = sum(p.numel() for p in mr.model.parameters())
+    avg_seq = (seq_sum_start + seq_sum_end) / 2 + args.bs / 2
+    step_bytes = n_params * 2 + avg_seq * 2 * cfg.num_key_value_heads * cfg.head_dim * 2 * cfg.num_hidden_layers
+    step_roofline_tok_s = args.bs / (step_bytes / (HBM_PEAK_GBPS * 1e9))
+    out = {
+        "metric": "decode_tokens_per_sec", "value": round(value, 1), "unit": "tokens/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic (random-init weights, random KV, seeded contexts and slot permutation)",
+        "config": {"workload": f"{args.model} TP=1 bf16 continuous-batching decode bs={args.bs} seq_len=1, "
+                               f"ctx={'U[128,4096] seed 0' if args.ctx == 'uniform' else args.ctx}, page_size=1, "
+                               f"{'HIP-graph replay' if not args.no_graph else 'eager'}",
+                   "batch_size": args.bs, "mean_context": round(avg_seq / args.bs, 1),
+                   "layers": cfg.num_hidden_layers, "replicas": world},
+        "step_hbm_roofline_tokens_per_sec": round(step_roofline_tok_s, 1),
+        "step_frac_of_hbm_roofline": round(value / world / step_roofline_tok_s, 4),
+    }
+    if roofline is not None:
+        out["roofline"] = roofline
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -107,9 +107,18 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  * kv_start may be NULL (= 0); it is the encoder offset of encoder-decoder models
  * (flashinfer_backend.py:593-621).  `chunk` tokens per split and `max_seq_len` (an upper bound
  * on every seq_lens[b], e.g. the context length under graph capture) fix the launch geometry:
- * num_splits = ceil(max_seq_len / chunk).  workspace: sp_decode_attention_workspace_bytes().     */
+ * num_splits = ceil(max_seq_len / chunk).  workspace: sp_decode_attention_workspace_bytes().
+ *
+ * `plan` (optional, may be NULL): the list of non-empty (request, split) items built by
+ * sp_decode_plan() from the same seq_lens / chunk, once per step, shared by all layers - the
+ * counterpart of flashinfer's begin_forward()/plan (flashinfer_backend.py:623-670) and of
+ * TritonAttnBackend.init_forward_metadata (triton_backend.py:48-68).  It changes only which
+ * workgroup does which split (XCD load balance on ragged batches), never the result.             */
 SP_API size_t sp_decode_attention_workspace_bytes(int batch_size, int num_q_heads, int v_head_dim,
                                            int64_t max_seq_len, int chunk);
+SP_API size_t sp_decode_plan_bytes(int batch_size, int64_t max_seq_len, int chunk);
+SP_API int sp_decode_plan(int32_t* plan, size_t plan_bytes, const void* seq_lens, int idx64,
+                   int batch_size, int64_t max_seq_len, int chunk, void* stream);
 SP_API int sp_decode_attention(void* out, const void* q, const void* k_buffer, const void* v_buffer,
                         const int32_t* req_to_token, int64_t req_to_token_stride,
                         const void* req_pool_indices, const void* seq_lens, const void* kv_start,
@@ -117,7 +126,7 @@ SP_API int sp_decode_attention(void* out, const void* q, const void* k_buffer, c
                         int head_dim, int64_t q_stride, int64_t out_stride,
                         int64_t kv_buffer_stride, float sm_scale, float logit_cap,
                         int64_t max_seq_len, int chunk, void* workspace, size_t workspace_bytes,
-                        int dtype, void* stream);
+                        const int32_t* plan, int dtype, void* stream);
 
 /* ---- Ragged extend (prefill) attention: replaces extend_attention_fwd (nn/attention/
  *      triton_attn/extend_attention.py:229-327; call site triton_backend.py:137-154) and the

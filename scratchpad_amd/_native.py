@@ -35,9 +35,11 @@ SIGNATURES = {
     "sp_compute_position": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp]),
     "sp_clamp_position": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "sp_decode_attention_workspace_bytes": (_sz, [_i32, _i32, _i32, _i64, _i32]),
+    "sp_decode_plan_bytes": (_sz, [_i32, _i64, _i32]),
+    "sp_decode_plan": (_i32, [_vp, _sz, _vp, _i32, _i32, _i64, _i32, _vp]),
     "sp_decode_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32,
                                    _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32, _i64, _i32,
-                                   _vp, _sz, _i32, _vp]),
+                                   _vp, _sz, _vp, _i32, _vp]),
     "sp_extend_attention_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32]),
     "sp_extend_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp,
                                    _i32, _i64, _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32,
@@ -249,13 +251,29 @@ def decode_workspace_bytes(bs: int, Hq: int, Dv: int, max_seq_len: int, chunk: i
     return int(load().sp_decode_attention_workspace_bytes(bs, Hq, Dv, max_seq_len, chunk))
 
 
+def decode_plan_bytes(bs: int, max_seq_len: int, chunk: int) -> int:
+    return int(load().sp_decode_plan_bytes(bs, max_seq_len, chunk))
+
+
+def decode_plan(plan: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int, chunk: int) -> None:
+    """Fill `plan` (int32) with the non-empty (request, split) items of this step."""
+    _gpu(plan, seq_lens)
+    if plan.dtype != torch.int32 or seq_lens.dtype not in (torch.int32, torch.int64):
+        raise RuntimeError("decode_plan: plan must be int32, seq_lens int32/int64")
+    seq_lens = seq_lens.contiguous()
+    _check(load().sp_decode_plan(plan.data_ptr(), plan.numel() * 4, seq_lens.data_ptr(),
+                                 int(seq_lens.dtype == torch.int64), seq_lens.shape[0], max_seq_len,
+                                 chunk, _stream()), "sp_decode_plan")
+
+
 def decode_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
                      v_buffer: torch.Tensor, req_to_token: torch.Tensor,
                      req_pool_indices: torch.Tensor, seq_lens: torch.Tensor, sm_scale: float,
                      logit_cap: float, max_seq_len: int, chunk: int, workspace: torch.Tensor,
-                     kv_start: Optional[torch.Tensor] = None) -> None:
+                     kv_start: Optional[torch.Tensor] = None,
+                     plan: Optional[torch.Tensor] = None) -> None:
     """q, out: [bs, Hq, D] (row stride free); buffers [P+1, Hkv, D]."""
-    _gpu(out, q, k_buffer, v_buffer, req_to_token, req_pool_indices, seq_lens, workspace, kv_start)
+    _gpu(out, q, k_buffer, v_buffer, req_to_token, req_pool_indices, seq_lens, workspace, kv_start, plan)
     bs, Hq, D = q.shape
     if q.stride(2) != 1 or q.stride(1) != D or out.stride(2) != 1 or out.stride(1) != D:
         raise RuntimeError("decode_attention: q/out must be [bs, Hq, D] with contiguous heads")
@@ -269,7 +287,7 @@ def decode_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
         req_to_token.stride(0), req.data_ptr(), seq.data_ptr(), _ptr(kv_start), idx64, bs, Hq,
         k_buffer.shape[1], D, q.stride(0), out.stride(0), k_buffer.stride(0), sm_scale, logit_cap,
         max_seq_len, chunk, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
-        _dt(q), _stream()), "sp_decode_attention")
+        _ptr(plan), _dt(q), _stream()), "sp_decode_attention")
 
 
 def extend_workspace_bytes(num_tokens: int, bs: int, Hq: int, D: int, dtype: torch.dtype) -> int:

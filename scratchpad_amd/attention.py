@@ -119,7 +119,9 @@ class HipAttnBackend(AttentionBackend):
         self.is_encoder_decoder = bool(getattr(cfg, "is_encoder_decoder", False))
         self.forward_metadata = None
         self._workspace = torch.empty(0, dtype=torch.uint8, device=self.device)
+        self._plans = [torch.empty(0, dtype=torch.int32, device=self.device) for _ in range(2)]
         self._graph_workspace = None
+        self._graph_plans = None
         self._graph_chunk = None
 
     # ---------------------------------------------------------------- launch planning
@@ -141,6 +143,22 @@ class HipAttnBackend(AttentionBackend):
             self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._workspace
 
+    def _build_plans(self, plans, bs, seq_lens, encoder_lens, max_len, chunk):
+        """One split plan per kv window (self-attention lens; encoder lens for cross-attention -
+        the reference keeps two flashinfer wrappers for the same reason, flashinfer_backend.py:
+        121-131).  Built once per step, read by every layer's launch."""
+        need = _native.decode_plan_bytes(bs, max_len, chunk) // 4
+        out = []
+        for i, lens in enumerate((seq_lens, encoder_lens)):
+            if lens is None:
+                out.append(None)
+                continue
+            if plans[i].numel() < need:
+                plans[i] = torch.empty(need, dtype=torch.int32, device=self.device)
+            _native.decode_plan(plans[i], lens, max_len, chunk)
+            out.append(plans[i])
+        return tuple(out)
+
     # ---------------------------------------------------------------- metadata hooks
     def init_forward_metadata(self, forward_batch: "ForwardBatch"):
         """Per-step plan.  Decode: (chunk, max_seq_len, workspace); extend: (max_extend_len,
@@ -159,7 +177,9 @@ class HipAttnBackend(AttentionBackend):
             chunk = self._plan_chunk(forward_batch.seq_lens_sum, pool_dtype)
             ws = self._ensure_workspace(_native.decode_workspace_bytes(
                 bs, self.num_head, self.v_head_dim, max_len, chunk))
-            self.forward_metadata = (chunk, max_len, ws)
+            enc = forward_batch.encoder_lens if self.is_encoder_decoder else None
+            plans = self._build_plans(self._plans, bs, forward_batch.seq_lens, enc, max_len, chunk)
+            self.forward_metadata = (chunk, max_len, ws, plans)
         else:
             max_extend = max(forward_batch.extend_seq_lens_cpu)
             if forward_batch.seq_lens_cpu is not None:
@@ -181,22 +201,30 @@ class HipAttnBackend(AttentionBackend):
         nbytes = _native.decode_workspace_bytes(max_bs, self.num_head, self.v_head_dim,
                                                 self.cuda_graph_max_seq_len, self._graph_chunk)
         self._graph_workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        n = _native.decode_plan_bytes(max_bs, self.cuda_graph_max_seq_len, self._graph_chunk) // 4
+        self._graph_plans = [torch.empty(n, dtype=torch.int32, device=self.device) for _ in range(2)]
 
     def init_forward_metadata_capture_cuda_graph(self, bs, num_tokens, req_pool_indices, seq_lens,
                                                  encoder_lens, forward_mode, spec_info=None):
         assert forward_mode.is_decode(), "only decode is captured"
         assert spec_info is None, "speculative decoding is out of scope"
+        plans = self._build_plans(self._graph_plans, bs, seq_lens, encoder_lens,
+                                  self.cuda_graph_max_seq_len, self._graph_chunk)
         self.forward_metadata = (self._graph_chunk, self.cuda_graph_max_seq_len,
-                                 self._graph_workspace)
+                                 self._graph_workspace, plans)
 
     def init_forward_metadata_replay_cuda_graph(self, bs, req_pool_indices, seq_lens, seq_lens_sum,
                                                 encoder_lens, forward_mode, spec_info=None,
                                                 seq_lens_cpu=None):
-        # geometry is static; the kernels read seq_lens / req_pool_indices from the graph's
-        # static input buffers, so there is nothing to rebuild (the reference recomputes
-        # start_loc / kv_indices here: triton_backend.py:103-113, flashinfer_backend.py:330-373)
+        # geometry is static and the kernels read seq_lens / req_pool_indices from the graph's
+        # static input buffers; only the split plan (static buffer, fixed address) is rebuilt for
+        # this step's lengths, ahead of the replay - where the reference recomputes start_loc /
+        # kv_indices (triton_backend.py:103-113, flashinfer_backend.py:330-373)
+        plans = self._build_plans(self._graph_plans, bs, seq_lens[:bs],
+                                  None if encoder_lens is None else encoder_lens[:bs],
+                                  self.cuda_graph_max_seq_len, self._graph_chunk)
         self.forward_metadata = (self._graph_chunk, self.cuda_graph_max_seq_len,
-                                 self._graph_workspace)
+                                 self._graph_workspace, plans)
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1  # padded rows attend to the dummy slot 0 only (triton_backend.py:115-116)
@@ -249,12 +277,13 @@ class HipAttnBackend(AttentionBackend):
         q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
         o = torch.empty_like(q)
         self._store(layer, forward_batch, k, v, save_kv_cache)
-        chunk, max_len, ws = self.forward_metadata
+        chunk, max_len, ws, plans = self.forward_metadata
         seq_lens, kv_start = self._kv_window(layer, forward_batch)
+        plan = plans[1] if layer.is_cross_attention else plans[0]
         kb, vb = forward_batch.token_to_kv_pool.get_kv_buffer(layer.layer_id)
         _native.decode_attention(
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), kb, vb,
             forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices, seq_lens,
-            layer.scaling, layer.logit_cap, max_len, chunk, ws, kv_start)
+            layer.scaling, layer.logit_cap, max_len, chunk, ws, kv_start, plan)
         return o

@@ -21,6 +21,7 @@ struct DecodeArgs {
   int chunk, num_splits, hh_shift, head_groups;
   float* part_o;    // [bs, Hq, num_splits, D]
   float* part_lse;  // [bs, Hq, num_splits]  (log2 domain)
+  const int32_t* plan;  // optional: [count, chunk, (b, c) x count] from sp_decode_plan
 };
 
 // decode_attention.hip: launch the split-KV decode kernel (+ merge when num_splits > 1)

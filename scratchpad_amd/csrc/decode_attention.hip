@@ -101,13 +101,23 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeArgs a) {
   constexpr int VEC = C::VEC, LPR = C::LPR, RPL = C::RPL, NB = C::NB, WAVES = C::WAVES;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
-  // blockIdx -> (request b, split c, head group hg); sibling head groups are adjacent so the two
-  // halves of a token's KV row are fetched at about the same time
-  int id = blockIdx.x;
-  const int hg = id % a.head_groups;
-  id /= a.head_groups;
-  const int c = id % a.num_splits;
-  const int b = id / a.num_splits;
+  // blockIdx -> (item, head group); sibling head groups are adjacent so the two halves of a
+  // token's KV row are fetched at about the same time.  With a plan (sp_decode_plan, built once
+  // per step and shared by all layers) item -> (request b, split c) walks only the NON-EMPTY
+  // splits, densely: the hardware deals workgroups to the 8 XCDs round-robin by blockIdx, each XCD
+  // with its own queue, so a static (b, c) grid with its empty splits leaves whole XCDs idle on
+  // ragged batches (measured on U[128,4096] contexts: 0.74x the fixed-length rate).
+  const int hg = blockIdx.x % a.head_groups;
+  const int item = blockIdx.x / a.head_groups;
+  int b, c;
+  if (a.plan) {
+    if (item >= a.plan[0]) return;
+    b = a.plan[2 + 2 * item];
+    c = a.plan[3 + 2 * item];
+  } else {
+    c = item % a.num_splits;
+    b = item / a.num_splits;
+  }
 
   const int seq = (int)load_idx(a.seq_lens, b, a.idx64);
   const int cs = c * a.chunk;
@@ -148,8 +158,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeArgs a) {
   const float cap = a.logit_cap;
   const float qk_scale = cap > 0.f ? a.sm_scale : a.sm_scale * kLog2e;
 
-  // this wave's contiguous share of the chunk
-  const int sub = (a.chunk + WAVES - 1) / WAVES;
+  // this wave's contiguous share of the chunk's ACTUAL tokens (a ragged last chunk is split
+  // evenly too, otherwise wave 0 alone sets the workgroup's duration), in whole wave-loads
+  const int sub = ((ce - cs + WAVES * TPL - 1) / (WAVES * TPL)) * TPL;
   const int ws = cs + wave * sub;
   const int we = min(ws + sub, ce);
 
@@ -307,6 +318,51 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
     E::store(a.out, (int64_t)b * a.o_stride + (int64_t)h * D + e * 64 + lane, o[e] / W);
 }
 
+// Build the list of non-empty (request, split) items: plan[0] = count, plan[2+2i], plan[3+2i] =
+// (b, c).  One workgroup; requests in tiles of 256 with a running offset.  Items are emitted in
+// two passes - all full splits first, the ragged last splits after them - so the short items
+// fill the tail of the launch.
+__global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ plan,
+                                                           const void* __restrict__ seq_lens,
+                                                           int idx64, int bs, int chunk) {
+  __shared__ int s_scan[256];
+  __shared__ int s_base;
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int t0 = 0; t0 < bs; t0 += 256) {
+      const int b = t0 + threadIdx.x;
+      int nfull = 0, tail = 0;
+      if (b < bs) {
+        const int seq = (int)load_idx(seq_lens, b, idx64);
+        nfull = seq > 0 ? seq / chunk : 0;
+        tail = seq > 0 && (seq % chunk) ? 1 : 0;
+      }
+      const int mine = pass == 0 ? nfull : tail;
+      s_scan[threadIdx.x] = mine;
+      __syncthreads();
+      for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan
+        const int v = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0;
+        __syncthreads();
+        s_scan[threadIdx.x] += v;
+        __syncthreads();
+      }
+      const int base = s_base + s_scan[threadIdx.x] - mine;
+      for (int i = 0; i < mine; ++i) {
+        plan[2 + 2 * (base + i)] = b;
+        plan[3 + 2 * (base + i)] = pass == 0 ? i : nfull;
+      }
+      __syncthreads();
+      if (threadIdx.x == 255) s_base += s_scan[255];
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0) {
+    plan[0] = s_base;
+    plan[1] = chunk;
+  }
+}
+
 template <typename Tag, int D, int G>
 static int launch_decode(const DecodeArgs& a, hipStream_t st) {
   typedef DecodeCfg<Tag, D, G> C;
@@ -378,6 +434,21 @@ extern "C" size_t sp_decode_attention_workspace_bytes(int batch_size, int num_q_
   return (size_t)batch_size * num_q_heads * s * (v_head_dim + 1) * sizeof(float) + 16;
 }
 
+extern "C" size_t sp_decode_plan_bytes(int batch_size, int64_t max_seq_len, int chunk) {
+  if (batch_size <= 0 || chunk <= 0) return 16;
+  return (size_t)(2 + 2 * (int64_t)batch_size * num_splits_for(max_seq_len, chunk)) * sizeof(int32_t);
+}
+
+extern "C" int sp_decode_plan(int32_t* plan, size_t plan_bytes, const void* seq_lens, int idx64,
+                              int batch_size, int64_t max_seq_len, int chunk, void* stream) {
+  SP_CHECK_ARG(plan && seq_lens && batch_size >= 0 && chunk >= 4 && chunk % 4 == 0);
+  if (plan_bytes < sp_decode_plan_bytes(batch_size, max_seq_len, chunk)) return SP_ERR_WORKSPACE;
+  decode_plan_kernel<<<dim3(1), 256, 0, (hipStream_t)stream>>>(plan, seq_lens, idx64, batch_size,
+                                                               chunk);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
 extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffer,
                                    const void* v_buffer, const int32_t* req_to_token,
                                    int64_t req_to_token_stride, const void* req_pool_indices,
@@ -385,8 +456,8 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
                                    int batch_size, int num_q_heads, int num_kv_heads, int head_dim,
                                    int64_t q_stride, int64_t out_stride, int64_t kv_buffer_stride,
                                    float sm_scale, float logit_cap, int64_t max_seq_len, int chunk,
-                                   void* workspace, size_t workspace_bytes, int dtype,
-                                   void* stream) {
+                                   void* workspace, size_t workspace_bytes, const int32_t* plan,
+                                   int dtype, void* stream) {
   SP_CHECK_ARG(out && q && k_buffer && v_buffer && req_to_token && req_pool_indices && seq_lens);
   SP_CHECK_ARG(batch_size >= 0 && num_q_heads > 0 && num_kv_heads > 0 && head_dim > 0);
   SP_CHECK_ARG(num_q_heads % num_kv_heads == 0 && max_seq_len >= 0);
@@ -415,7 +486,7 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
   a.seq_lens = seq_lens; a.kv_start = kv_start; a.idx64 = idx64; a.bs = batch_size;
   a.Hq = num_q_heads; a.Hkv = num_kv_heads; a.q_stride = q_stride; a.o_stride = out_stride;
   a.kv_stride = kv_buffer_stride; a.sm_scale = sm_scale; a.logit_cap = logit_cap;
-  a.chunk = chunk; a.num_splits = (int)S;
+  a.chunk = chunk; a.num_splits = (int)S; a.plan = plan;
   a.hh_shift = decode_heads_per_load_shift(num_kv_heads, head_dim, dtype, &a.head_groups);
   a.part_o = nullptr; a.part_lse = nullptr;
   if (S > 1) {

@@ -98,6 +98,6 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
   if (chunk > 0x7ffffff0LL) return SP_ERR_INVALID_ARG;
   a.chunk = (int)chunk; a.num_splits = 1;
   a.hh_shift = decode_heads_per_load_shift(num_kv_heads, head_dim, dtype, &a.head_groups);
-  a.part_o = nullptr; a.part_lse = nullptr;
+  a.part_o = nullptr; a.part_lse = nullptr; a.plan = nullptr;
   return run_decode(a, head_dim, G, dtype, st);
 }

@@ -23,7 +23,8 @@ def nat():
     return _native
 
 
-def run_decode(nat, p, scale, cap=0.0, chunk=64, max_len=None, kv_start=None, idx_dtype=None):
+def run_decode(nat, p, scale, cap=0.0, chunk=64, max_len=None, kv_start=None, idx_dtype=None,
+               use_plan=True):
     q = p["q"]
     bs, Hq, D = q.shape
     seq, req = p["seq_lens"], p["req_pool_indices"]
@@ -33,8 +34,12 @@ def run_decode(nat, p, scale, cap=0.0, chunk=64, max_len=None, kv_start=None, id
         max_len = int(p["seq_lens"].max())
     ws = torch.empty(nat.decode_workspace_bytes(bs, Hq, D, max_len, chunk), dtype=torch.uint8, device=DEV)
     o = torch.full_like(q, float("nan"))
+    plan = None
+    if use_plan:   # the per-step split plan the backend builds in init_forward_metadata
+        plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk) // 4, dtype=torch.int32, device=DEV)
+        nat.decode_plan(plan, seq, max_len, chunk)
     nat.decode_attention(o, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], req, seq, scale, cap,
-                         max_len, chunk, ws, kv_start)
+                         max_len, chunk, ws, kv_start, plan)
     return o
 
 
@@ -147,6 +152,38 @@ def test_decode_edge_cases(nat):
     p = paged_problem(13, 2, 4, 1, 128, [300, 77], torch.float32, DEV)
     p["k_buffer"][p["req_to_token"][p["req_pool_indices"][0], 200].long()] *= 40
     assert_close(run_decode(nat, p, 1.0, chunk=512), oracle_decode(p, 1.0), torch.float32, what="spike")
+
+
+def test_decode_plan_is_exact_and_changes_nothing(nat):
+    """plan = the non-empty (request, split) items, full splits first; same bits with or without"""
+    lens = [1, 64, 65, 128, 500, 0, 129, 1000, 3, 640]
+    p = paged_problem(16, len(lens), 32, 8, 128, [max(l, 1) for l in lens], torch.bfloat16, DEV)
+    p["seq_lens"] = torch.tensor(lens, device=DEV)
+    chunk = 64
+    plan = torch.empty(nat.decode_plan_bytes(len(lens), 1000, chunk) // 4, dtype=torch.int32, device=DEV)
+    nat.decode_plan(plan, p["seq_lens"], 1000, chunk)
+    pl = plan.cpu().tolist()
+    want_full = [(b, c) for b, l in enumerate(lens) for c in range(l // chunk)]
+    want_tail = [(b, l // chunk) for b, l in enumerate(lens) if l % chunk]
+    n = pl[0]
+    assert n == len(want_full) + len(want_tail) and pl[1] == chunk
+    got = [(pl[2 + 2 * i], pl[3 + 2 * i]) for i in range(n)]
+    assert got == want_full + want_tail
+    # 700 requests: the scan crosses several 256-request tiles
+    gen = torch.Generator().manual_seed(17)
+    seq = torch.randint(0, 900, (700,), generator=gen)
+    plan = torch.empty(nat.decode_plan_bytes(700, 900, 128) // 4, dtype=torch.int32, device=DEV)
+    nat.decode_plan(plan, seq.to(DEV), 900, 128)
+    pl = plan.cpu()
+    assert int(pl[0]) == int(((seq + 127) // 128).sum())
+    items = pl[2:2 + 2 * int(pl[0])].view(-1, 2)
+    key = items[:, 0].long() * 100 + items[:, 1].long()
+    want = torch.cat([b * 100 + torch.arange((int(l) + 127) // 128) for b, l in enumerate(seq.tolist())])
+    assert torch.equal(torch.sort(key).values, torch.sort(want).values), "every item exactly once"
+    a = run_decode(nat, p, 0.1, chunk=chunk, use_plan=True)
+    b = run_decode(nat, p, 0.1, chunk=chunk, use_plan=False)
+    keep = [i for i, l in enumerate(lens) if l > 0]
+    assert torch.equal(a[keep], b[keep])
 
 
 def test_decode_rejects_bad_arguments(nat):

@@ -25,7 +25,8 @@ def test_header_declares_the_whole_path():
     syms = header_symbols()
     for s in ["sp_rmsnorm", "sp_fused_add_rmsnorm", "sp_silu_and_mul", "sp_rotary_embedding",
               "sp_kv_store", "sp_write_req_to_token", "sp_compute_position", "sp_clamp_position",
-              "sp_decode_attention", "sp_decode_attention_workspace_bytes", "sp_extend_attention",
+              "sp_decode_attention", "sp_decode_attention_workspace_bytes", "sp_decode_plan",
+              "sp_decode_plan_bytes", "sp_extend_attention",
               "sp_extend_attention_workspace_bytes", "sp_abi_version", "sp_status_string"]:
         assert s in syms
 

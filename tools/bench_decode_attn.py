@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of sp_decode_attention on the headline workload's shapes (no model around it).
+
+  python tools/bench_decode_attn.py [--bs 256] [--ctx uniform|N] [--chunks 128,256,512] [--iters 20]
+Prints one line per chunk: avg launch time (HIP events on the launch stream), algorithmic GB/s."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scratchpad_amd import _native  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bs", type=int, default=256)
+    ap.add_argument("--ctx", default="uniform")
+    ap.add_argument("--Hq", type=int, default=32)
+    ap.add_argument("--Hkv", type=int, default=8)
+    ap.add_argument("--D", type=int, default=128)
+    ap.add_argument("--chunks", default="128,256,512,1024")
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--no-plan", action="store_true")
+    ap.add_argument("--gemm", action="store_true", help="interleave a bf16 GEMM between launches (as in a model)")
+    a = ap.parse_args()
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
+    dev = "cuda"
+    g = torch.Generator().manual_seed(0)
+    ctx = (torch.randint(128, 4097, (a.bs,), generator=g) if a.ctx == "uniform"
+           else torch.full((a.bs,), int(a.ctx)))
+    total = int(ctx.sum())
+    P = total + 1024
+    kb = torch.empty(P + 1, a.Hkv, a.D, dtype=dt, device=dev).normal_(0, 0.5)
+    vb = torch.empty(P + 1, a.Hkv, a.D, dtype=dt, device=dev).normal_(0, 0.5)
+    perm = (torch.randperm(P, generator=g) + 1).to(torch.int32)
+    r2t = torch.zeros(a.bs, int(ctx.max()) + 8, dtype=torch.int32)
+    off = 0
+    for b in range(a.bs):
+        n = int(ctx[b])
+        r2t[b, :n] = perm[off:off + n]
+        off += n
+    r2t = r2t.to(dev)
+    req = torch.arange(a.bs, dtype=torch.int32, device=dev)
+    seq = ctx.to(torch.int32).to(dev)
+    q = torch.randn(a.bs, a.Hq, a.D, device=dev).to(dt)
+    o = torch.empty_like(q)
+    eb = q.element_size()
+    alg = total * 2 * a.Hkv * a.D * eb + 2 * a.bs * a.Hq * a.D * eb + 4 * total
+    max_len = int(ctx.max())
+    ref = None
+    for chunk in [int(c) for c in a.chunks.split(",")]:
+        ws = torch.empty(_native.decode_workspace_bytes(a.bs, a.Hq, a.D, max_len, chunk), dtype=torch.uint8, device=dev)
+        plan = None
+        if not a.no_plan:
+            plan = torch.empty(_native.decode_plan_bytes(a.bs, max_len, chunk) // 4, dtype=torch.int32, device=dev)
+            _native.decode_plan(plan, seq, max_len, chunk)
+        run = lambda: _native.decode_attention(o, q, kb, vb, r2t, req, seq, a.D ** -0.5, 0.0, max_len, chunk, ws, None, plan)
+        for _ in range(a.warmup):
+            run()
+        torch.cuda.synchronize()
+        evs = []
+        if a.gemm:
+            ga = torch.randn(256, 4096, device=dev, dtype=torch.bfloat16)
+            gw = torch.randn(28672, 4096, device=dev, dtype=torch.bfloat16)
+        for _ in range(a.iters):
+            if a.gemm:
+                torch.nn.functional.linear(ga, gw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); run(); e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        ms = sorted(x.elapsed_time(y) for x, y in evs)
+        med, best = ms[len(ms) // 2], ms[0]
+        msg = f"chunk {chunk:5d}: median {med * 1e3:8.1f} us  best {best * 1e3:8.1f} us  {alg / med / 1e6:8.1f} GB/s (median)  alg bytes {alg / 1e9:.3f} GB"
+        if a.check:
+            if ref is None:
+                ref = o.float().clone()
+            msg += f"  max|d| vs first {float((o.float() - ref).abs().max()):.2e}"
+        print(msg, flush=True)
+
+
+if __name__ == "__main__":
+    main()
