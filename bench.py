@@ -115,12 +115,24 @@ def attention_algorithmic_bytes(cfg, seq_sum, bs, elem=2):
     return kv + qo + 4 * seq_sum
 
 
+def usable_cores() -> int:
+    """host cores this process may actually use (affinity mask and cgroup CPU quota)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(bs=8, ctx=512, layers=2, seconds=12.0):
     """The oracle's decode step (oracle/llama.py, plain torch fp32) on the host cores: Llama-3-8B
     layer shapes, `layers` layers, bs x ctx; extrapolated to 32 layers + lm_head."""
     from oracle import llama as ollama
     from oracle import ops
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     shape = ollama.LlamaShape(4096, 14336, layers, 32, 8, 128256, False, 500000.0, None, 8192, 1e-5)
     g = torch.Generator().manual_seed(0)
@@ -246,9 +258,17 @@ def main():
         avg_ms = sum(ms) / len(ms)
         alg = sum(attention_algorithmic_bytes(cfg, s, args.bs) for s in sums) / len(sums)
         achieved = alg / (avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per
+        # the gfx950 correction + WRITE_SIZE, same shapes): measured traffic/algorithmic ratio
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_decode_attn_pmc.json")
+        if os.path.exists(pmc) and args.model == "llama3-8b":
+            ratio = json.load(open(pmc))["traffic_over_algorithmic"]
+            traffic, traffic_src = int(alg * ratio), "profiles/r01_decode_attn_pmc.txt (PMC ratio x algorithmic)"
         roofline = {"bound": "hbm", "kernel": "decode_attn_kernel+decode_merge_kernel",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "avg_launch_ms": round(avg_ms, 4), "launches": len(ms),
                     "algorithmic_bytes_per_launch": int(alg)}
 

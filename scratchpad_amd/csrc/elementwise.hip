@@ -3,7 +3,7 @@
 // (cdna_hip_programming.md Guideline 13); each has a scalar twin for odd shapes / alignments.
 //
 // Rounding points follow the reference's torch path (forward_native) so that 16-bit results
-// are bit-comparable with the oracle: see the per-kernel comments.
+// are bit-comparable with torch's tensor arithmetic: see the per-kernel comments.
 #include "sp_common.h"
 
 // The rounding points below must survive to the ISA.  With the default -ffp-contract=fast hipcc

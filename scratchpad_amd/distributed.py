@@ -69,9 +69,12 @@ class GroupCoordinator:
         if dim < 0:
             dim += input_.dim()
         input_size = input_.size()
-        output = torch.empty((world_size,) + input_size, dtype=input_.dtype, device=input_.device)
-        dist.all_gather_into_tensor(output, input_.contiguous(), group=self.device_group)
-        output = output.movedim(0, dim)
+        # rank-major concatenation along dim 0 (a layout gloo and RCCL both accept), then viewed
+        # as [world, *input] exactly like the reference's output tensor
+        flat = torch.empty((world_size * input_size[0],) + tuple(input_size[1:]), dtype=input_.dtype,
+                           device=input_.device)
+        dist.all_gather_into_tensor(flat, input_.contiguous(), group=self.device_group)
+        output = flat.view((world_size,) + tuple(input_size)).movedim(0, dim)
         return output.reshape(input_size[:dim] + (world_size * input_size[dim],) + input_size[dim + 1:])
 
     def broadcast_object(self, obj=None, src: int = 0):

@@ -1,0 +1,146 @@
+"""CPU tests of the host-side mirror: pools/allocator against the reference's recorded trace,
+ForwardMode semantics, rope cache construction, TP shard math, graph buckets."""
+import numpy as np
+import pytest
+import torch
+
+from scratchpad_amd import distributed as dist_
+from scratchpad_amd.forward_info import CaptureHiddenMode, ForwardMode
+from scratchpad_amd.layers import get_rope
+from scratchpad_amd.model_runner import ModelConfig, ServerArgs, get_batch_sizes_to_capture
+from scratchpad_amd.pool import KVCache, MHATokenToKVPool, ReqToTokenPool, TokenToKVPoolAllocator
+from tests import golden
+
+
+def test_allocator_trace_matches_reference():
+    g = golden.load("kv_pool")
+    alloc = TokenToKVPoolAllocator(16, torch.float32, "cpu", None)
+    assert alloc.free_slots.dtype == torch.int64 and alloc.page_size == 1
+    a0 = alloc.alloc(5)
+    a1 = alloc.alloc(4)
+    assert alloc.available_size() == int(g["alloc_avail0"])
+    alloc.free(a0[1:3])
+    a2 = alloc.alloc(8)
+    assert (alloc.alloc(100) is None) == bool(g["alloc_too_many_is_none"])
+    state = alloc.backup_state()
+    a3 = alloc.alloc(1)
+    alloc.restore_state(state)
+    a4 = alloc.alloc(1)
+    alloc.free_group_begin()
+    alloc.free(a1[:2])
+    alloc.free(a2[:3])
+    assert alloc.available_size() == int(g["alloc_avail_in_group"])
+    alloc.free_group_end()
+    for name, val in (("a0", a0), ("a1", a1), ("a2", a2), ("a3", a3), ("a4", a4)):
+        assert np.array_equal(val.numpy(), g["alloc_" + name]), name
+    assert np.array_equal(alloc.free_slots.numpy(), g["alloc_free_final"])
+    alloc.free(torch.empty(0, dtype=torch.int64))          # no-op
+    alloc.clear()
+    assert np.array_equal(alloc.free_slots.numpy(), g["alloc_free_after_clear"])
+    assert 0 not in alloc.free_slots.tolist(), "slot 0 is the reserved dummy slot"
+
+
+def test_req_to_token_pool_trace_matches_reference():
+    g = golden.load("kv_pool")
+    r2t = ReqToTokenPool(5, 12, "cpu", False)
+    assert r2t.req_to_token.dtype == torch.int32
+    r0 = r2t.alloc(2)
+    r1 = r2t.alloc(2)
+    r2t.free(r0[0])
+    r2 = r2t.alloc(2)
+    assert (r2t.alloc(3) is None) == bool(g["r2t_none"])
+    r2t.write((torch.tensor([1, 3]), torch.tensor([4, 7])), torch.tensor([11, 13], dtype=torch.int32))
+    r2t.write((2, slice(0, 3)), torch.tensor([5, 6, 7], dtype=torch.int32))
+    assert r0 == g["r2t_r0"].tolist() and r1 == g["r2t_r1"].tolist() and r2 == g["r2t_r2"].tolist()
+    assert np.array_equal(r2t.req_to_token.numpy(), g["r2t_table"])
+    assert r2t.available_size() == int(g["r2t_avail"])
+    rec = ReqToTokenPool(3, 4, "cpu", True)
+    rec.write((0, slice(0, 2)), torch.tensor([9, 8], dtype=torch.int32))
+    records = rec.get_write_records()
+    other = ReqToTokenPool(3, 4, "cpu", False)
+    other.apply_write_records(records)
+    assert torch.equal(other.req_to_token, rec.req_to_token) and rec.get_write_records() == []
+
+
+def test_kv_pool_layout_and_guards():
+    pool = MHATokenToKVPool(10, 1, torch.bfloat16, 2, 64, 3, "cpu")
+    assert isinstance(pool, KVCache)
+    k = pool.get_key_buffer(1)
+    assert k.shape == (11, 2, 64) and k.stride() == (128, 64, 1), "[size+1, Hkv, D] token-major"
+    # one arena per K/V: layer l is a view at l * (size+1) rows
+    assert pool.get_key_buffer(2).data_ptr() - pool.get_key_buffer(1).data_ptr() == 11 * 128 * 2
+    kb, vb = pool.get_kv_buffer(0)
+    assert kb.data_ptr() != vb.data_ptr()
+    assert pool.get_kv_size_bytes() == (3 * 11 * 128 * 2,) * 2
+    with pytest.raises(NotImplementedError):
+        MHATokenToKVPool(10, 16, torch.bfloat16, 2, 64, 1, "cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):   # the store itself is HIP-only
+        from types import SimpleNamespace
+        pool.set_kv_buffer(SimpleNamespace(layer_id=0), torch.tensor([1]), torch.zeros(1, 2, 64, dtype=torch.bfloat16),
+                           torch.zeros(1, 2, 64, dtype=torch.bfloat16))
+
+
+def test_forward_mode_semantics():
+    # forward_info.py:38-66 (the reference compares against the raw ints 1..7)
+    assert [int(m) for m in ForwardMode] == [1, 2, 3, 4, 5, 6, 7]
+    assert ForwardMode.EXTEND.is_extend() and ForwardMode.MIXED.is_extend()
+    assert not ForwardMode.DECODE.is_extend() and ForwardMode.DECODE.is_decode()
+    assert ForwardMode.MIXED.is_mixed() and ForwardMode.IDLE.is_idle()
+    assert ForwardMode.DECODE.is_cuda_graph() and ForwardMode.IDLE.is_cuda_graph()
+    assert ForwardMode.TARGET_VERIFY.is_cuda_graph() and not ForwardMode.EXTEND.is_cuda_graph()
+    assert ForwardMode.IDLE.is_decode_or_idle() and ForwardMode.DUMMY_FIRST.is_dummy_first()
+    assert not CaptureHiddenMode.NULL.need_capture() and CaptureHiddenMode.LAST.is_last()
+
+
+def test_rope_cache_is_the_references_bit_for_bit():
+    g = golden.load("rotary")
+    for i in range(int(g["num_cases"])):
+        sc = None
+        if f"c{i}_scaling" in g:
+            f = g[f"c{i}_scaling"]
+            sc = {"rope_type": "llama3", "factor": float(f[0]), "low_freq_factor": float(f[1]),
+                  "high_freq_factor": float(f[2]), "original_max_position_embeddings": int(f[3])}
+        rope = get_rope(int(g[f"c{i}_head_size"]), int(g[f"c{i}_rotary_dim"]), int(g[f"c{i}_max_pos"]),
+                        float(g[f"c{i}_base"]), bool(g[f"c{i}_neox"]), sc, dtype=torch.float32)
+        assert np.array_equal(rope.cos_sin_cache.numpy(), g[f"c{i}_cos_sin_cache"]), f"case {i}"
+    a = get_rope(64, 64, 128, 10000, True, None, torch.float32)
+    assert a is get_rope(64, 64, 128, 10000, True, None, torch.float32), "cached per key"
+    assert get_rope(64, 64, 128, 10000, True, None, torch.float32, partial_rotary_factor=0.5).rotary_dim == 32
+    with pytest.raises(ValueError):
+        get_rope(64, 64, 128, 10000, True, {"rope_type": "yarn", "factor": 2.0}, torch.float32)
+
+
+def test_model_config_head_math_and_graph_buckets():
+    c8, c70 = ModelConfig.llama3_8b(), ModelConfig.llama3_70b()
+    assert (c8.head_dim, c8.get_num_kv_heads(1), c8.get_num_kv_heads(8), c8.get_num_kv_heads(16)) == (128, 8, 1, 1)
+    assert c70.num_attention_heads // 8 == 8 and c70.get_num_kv_heads(8) == 1
+    assert ModelConfig.llama32_1b().head_dim == 64
+    assert get_batch_sizes_to_capture(ServerArgs(cuda_graph_max_bs=160), 4096) == \
+        [1, 2, 4, 8] + list(range(16, 161, 8))          # the reference's list (cuda_graph_runner.py:100)
+    assert get_batch_sizes_to_capture(ServerArgs(), 4096)[-1] == 256
+    assert get_batch_sizes_to_capture(ServerArgs(cuda_graph_bs=[4, 300, 64]), 100) == [4, 64]
+
+
+def test_runner_refuses_to_run_without_a_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from scratchpad_amd.model_runner import ModelRunner
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ModelRunner(ModelConfig(64, 128, 1, 2, 1, 100))
+    with pytest.raises(RuntimeError, match="unsupported device"):
+        ModelRunner(ModelConfig(64, 128, 1, 2, 1, 100), device="cpu")
+
+
+def test_qkv_shard_math_single_rank():
+    """tp=1: the merged layout is [q | k | v] (linear.py:746-760)"""
+    dist_.destroy_model_parallel()
+    dist_.initialize_model_parallel(1)
+    from scratchpad_amd.llama import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
+    qkv = QKVParallelLinear(64, 16, 4, 2)
+    assert (qkv.num_heads, qkv.num_kv_heads, qkv.num_kv_head_replicas) == (4, 2, 1)
+    assert qkv.weight.shape == ((4 + 2 * 2) * 16, 64)
+    full = torch.arange(128 * 64, dtype=torch.float32).view(128, 64)
+    assert torch.equal(qkv.shard_from_full(full), full)
+    assert MergedColumnParallelLinear(64, [96, 96]).weight.shape == (192, 64)
+    assert RowParallelLinear(96, 64).weight.shape == (64, 96)
+    dist_.destroy_model_parallel()
