@@ -157,6 +157,19 @@ def _softcap(s: torch.Tensor, cap: float) -> torch.Tensor:
     return cap * torch.tanh(s / cap) if cap > 0 else s
 
 
+def _softmax_parts(s: torch.Tensor, dtype: torch.dtype):
+    """exp(s - rowmax) and its fp32 row sum.  As in the reference's kernels the probabilities are
+    cast to the KV dtype before the P.V product while the denominator keeps the unrounded fp32 sum
+    (decode_attention.py:421-428 `e_sum += sum(p); p = p.to(v.dtype)`; extend_attention.py:150-156).
+    A no-op for fp32 inputs."""
+    m = s.amax(dim=-1, keepdim=True)
+    p = torch.exp(s - m)
+    denom = p.sum(dim=-1, keepdim=True)
+    if dtype in (torch.float16, torch.bfloat16):
+        p = p.to(dtype).to(torch.float32)
+    return p, denom
+
+
 def decode_attention(q: torch.Tensor, k_buffer: torch.Tensor, v_buffer: torch.Tensor,
                      req_to_token: torch.Tensor, req_pool_indices: torch.Tensor,
                      seq_lens: torch.Tensor, sm_scale: float, logit_cap: float = 0.0,
@@ -185,8 +198,8 @@ def decode_attention(q: torch.Tensor, k_buffer: torch.Tensor, v_buffer: torch.Te
         qb = q[b].to(torch.float32).view(Hkv, g, D)
         s = torch.einsum("hgd,lhd->hgl", qb, k) * sm_scale
         s = _softcap(s, logit_cap)
-        p = torch.softmax(s, dim=-1)
-        o[b] = torch.einsum("hgl,lhd->hgd", p, v).reshape(Hq, Dv)
+        p, denom = _softmax_parts(s, q.dtype)
+        o[b] = (torch.einsum("hgl,lhd->hgd", p, v) / denom).reshape(Hq, Dv)
     return o.to(q.dtype)
 
 
@@ -213,7 +226,7 @@ def extend_attention(q: torch.Tensor, k_buffer: torch.Tensor, v_buffer: torch.Te
     o = torch.zeros(T, Hq, Dv, dtype=torch.float32)
     for b in range(req_pool_indices.shape[0]):
         L, E = int(seq_lens[b]), int(extend_seq_lens[b])
-        if E == 0:
+        if E == 0 or L == 0:   # no new rows / no visible keys (text-only row of cross-attention): zeros
             continue
         s0 = int(extend_start_loc[b])
         off = 0 if kv_start is None else int(kv_start[b])
@@ -231,8 +244,8 @@ def extend_attention(q: torch.Tensor, k_buffer: torch.Tensor, v_buffer: torch.Te
             col = torch.arange(L).view(1, L)
             row = torch.arange(E).view(E, 1) + P
             s = s.masked_fill(col > row, float("-inf"))
-        p = torch.softmax(s, dim=-1)
-        o[s0:s0 + E] = torch.einsum("hgel,lhd->ehgd", p, v).reshape(E, Hq, Dv)
+        p, denom = _softmax_parts(s, q.dtype)
+        o[s0:s0 + E] = (torch.einsum("hgel,lhd->hged", p, v) / denom).permute(2, 0, 1, 3).reshape(E, Hq, Dv)
     return o.to(q.dtype)
 
 

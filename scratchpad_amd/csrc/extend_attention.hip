@@ -78,6 +78,17 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
   if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) return SP_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
 
+  // 16-bit dtypes run on the matrix cores (extend_mfma.hip); fp32 and unsupported shapes take the
+  // row-stream path below
+  {
+    const int rc = run_extend_mfma(out, q, k_buffer, v_buffer, req_to_token, req_to_token_stride,
+                                   req_pool_indices, seq_lens, kv_start, idx64, extend_seq_lens,
+                                   extend_start_loc, batch_size, num_q_heads, num_kv_heads, head_dim,
+                                   q_stride, out_stride, kv_buffer_stride, sm_scale, logit_cap, causal,
+                                   max_extend_len, dtype, st);
+    if (rc != SP_ERR_UNSUPPORTED) return rc;
+  }
+
   int32_t* row_req = (int32_t*)workspace;
   int32_t* row_len = row_req + num_tokens;
   int32_t* row_kv0 = row_len + num_tokens;

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of sp_extend_attention (ragged prefill) on config-3 shapes:
+bs prompts with lengths U[128,4096] seed 0, optional shared cached prefix.
+  python tools/bench_extend_attn.py [--bs 64] [--prefix 0] [--Hq 32 --Hkv 8 --D 128]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scratchpad_amd import _native  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bs", type=int, default=64)
+    ap.add_argument("--prefix", type=int, default=0)
+    ap.add_argument("--len", default="uniform")
+    ap.add_argument("--Hq", type=int, default=32)
+    ap.add_argument("--Hkv", type=int, default=8)
+    ap.add_argument("--D", type=int, default=128)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--dtype", default="bf16")
+    a = ap.parse_args()
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
+    dev = "cuda"
+    g = torch.Generator().manual_seed(0)
+    ext = (torch.randint(128, 4097, (a.bs,), generator=g) if a.len == "uniform"
+           else torch.full((a.bs,), int(a.len)))
+    pre = torch.full((a.bs,), a.prefix)
+    seq = ext + pre
+    total = int(seq.sum())
+    P = total + 64
+    kb = torch.empty(P + 1, a.Hkv, a.D, dtype=dt, device=dev).normal_(0, 0.5)
+    vb = torch.empty(P + 1, a.Hkv, a.D, dtype=dt, device=dev).normal_(0, 0.5)
+    perm = (torch.randperm(P, generator=g) + 1).to(torch.int32)
+    r2t = torch.zeros(a.bs, int(seq.max()) + 8, dtype=torch.int32)
+    off = 0
+    for b in range(a.bs):
+        n = int(seq[b])
+        r2t[b, :n] = perm[off:off + n]
+        off += n
+    r2t = r2t.to(dev)
+    T = int(ext.sum())
+    q = torch.randn(T, a.Hq, a.D, device=dev).to(dt)
+    o = torch.empty_like(q)
+    req = torch.arange(a.bs, device=dev)
+    ext_d = ext.to(torch.int32).to(dev)
+    start = torch.zeros(a.bs, dtype=torch.int32, device=dev)
+    start[1:] = torch.cumsum(ext_d[:-1], 0)
+    ws = torch.empty(_native.extend_workspace_bytes(T, a.bs, a.Hq, a.D, dt), dtype=torch.uint8, device=dev)
+    seq_d = seq.to(dev)
+    run = lambda: _native.extend_attention(o, q, kb, vb, r2t, req, seq_d, ext_d, start, a.D ** -0.5, 0.0, True,
+                                           int(ext.max()), int(seq.max()), ws)
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.iters
+    flops = 4 * a.Hq * a.D * float(((ext.double() ** 2) / 2 + ext.double() * pre.double()).sum())
+    print(f"extend bs={a.bs} tokens={T} prefix={a.prefix} {a.dtype}: {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s "
+          f"(causal flops {flops / 1e12:.2f} T)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
