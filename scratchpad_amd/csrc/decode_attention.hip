@@ -164,9 +164,13 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeArgs a) {
   const int ws = cs + wave * sub;
   const int we = min(ws + sub, ce);
 
-  for (int ps = ws; ps < we; ps += 64) {  // pieces of <= 64 tokens: one index register
+  // pieces of <= 64 tokens: one index register each, fetched one piece ahead so the dependent
+  // req_to_token -> KV row chain is paid once per workgroup, not once per piece
+  int nextidx = (ws + lane < we) ? idx_row[ws + lane] : 0;
+  for (int ps = ws; ps < we; ps += 64) {
     const int n = min(64, we - ps);
-    const int myidx = lane < n ? idx_row[ps + lane] : 0;
+    const int myidx = nextidx;
+    nextidx = (ps + 64 + lane < we) ? idx_row[ps + 64 + lane] : 0;
     const int nloads = (n + TPL - 1) / TPL;
 
     u32x4 kA[NB], vA[NB], kB[NB], vB[NB];
@@ -319,9 +323,9 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
 }
 
 // Build the list of non-empty (request, split) items: plan[0] = count, plan[2+2i], plan[3+2i] =
-// (b, c).  One workgroup; requests in tiles of 256 with a running offset.  Items are emitted in
-// two passes - all full splits first, the ragged last splits after them - so the short items
-// fill the tail of the launch.
+// (b, c).  One workgroup; requests in tiles of 256 with a running offset.  Items are emitted
+// longest-first: all full splits, then the ragged last splits in four length classes (longest
+// quarter first), so the launch ends on its shortest items.
 __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ plan,
                                                            const void* __restrict__ seq_lens,
                                                            int idx64, int bs, int chunk) {
@@ -329,14 +333,16 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ 
   __shared__ int s_base;
   if (threadIdx.x == 0) s_base = 0;
   __syncthreads();
-  for (int pass = 0; pass < 2; ++pass) {
+  for (int pass = 0; pass < 5; ++pass) {
     for (int t0 = 0; t0 < bs; t0 += 256) {
       const int b = t0 + threadIdx.x;
       int nfull = 0, tail = 0;
       if (b < bs) {
         const int seq = (int)load_idx(seq_lens, b, idx64);
         nfull = seq > 0 ? seq / chunk : 0;
-        tail = seq > 0 && (seq % chunk) ? 1 : 0;
+        const int rem = seq > 0 ? seq % chunk : 0;
+        // tail class 3 = longest quarter of the chunk ... 0 = shortest; pass 1 takes class 3
+        tail = rem > 0 && (4 - pass) == (int)(((int64_t)rem * 4 - 1) / chunk) ? 1 : 0;
       }
       const int mine = pass == 0 ? nfull : tail;
       s_scan[threadIdx.x] = mine;

@@ -164,7 +164,10 @@ def test_decode_plan_is_exact_and_changes_nothing(nat):
     nat.decode_plan(plan, p["seq_lens"], 1000, chunk)
     pl = plan.cpu().tolist()
     want_full = [(b, c) for b, l in enumerate(lens) for c in range(l // chunk)]
-    want_tail = [(b, l // chunk) for b, l in enumerate(lens) if l % chunk]
+    want_tail = []          # ragged last splits, longest quarter-of-a-chunk class first
+    for cls in (3, 2, 1, 0):
+        want_tail += [(b, l // chunk) for b, l in enumerate(lens)
+                      if l % chunk and ((l % chunk) * 4 - 1) // chunk == cls]
     n = pl[0]
     assert n == len(want_full) + len(want_tail) and pl[1] == chunk
     got = [(pl[2 + 2 * i], pl[3 + 2 * i]) for i in range(n)]
