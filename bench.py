@@ -42,6 +42,11 @@ def parse_args():
     ap.add_argument("--layers", type=int, default=None, help="override layer count (debug only)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="decode", choices=["decode", "prefill"],
+                    help="decode = the headline metric; prefill = config 3 (ragged prefill, TTFT)")
+    ap.add_argument("--prefix", type=int, default=0, help="prefill mode: shared cached prefix length")
+    ap.add_argument("--max-prefill-tokens", type=int, default=16384,
+                    help="prefill mode: tokens per extend batch (server/args.py max_prefill_tokens)")
     ap.add_argument("--profile-steps", type=int, default=4,
                     help="extra eager steps with HIP events around every attention launch")
     return ap.parse_args()
@@ -183,6 +188,85 @@ def cpu_baseline(bs=8, ctx=512, layers=2, seconds=12.0):
                       f"({t_head * 1e3:.1f} ms), extrapolated to 32 layers"}
 
 
+def prefill_main(args, rank, local_rank, world):
+    """Config 3: bs prompts with lengths U[128,4096] (seed 0), optionally on top of a shared cached
+    prefix, admitted in arrival order into extend batches of <= max_prefill_tokens new tokens (the
+    reference's PrefillAdder budget, server/args.py:33-34); TTFT of a request = time from the start
+    of the run to the end of the batch that contains it (all requests arrive at t = 0)."""
+    from scratchpad_amd.model_runner import ModelConfig, ModelRunner, ServerArgs, TpModelWorker
+    from scratchpad_amd.schedule_batch import Req, ScheduleBatch
+    bs = 64 if args.bs == 256 else args.bs
+    gen = torch.Generator().manual_seed(rank)
+    lens = torch.randint(128, 4097, (bs,), generator=gen).tolist()
+    total = sum(lens) + args.prefix
+    cfg = ModelConfig.llama3_8b(4096 + args.prefix + 8)
+    if args.layers:
+        cfg.num_hidden_layers = args.layers
+    reps = args.warmup + args.steps
+    sargs = ServerArgs(max_total_tokens=total + 64, max_running_requests=bs, disable_cuda_graph=True)
+    mr = ModelRunner(cfg, sargs, dtype=torch.bfloat16, gpu_id=local_rank, seed=rank)
+    worker = TpModelWorker(mr)
+    dev = mr.device
+    vocab = cfg.vocab_size
+    prompts = [torch.randint(0, vocab, (n,), generator=gen).tolist() for n in lens]
+    prefix_ids = torch.randint(0, vocab, (args.prefix,), generator=gen).tolist()
+
+    def one_pass():
+        mr.req_to_token_pool.clear()
+        mr.token_to_kv_pool_allocator.clear()
+        prefix_slots = None
+        if args.prefix:     # a radix-cache hit: the prefix KV is already in the pool (computed once)
+            pre = ScheduleBatch([Req("prefix", prefix_ids)], mr.req_to_token_pool,
+                                mr.token_to_kv_pool_allocator, dev)
+            pre.prepare_for_extend()
+            worker.forward_batch_generation(pre.get_model_worker_batch())
+            prefix_slots = pre.out_cache_loc.clone()
+            mr.req_to_token_pool.free(pre.reqs[0].req_pool_idx)
+        batches, cur, cur_tok = [], [], 0
+        for i, n in enumerate(lens):
+            if cur and cur_tok + n > args.max_prefill_tokens:
+                batches.append(cur)
+                cur, cur_tok = [], 0
+            cur.append(i)
+            cur_tok += n
+        batches.append(cur)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ttft = [0.0] * bs
+        for ids in batches:
+            reqs = [Req(str(i), prefix_ids + prompts[i], prefix_indices=prefix_slots) for i in ids]
+            sb = ScheduleBatch(reqs, mr.req_to_token_pool, mr.token_to_kv_pool_allocator, dev)
+            sb.prepare_for_extend()
+            _, nxt = worker.forward_batch_generation(sb.get_model_worker_batch())
+            nxt.cpu()                       # first token delivered to the host
+            t = time.perf_counter() - t0
+            for i in ids:
+                ttft[i] = t
+        return time.perf_counter() - t0, ttft, len(batches)
+
+    for _ in range(max(args.warmup, 1)):
+        one_pass()
+    times, ttfts = [], []
+    for _ in range(args.steps):
+        el, tt, nb = one_pass()
+        times.append(el)
+        ttfts.append(tt)
+    el = sorted(times)[len(times) // 2]
+    tt = sorted(ttfts[times.index(el)])
+    if rank != 0:
+        return
+    out = {"metric": "ttft_p50_ms", "value": round(tt[len(tt) // 2] * 1e3, 2), "unit": "ms", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el * 1e3, 2),
+           "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+           "data": "synthetic (random-init weights, random token ids)",
+           "config": {"workload": f"llama3-8b TP=1 bf16 ragged prefill bs={bs}, prompt lengths U[128,4096] seed 0, "
+                                  f"cached prefix {args.prefix}, extend batches <= {args.max_prefill_tokens} tokens",
+                      "prompt_tokens": sum(lens), "extend_batches": nb, "layers": cfg.num_hidden_layers},
+           "ttft_p99_ms": round(tt[int(len(tt) * 0.99)] * 1e3, 2),
+           "prefill_tokens_per_sec": round(sum(lens) / el, 1)}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -199,6 +283,11 @@ def main():
     from scratchpad_amd import _native
     from scratchpad_amd.model_runner import TpModelWorker
     _native.load()
+    if args.mode == "prefill":
+        if args.steps == 64:
+            args.steps, args.warmup = 3, 1
+        prefill_main(args, rank, local_rank, world)
+        return
     mr, ctx, gen = build_engine(args, local_rank, seed=rank)
     if not args.no_graph:
         mr.init_cuda_graphs()

@@ -1,0 +1,122 @@
+"""The scheduler-side producers driving the hot path on the GPU: prepare_for_extend (with a cached
+prefix), prepare_for_decode over several steps, and a MIXED batch (chunked prefill + running
+decodes), checked step by step against the CPU oracle fed with the SAME slots/tables.
+
+This is the continuous-batching trace in miniature: slot allocation, req_to_token writes and the
+KV pool contents must agree bit-exactly in their indices; logits within the fp32 bar."""
+import pytest
+import torch
+
+from oracle import llama as ollama
+from oracle import ops
+from tests import smoke_impl
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_step(shape, w, kv, mode, ids, req, seq, loc, pre=None, ext=None):
+    if mode == "decode":
+        return ollama.forward(shape, w, kv, mode="decode", input_ids=ids, positions=ops.clamp_position(seq),
+                              req_pool_indices=req, seq_lens=seq, out_cache_loc=loc)
+    positions, start = ops.compute_position(pre, ext)
+    return ollama.forward(shape, w, kv, mode="extend", input_ids=ids, positions=positions, req_pool_indices=req,
+                          seq_lens=seq, out_cache_loc=loc, extend_seq_lens=ext, extend_start_loc=start)
+
+
+def close(got, want, what):
+    dev = float((got.float().cpu() - want).abs().max() / want.abs().max())
+    assert dev <= 1e-4, f"{what}: relative logit deviation {dev:.2e}"
+
+
+def test_extend_decode_mixed_trace_matches_oracle():
+    from scratchpad_amd.forward_info import ForwardMode
+    from scratchpad_amd.model_runner import TpModelWorker
+    from scratchpad_amd.schedule_batch import Req, ScheduleBatch
+    g, pfx, shape, w = smoke_impl.load_case("a")
+    mr = smoke_impl.make_runner(shape, w, torch.float32)
+    worker = TpModelWorker(mr)
+    dev = mr.device
+    gen = torch.Generator().manual_seed(7)
+    okv = ollama.OracleKV(shape, 96, 4, 64)
+
+    def mirror_tables():
+        okv.req_to_token.copy_(mr.req_to_token_pool.req_to_token.cpu())
+
+    # ---- 1. prefill of two requests; the second reuses the first 4 tokens' KV of a shared prompt
+    shared = torch.randint(0, shape.vocab, (4,), generator=gen).tolist()
+    warm = ScheduleBatch([Req("warm", shared)], mr.req_to_token_pool, mr.token_to_kv_pool_allocator, dev)
+    warm.prepare_for_extend()
+    out, _ = worker.forward_batch_generation(warm.get_model_worker_batch())
+    mirror_tables()
+    ref = oracle_step(shape, w, okv, "extend", warm.input_ids.cpu(), warm.req_pool_indices.cpu(),
+                      warm.seq_lens.cpu(), warm.out_cache_loc.cpu(), torch.tensor([0], dtype=torch.int32),
+                      torch.tensor([4], dtype=torch.int32))
+    close(out.next_token_logits, ref, "warm prefill")
+    prefix_slots = warm.out_cache_loc.clone()          # what RadixCache.match_prefix would return
+    mr.req_to_token_pool.free(warm.reqs[0].req_pool_idx)
+
+    r0 = Req("r0", torch.randint(0, shape.vocab, (7,), generator=gen).tolist())
+    r1 = Req("r1", shared + torch.randint(0, shape.vocab, (5,), generator=gen).tolist(), prefix_indices=prefix_slots)
+    sb = ScheduleBatch([r0, r1], mr.req_to_token_pool, mr.token_to_kv_pool_allocator, dev)
+    sb.prepare_for_extend()
+    assert sb.prefix_lens == [0, 4] and sb.extend_lens == [7, 5] and sb.extend_num_tokens == 12
+    table = mr.req_to_token_pool.req_to_token.cpu()
+    assert torch.equal(table[r1.req_pool_idx, :4].long(), prefix_slots.cpu()), "cached prefix slots copied"
+    assert torch.equal(table[r0.req_pool_idx, :7].long(), sb.out_cache_loc[:7].cpu())
+    assert torch.equal(table[r1.req_pool_idx, 4:9].long(), sb.out_cache_loc[7:].cpu())
+    out, nxt = worker.forward_batch_generation(sb.get_model_worker_batch())
+    mirror_tables()
+    ref = oracle_step(shape, w, okv, "extend", sb.input_ids.cpu(), sb.req_pool_indices.cpu(), sb.seq_lens.cpu(),
+                      sb.out_cache_loc.cpu(), torch.tensor(sb.prefix_lens, dtype=torch.int32),
+                      torch.tensor(sb.extend_lens, dtype=torch.int32))
+    close(out.next_token_logits, ref, "prefill with cached prefix")
+    assert torch.equal(nxt.cpu(), ref.argmax(-1))
+
+    # ---- 2. three decode steps (seq_lens += 1, alloc(bs), table write) feeding sampled tokens back
+    sb.output_ids = nxt
+    for step in range(3):
+        before = sb.seq_lens.clone()
+        sb.prepare_for_decode()
+        assert sb.forward_mode == ForwardMode.DECODE and torch.equal(sb.seq_lens, before + 1)
+        out, nxt = worker.forward_batch_generation(sb.get_model_worker_batch())
+        mirror_tables()
+        ref = oracle_step(shape, w, okv, "decode", sb.input_ids.cpu(), sb.req_pool_indices.cpu(),
+                          sb.seq_lens.cpu(), sb.out_cache_loc.cpu())
+        close(out.next_token_logits, ref, f"decode step {step}")
+        for r, tok in zip(sb.reqs, sb.input_ids.tolist()):
+            r.output_ids.append(tok)
+        sb.output_ids = nxt
+
+    # ---- 3. MIXED: a new prompt is prefilled in the same batch as the two running decodes
+    sb.prepare_for_decode()
+    newr = Req("r2", torch.randint(0, shape.vocab, (6,), generator=gen).tolist())
+    mix = ScheduleBatch([newr], mr.req_to_token_pool, mr.token_to_kv_pool_allocator, dev)
+    mix.prepare_for_extend()
+    for r, tok in zip(sb.reqs, sb.input_ids.tolist()):
+        r.output_ids.append(tok)
+    mix.mix_with_running(sb)
+    assert mix.forward_mode == ForwardMode.MIXED and mix.extend_lens == [6, 1, 1]
+    assert mix.prefix_lens[1:] == [int(x) - 1 for x in sb.seq_lens.tolist()]
+    out, _ = worker.forward_batch_generation(mix.get_model_worker_batch())
+    mirror_tables()
+    ref = oracle_step(shape, w, okv, "extend", mix.input_ids.cpu(), mix.req_pool_indices.cpu(), mix.seq_lens.cpu(),
+                      mix.out_cache_loc.cpu(), torch.tensor(mix.prefix_lens, dtype=torch.int32),
+                      torch.tensor(mix.extend_lens, dtype=torch.int32))
+    close(out.next_token_logits, ref, "mixed batch")
+    # the two pools hold the same K rows in the same slots
+    for layer in range(shape.layers):
+        assert torch.allclose(mr.token_to_kv_pool.get_key_buffer(layer).cpu(), okv.k[layer], atol=2e-5)
+
+
+def test_out_of_memory_is_reported_like_the_reference():
+    from scratchpad_amd.schedule_batch import Req, ScheduleBatch
+    g, pfx, shape, w = smoke_impl.load_case("a")
+    mr = smoke_impl.make_runner(shape, w, torch.float32)
+    big = ScheduleBatch([Req("x", list(range(50))), Req("y", list(range(50)))], mr.req_to_token_pool,
+                        mr.token_to_kv_pool_allocator, mr.device)
+    with pytest.raises(RuntimeError, match="Out of memory"):
+        big.prepare_for_extend()          # 100 tokens > the 96-slot pool
+    many = ScheduleBatch([Req(str(i), [1]) for i in range(9)], mr.req_to_token_pool,
+                         mr.token_to_kv_pool_allocator, mr.device)
+    with pytest.raises(RuntimeError, match="max-running-requests"):
+        many.prepare_for_extend()
