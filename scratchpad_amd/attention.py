@@ -238,6 +238,13 @@ class HipAttnBackend(AttentionBackend):
             return forward_batch.seq_lens, forward_batch.encoder_lens
         return forward_batch.seq_lens, None
 
+    @staticmethod
+    def _alloc_out(q: torch.Tensor, layer: RadixAttention) -> torch.Tensor:
+        # The kernels leave a row with no visible key untouched (sp_decode_attention: seq_len 0).
+        # Only cross-attention has such rows (text-only requests, encoder_len 0); they must read as
+        # zeros because the model multiplies them by the row mask (mllama.py:621-622).
+        return torch.zeros_like(q) if layer.is_cross_attention else torch.empty_like(q)
+
     def _store(self, layer, forward_batch, k, v, save_kv_cache):
         if k is None or not save_kv_cache:
             return
@@ -253,7 +260,7 @@ class HipAttnBackend(AttentionBackend):
         if layer.qk_head_dim != layer.v_head_dim:
             raise NotImplementedError("v_head_dim != head_dim (MLA) is out of scope")
         q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
-        o = torch.empty_like(q)
+        o = self._alloc_out(q, layer)
         # KV store BEFORE the kernel: the kernel reads every key, new ones included, from the pool
         # (triton_backend.py:131-134)
         self._store(layer, forward_batch, k, v, save_kv_cache)
@@ -275,7 +282,7 @@ class HipAttnBackend(AttentionBackend):
         if layer.qk_head_dim != layer.v_head_dim:
             raise NotImplementedError("v_head_dim != head_dim (MLA) is out of scope")
         q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
-        o = torch.empty_like(q)
+        o = self._alloc_out(q, layer)
         self._store(layer, forward_batch, k, v, save_kv_cache)
         chunk, max_len, ws, plans = self.forward_metadata
         seq_lens, kv_start = self._kv_window(layer, forward_batch)

@@ -101,6 +101,9 @@ class ModelWorkerBatch:
     spec_info: Optional[Any] = None
     capture_hidden_mode: CaptureHiddenMode = CaptureHiddenMode.NULL
     launch_done: Optional[threading.Event] = None
+    # stand-in for the (un-hosted) vision tower: projected + flattened vision states of the requests
+    # whose encoder is not cached, [sum(encoder_lens_need), hidden] (mllama.py:966-979)
+    encoder_states: Optional[torch.Tensor] = None
 
 
 @dataclass
@@ -145,6 +148,7 @@ class ForwardBatch:
     capture_hidden_mode: CaptureHiddenMode = None
     padded_static_len: int = -1
     mrope_positions: torch.Tensor = None
+    encoder_states: Optional[torch.Tensor] = None
 
     @classmethod
     def init_new(cls, batch: ModelWorkerBatch, model_runner) -> "ForwardBatch":
@@ -163,7 +167,8 @@ class ForwardBatch:
             sampling_info=batch.sampling_info, req_to_token_pool=model_runner.req_to_token_pool,
             token_to_kv_pool=model_runner.token_to_kv_pool, attn_backend=model_runner.attn_backend,
             spec_algorithm=batch.spec_algorithm, spec_info=batch.spec_info,
-            capture_hidden_mode=batch.capture_hidden_mode, input_embeds=batch.input_embeds)
+            capture_hidden_mode=batch.capture_hidden_mode, input_embeds=batch.input_embeds,
+            encoder_states=batch.encoder_states)
         if ret.forward_mode.is_idle():
             ret.positions = torch.empty((0,), device=device)
             return ret

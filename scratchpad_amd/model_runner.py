@@ -36,7 +36,13 @@ class ModelConfig:
     max_position_embeddings: int = 8192
     tie_word_embeddings: bool = False
     hidden_act: str = "silu"
-    is_encoder_decoder: bool = False
+    # Mllama text model: indices of the cross-attention decoder layers (None = plain Llama)
+    cross_attention_layers: Optional[List[int]] = None
+    pad_token_id: Optional[int] = None
+
+    @property
+    def is_encoder_decoder(self) -> bool:
+        return bool(self.cross_attention_layers)
 
     def __post_init__(self):
         if self.head_dim is None:
@@ -116,7 +122,11 @@ class ModelRunner:
     # ------------------------------------------------------------------ model
     def load_model(self, seed: int, init_weights: bool):
         with torch.device(self.device):
-            self.model = LlamaForCausalLM(self.model_config, dtype=self.dtype).eval()
+            if self.model_config.is_encoder_decoder:
+                from .mllama import MllamaForConditionalGeneration
+                self.model = MllamaForConditionalGeneration(self.model_config, dtype=self.dtype).eval()
+            else:
+                self.model = LlamaForCausalLM(self.model_config, dtype=self.dtype).eval()
         for p in self.model.parameters():
             if p.dtype != self.dtype:
                 p.data = p.data.to(self.dtype)
@@ -125,6 +135,8 @@ class ModelRunner:
             for name, p in self.model.named_parameters():
                 if "norm" in name:
                     p.data.fill_(1.0)
+                elif p.numel() == 1:          # Mllama tanh gates
+                    p.data.fill_(0.5)
                 else:
                     p.data.normal_(0.0, 0.02, generator=g)
 
@@ -167,13 +179,19 @@ class ModelRunner:
         self.graph_runner = HipGraphRunner(self)
 
     # ------------------------------------------------------------------ forward
+    def _run_model(self, forward_batch: ForwardBatch) -> LogitsProcessorOutput:
+        if self.model_config.is_encoder_decoder:
+            return self.model.forward(forward_batch.input_ids, forward_batch.positions, forward_batch,
+                                      cross_attention_states=forward_batch.encoder_states)
+        return self.model.forward(forward_batch.input_ids, forward_batch.positions, forward_batch)
+
     def forward_decode(self, forward_batch: ForwardBatch) -> LogitsProcessorOutput:
         self.attn_backend.init_forward_metadata(forward_batch)
-        return self.model.forward(forward_batch.input_ids, forward_batch.positions, forward_batch)
+        return self._run_model(forward_batch)
 
     def forward_extend(self, forward_batch: ForwardBatch) -> LogitsProcessorOutput:
         self.attn_backend.init_forward_metadata(forward_batch)
-        return self.model.forward(forward_batch.input_ids, forward_batch.positions, forward_batch)
+        return self._run_model(forward_batch)
 
     def forward(self, forward_batch: ForwardBatch) -> LogitsProcessorOutput:
         if (forward_batch.forward_mode.is_cuda_graph() and self.graph_runner is not None
@@ -216,7 +234,8 @@ class HipGraphRunner:
         self.capture()
 
     def can_run(self, forward_batch: ForwardBatch) -> bool:
-        return forward_batch.batch_size <= self.max_bs
+        # encoder-decoder batches carry encoder_lens, which this runner does not capture yet
+        return forward_batch.batch_size <= self.max_bs and forward_batch.encoder_lens is None
 
     def capture(self):
         for bs in reversed(self.capture_bs):

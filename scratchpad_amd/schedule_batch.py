@@ -27,6 +27,9 @@ class Req:
     output_ids: List[int] = field(default_factory=list)
     prefix_indices: Optional[torch.Tensor] = None   # cached KV slots (radix-cache hit), int
     req_pool_idx: Optional[int] = None
+    # encoder-decoder models: the first num_image_tokens ids of origin_input_ids are the image pad
+    # ids (mllama.py pad_input_ids 803-816; MultimodalInputs.num_image_tokens)
+    num_image_tokens: Optional[int] = None
 
     @property
     def fill_ids(self) -> List[int]:
@@ -43,7 +46,11 @@ class Req:
 
 class ScheduleBatch:
     def __init__(self, reqs: List[Req], req_to_token_pool: ReqToTokenPool,
-                 token_to_kv_pool_allocator: TokenToKVPoolAllocator, device: str):
+                 token_to_kv_pool_allocator: TokenToKVPoolAllocator, device: str,
+                 is_encoder_decoder: bool = False):
+        self.is_encoder_decoder = is_encoder_decoder
+        self.encoder_cached = self.encoder_lens = self.encoder_lens_cpu = None
+        self.encoder_out_cache_loc = None
         self.reqs = reqs
         self.req_to_token_pool = req_to_token_pool
         self.token_to_kv_pool_allocator = token_to_kv_pool_allocator
@@ -107,6 +114,52 @@ class ScheduleBatch:
         _native.write_req_to_token(self.req_to_token_pool.req_to_token, req_pool_indices_tensor,
                                    prefix_lens_tensor, seq_lens_tensor, extend_lens_tensor,
                                    out_cache_loc)
+        if self.is_encoder_decoder:
+            self.prepare_encoder_info_extend(input_ids, seq_lens)
+
+    def prepare_encoder_info_extend(self, input_ids: List[List[int]], seq_lens: List[int]):
+        """schedule_batch.py:830-899: strip the encoder (image) tokens out of the decoder-side
+        fields.  The request's req_to_token row keeps [encoder slots | text slots]; seq_lens,
+        extend_lens/prefix_lens, input_ids and out_cache_loc describe the TEXT tokens only, and
+        encoder_out_cache_loc receives the encoder slots (the encoder is all-or-nothing)."""
+        self.encoder_lens_cpu, self.encoder_cached = [], []
+        for req in self.reqs:
+            if req.num_image_tokens is None:
+                self.encoder_lens_cpu.append(0)
+                self.encoder_cached.append(True)
+            else:
+                self.encoder_lens_cpu.append(req.num_image_tokens)
+                self.encoder_cached.append(self.forward_mode.is_decode()
+                                           or req.prefix_len >= req.num_image_tokens)
+        self.encoder_lens = torch.tensor(self.encoder_lens_cpu, dtype=torch.int64).to(
+            self.device, non_blocking=True)
+        pt = 0
+        decoder_out_cache_loc, encoder_out_cache_loc = [], []
+        for i, req in enumerate(self.reqs):
+            encoder_len = self.encoder_lens_cpu[i]
+            seq_lens[i] -= encoder_len
+            if req.prefix_len < encoder_len:
+                assert req.prefix_len == 0, "the encoder part is cached as a whole"
+                input_ids[i] = input_ids[i][encoder_len:]
+                encoder_out_cache_loc.append(self.out_cache_loc[pt:pt + encoder_len])
+                decoder_out_cache_loc.append(self.out_cache_loc[pt + encoder_len:pt + req.extend_input_len])
+                self.extend_lens[i] -= encoder_len
+                self.extend_num_tokens -= encoder_len
+            else:
+                decoder_out_cache_loc.append(self.out_cache_loc[pt:pt + req.extend_input_len])
+                self.prefix_lens[i] -= encoder_len
+            pt += req.extend_input_len
+        self.input_ids = torch.tensor(sum(input_ids, []), dtype=torch.int64).to(self.device, non_blocking=True)
+        self.seq_lens = torch.tensor(seq_lens, dtype=torch.int64).to(self.device, non_blocking=True)
+        self.seq_lens_sum = sum(seq_lens)
+        empty = torch.zeros(0, dtype=torch.int64).to(self.device)
+        self.out_cache_loc = torch.cat(decoder_out_cache_loc) if decoder_out_cache_loc else empty
+        self.encoder_out_cache_loc = torch.cat(encoder_out_cache_loc) if encoder_out_cache_loc else empty
+        assert len(self.out_cache_loc) == self.extend_num_tokens
+
+    def prepare_encoder_info_decode(self):
+        """schedule_batch.py:1213-1215"""
+        self.encoder_cached = [True] * len(self.reqs)
 
     def mix_with_running(self, running_batch: "ScheduleBatch"):
         """Chunked prefill + running decodes in one extend batch: the decode rows become
@@ -130,7 +183,11 @@ class ScheduleBatch:
         bs = len(self.reqs)
         self.input_ids = self.output_ids
         self.output_ids = None
-        locs = self.seq_lens.clone()
+        if self.is_encoder_decoder:
+            locs = self.encoder_lens + self.seq_lens      # text position behind the encoder slots
+            self.prepare_encoder_info_decode()
+        else:
+            locs = self.seq_lens.clone()
         # overlap-safe (no in-place op): schedule_batch.py:1287-1292
         self.seq_lens = self.seq_lens + 1
         self.seq_lens_sum += bs
@@ -149,4 +206,6 @@ class ScheduleBatch:
             req_pool_indices=self.req_pool_indices, seq_lens=self.seq_lens,
             out_cache_loc=self.out_cache_loc, seq_lens_sum=self.seq_lens_sum,
             extend_num_tokens=self.extend_num_tokens, extend_seq_lens=extend_seq_lens,
-            extend_prefix_lens=extend_prefix_lens, capture_hidden_mode=CaptureHiddenMode.NULL)
+            extend_prefix_lens=extend_prefix_lens, capture_hidden_mode=CaptureHiddenMode.NULL,
+            encoder_cached=self.encoder_cached, encoder_lens=self.encoder_lens,
+            encoder_lens_cpu=self.encoder_lens_cpu, encoder_out_cache_loc=self.encoder_out_cache_loc)

@@ -475,10 +475,183 @@ def gen_tiny_llama():
     _save("tiny_llama", **out)
 
 
+def gen_tiny_mllama():
+    """Reference MllamaForCausalLM (text model with one cross-attention layer) on CPU: a mixed batch
+    (two requests with image tokens, one text-only), prefill then one decode step.
+
+    The layer glue is the reference's own code (MllamaTextCrossAttention incl. per-head q/k RMSNorm,
+    tanh gates, full_text_row_masked_out_mask, `hidden + residual` after each self-attention layer,
+    the shared KV pool with encoder slots first).  The attention CALLS go through a probe backend
+    written here from the flashinfer backend's documented semantics (flashinfer itself is absent):
+    cross-attention = non-causal over req_to_token[req, 0:encoder_len], K/V stored at
+    encoder_out_cache_loc; self-attention = causal over req_to_token[req, encoder_len:encoder_len+seq]
+    (nn/attention/flashinfer_backend.py:400-417, 593-621, 792-828)."""
+    import transformers.models.mllama.configuration_mllama as cm
+    import scratchpad.nn.models.llama.mllama as M
+    import torch.distributed as dist
+    from scratchpad.distributed import init_distributed_environment, initialize_model_parallel
+    from scratchpad.memory.pool import MHATokenToKVPool, ReqToTokenPool
+    from scratchpad.model_executor.cuda_graph_runner import _to_torch
+    from scratchpad.model_executor.forward_info import CaptureHiddenMode, ForwardBatch, ForwardMode
+    from scratchpad.nn.attention.backend import AttentionBackend
+
+    if not dist.is_initialized():
+        init_distributed_environment(world_size=1, rank=0, distributed_init_method="tcp://127.0.0.1:29518",
+                                     local_rank=0, backend="gloo")
+        initialize_model_parallel(1)
+    torch.manual_seed(110)
+    hidden, inter, nl, Hq, Hkv, vocab = 256, 256, 3, 4, 2, 200
+    cfg = cm.MllamaTextConfig(vocab_size=vocab, hidden_size=hidden, num_hidden_layers=nl,
+                              num_attention_heads=Hq, num_key_value_heads=Hkv, intermediate_size=inter,
+                              cross_attention_layers=[1], rms_norm_eps=1e-5, max_position_embeddings=128,
+                              pad_token_id=0, bos_token_id=1, eos_token_id=2)
+    cfg.rope_theta = 500000.0
+    cfg.rope_scaling = None
+    D = hidden // Hq
+    from scratchpad.nn.layers.logits_processor import LogitsProcessor
+    model = M.MllamaForCausalLM(cfg, quant_config=None).eval()
+    logits_processor = LogitsProcessor(cfg)          # MllamaForConditionalGeneration.__init__ :801
+    for pname, p in model.named_parameters():
+        if "gate" in pname and p.numel() == 1:
+            p.data = torch.tensor([0.5 if "attn_gate" in pname else -0.75])
+        elif "norm" in pname:
+            p.data = _grid(1.0 + 0.1 * torch.randn_like(p))
+        else:
+            p.data = _grid(torch.randn_like(p) * 0.05, step=1024.0, lim=255.0)
+    _to_torch(model, reverse=False, num_tokens=2)
+    kv = MHATokenToKVPool(96, 1, torch.float32, Hkv, D, nl, "cpu", False)
+    r2t = ReqToTokenPool(4, 64, "cpu", False)
+
+    def dense(q, kb, vb, idx, causal_offset, scale):
+        """q [n,Hq,D] over pool rows idx; causal_offset = index of row 0's last visible key, or None"""
+        k = kb[idx].float()
+        v = vb[idx].float()
+        g = q.shape[1] // k.shape[1]
+        k = k.repeat_interleave(g, dim=1)
+        v = v.repeat_interleave(g, dim=1)
+        s = torch.einsum("nhd,lhd->hnl", q.float(), k) * scale
+        if causal_offset is not None:
+            n, L = q.shape[0], k.shape[0]
+            col = torch.arange(L).view(1, L)
+            row = torch.arange(n).view(n, 1) + causal_offset
+            s = s.masked_fill(col > row, float("-inf"))
+        return torch.einsum("hnl,lhd->nhd", torch.softmax(s, -1), v)
+
+    class Probe(AttentionBackend):
+        def init_forward_metadata(self, fb):
+            pass
+
+        def _run(self, q, k, v, layer, fb, starts, lens):
+            q3 = q.reshape(-1, layer.tp_q_head_num, layer.qk_head_dim)
+            o = torch.zeros_like(q3)
+            cross = layer.is_cross_attention
+            if k is not None:
+                loc = fb.encoder_out_cache_loc if cross else fb.out_cache_loc
+                fb.token_to_kv_pool.set_kv_buffer(layer, loc, k, v)
+            kb, vb = fb.token_to_kv_pool.get_kv_buffer(layer.layer_id)
+            for b in range(fb.batch_size):
+                enc = int(fb.encoder_lens[b])
+                row = fb.req_to_token_pool.req_to_token[int(fb.req_pool_indices[b])]
+                s0, n = starts[b], lens[b]
+                if n == 0:
+                    continue
+                if cross:
+                    if enc == 0:
+                        continue
+                    o[s0:s0 + n] = dense(q3[s0:s0 + n], kb, vb, row[:enc].long(), None, layer.scaling)
+                else:
+                    L = int(fb.seq_lens[b])
+                    o[s0:s0 + n] = dense(q3[s0:s0 + n], kb, vb, row[enc:enc + L].long(), L - n, layer.scaling)
+            return o.reshape(-1, layer.tp_q_head_num * layer.v_head_dim)
+
+        def forward_extend(self, q, k, v, layer, fb, save_kv_cache=True):
+            return self._run(q, k, v, layer, fb, fb.extend_start_loc.tolist(), fb.extend_seq_lens.tolist())
+
+        def forward_decode(self, q, k, v, layer, fb, save_kv_cache=True):
+            return self._run(q, k, v, layer, fb, list(range(fb.batch_size)), [1] * fb.batch_size)
+
+    backend = Probe()
+    g = torch.Generator().manual_seed(111)
+    enc = [10, 0, 7]
+    text = [6, 5, 4]
+    bs = 3
+    req_idx = torch.tensor([1, 3, 0], dtype=torch.int64)
+    slots = (torch.randperm(90, generator=g) + 1).to(torch.int64)
+    # scheduler layout (prepare_for_extend + prepare_encoder_info_extend): per request the slots of
+    # [encoder tokens | text tokens] are contiguous in out_cache_loc order
+    pt, enc_loc, dec_loc = 0, [], []
+    for b in range(bs):
+        n = enc[b] + text[b]
+        r2t.req_to_token[req_idx[b], :n] = slots[pt:pt + n].to(torch.int32)
+        enc_loc.append(slots[pt:pt + enc[b]])
+        dec_loc.append(slots[pt + enc[b]:pt + n])
+        pt += n
+    out_loc, enc_out_loc = torch.cat(dec_loc), torch.cat(enc_loc)
+    ids = torch.randint(3, vocab, (sum(text),), generator=g)
+    ext_t = torch.tensor(text, dtype=torch.int32)
+    start = torch.zeros(bs, dtype=torch.int32)
+    start[1:] = torch.cumsum(ext_t[:-1], 0)
+    positions = torch.cat([torch.arange(n) for n in text]).to(torch.int64)
+    cross_states = _randn(sum(enc), hidden, generator=g, scale=0.5)
+    enc_t = torch.tensor(enc, dtype=torch.int64)
+    seq = torch.tensor(text, dtype=torch.int64)
+    fb = ForwardBatch(
+        forward_mode=ForwardMode.EXTEND, batch_size=bs, input_ids=ids, req_pool_indices=req_idx, seq_lens=seq,
+        out_cache_loc=out_loc, seq_lens_sum=int(seq.sum()), positions=positions,
+        extend_num_tokens=sum(text), extend_seq_lens=ext_t, extend_prefix_lens=torch.zeros(bs, dtype=torch.int32),
+        extend_start_loc=start, extend_prefix_lens_cpu=[0] * bs, extend_seq_lens_cpu=text,
+        encoder_cached=[False, True, False], encoder_lens=enc_t, encoder_lens_cpu=enc,
+        encoder_out_cache_loc=enc_out_loc, req_to_token_pool=r2t, token_to_kv_pool=kv, attn_backend=backend,
+        capture_hidden_mode=CaptureHiddenMode.NULL)
+
+    class Host:   # get_full_text_row_masked_out_mask is a method of the conditional-generation class
+        pass
+    mask = M.MllamaForConditionalGeneration.get_full_text_row_masked_out_mask(Host(), fb)
+    hidden_states = model.model(input_ids=ids, positions=positions, cross_attention_states=cross_states,
+                                cross_attention_mask=None, full_text_row_masked_out_mask=mask,
+                                forward_batch=fb, skip_cross_attention=False)
+    prefill_logits = logits_processor(ids, hidden_states, model.lm_head, fb).next_token_logits.clone()
+    next_ids = prefill_logits.argmax(-1)
+
+    # decode step: locs = encoder_lens + seq_lens (schedule_batch.py:1281-1283)
+    dloc = slots[pt:pt + bs]
+    for b in range(bs):
+        r2t.req_to_token[req_idx[b], enc[b] + text[b]] = int(dloc[b])
+    seq2 = seq + 1
+    fb2 = ForwardBatch(
+        forward_mode=ForwardMode.DECODE, batch_size=bs, input_ids=next_ids, req_pool_indices=req_idx,
+        seq_lens=seq2, out_cache_loc=dloc, seq_lens_sum=int(seq2.sum()),
+        positions=torch.clamp(seq2 - 1, min=0).to(torch.int64), encoder_cached=[True] * bs,
+        encoder_lens=enc_t, encoder_lens_cpu=enc, encoder_out_cache_loc=torch.zeros(0, dtype=torch.int64),
+        req_to_token_pool=r2t, token_to_kv_pool=kv, attn_backend=backend,
+        capture_hidden_mode=CaptureHiddenMode.NULL)
+    mask2 = M.MllamaForConditionalGeneration.get_full_text_row_masked_out_mask(Host(), fb2)
+    hs2 = model.model(input_ids=next_ids, positions=fb2.positions, cross_attention_states=None,
+                      cross_attention_mask=None, full_text_row_masked_out_mask=mask2, forward_batch=fb2,
+                      skip_cross_attention=False)
+    decode_logits = logits_processor(next_ids, hs2, model.lm_head, fb2).next_token_logits.clone()
+
+    # per-head q/k RMSNorm on its own (MllamaTextRMSNorm): [T, H, D] -> normalised over D
+    norm = model.model.layers[1].cross_attn.q_norm
+    xn = _randn(7, Hq, D, generator=g)
+    out = {"w::" + k: v for k, v in model.state_dict().items()}
+    out.update({
+        "cfg": np.array([hidden, inter, nl, Hq, Hkv, vocab], np.int64), "cross_layers": np.array([1], np.int64),
+        "input_ids": ids, "text_lens": ext_t, "encoder_lens": enc_t, "req_pool_indices": req_idx,
+        "out_cache_loc": out_loc, "encoder_out_cache_loc": enc_out_loc, "positions": positions,
+        "cross_attention_states": cross_states, "row_mask_extend": mask.to(torch.int64),
+        "row_mask_decode": mask2.to(torch.int64), "req_to_token_extend_rows": r2t.req_to_token.clone(),
+        "prefill_logits": prefill_logits, "next_ids": next_ids, "decode_out_cache_loc": dloc,
+        "decode_logits": decode_logits, "k_buffer1_after": kv.get_key_buffer(1),
+        "qnorm_x": xn, "qnorm_w": norm.weight.data, "qnorm_y": norm(xn),
+    })
+    _save("tiny_mllama", **out)
+
+
 GENERATORS = {
     "rmsnorm": gen_rmsnorm, "silu_mul": gen_silu_mul, "rotary": gen_rotary, "kv_pool": gen_kv_pool,
     "positions": gen_positions, "decode_attention": gen_decode, "extend_attention": gen_extend,
-    "tiny_llama": gen_tiny_llama,
+    "tiny_llama": gen_tiny_llama, "tiny_mllama": gen_tiny_mllama,
 }
 
 if __name__ == "__main__":

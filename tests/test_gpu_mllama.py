@@ -1,0 +1,102 @@
+"""Mllama text model (config 5's cross-attention path) on the GPU against the logits of the
+reference's MllamaForCausalLM: cross-attention over the encoder slots, per-head q/k RMSNorm, tanh
+gates, the row mask, self-attention behind the encoder slots, encoder K/V reuse in decode - driven
+through the scheduler-side encoder bookkeeping (prepare_encoder_info_extend/decode)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def build(dtype):
+    from scratchpad_amd.model_runner import ModelConfig, ModelRunner, ServerArgs
+    g = golden.load("tiny_mllama")
+    hidden, inter, nl, Hq, Hkv, vocab = (int(x) for x in g["cfg"])
+    cfg = ModelConfig(hidden, inter, nl, Hq, Hkv, vocab, context_len=60, rms_norm_eps=1e-5, rope_theta=500000.0,
+                      max_position_embeddings=128, cross_attention_layers=[int(x) for x in g["cross_layers"]])
+    mr = ModelRunner(cfg, ServerArgs(max_total_tokens=96, max_running_requests=3, disable_cuda_graph=True),
+                     dtype=dtype, init_weights=False)
+    w = {k[3:]: torch.from_numpy(v).to(mr.device) for k, v in g.items() if k.startswith("w::")}
+    mr.model.load_full_state_dict(w)
+    return g, mr
+
+
+def test_per_head_rmsnorm_matches_reference():
+    from scratchpad_amd.mllama import MllamaTextRMSNorm
+    g = golden.load("tiny_mllama")
+    n = MllamaTextRMSNorm(64, 1e-5).cuda()
+    n.weight.data = torch.from_numpy(g["qnorm_w"]).cuda()
+    y = n(torch.from_numpy(g["qnorm_x"]).cuda())
+    assert y.shape == (7, 4, 64)
+    assert torch.allclose(y.cpu(), torch.from_numpy(g["qnorm_y"]), atol=2e-6, rtol=2e-6)
+    k_view = torch.randn(5, 512, device="cuda")[:, 256:384].view(5, 2, 64)      # a strided qkv slice
+    assert torch.allclose(n(k_view), n(k_view.contiguous()))
+
+
+def test_tiny_mllama_matches_reference_logits():
+    from scratchpad_amd.forward_info import ForwardMode
+    from scratchpad_amd.mllama import get_full_text_row_masked_out_mask
+    from scratchpad_amd.model_runner import TpModelWorker
+    from scratchpad_amd.schedule_batch import Req, ScheduleBatch
+    g, mr = build(torch.float32)
+    worker = TpModelWorker(mr)
+    dev = mr.device
+    enc, text = g["encoder_lens"].tolist(), g["text_lens"].tolist()
+    ids = g["input_ids"].tolist()
+    # the fixture's slot order and request rows: make the allocator and the row pool hand them out
+    slots = np.concatenate([np.concatenate([g["encoder_out_cache_loc"][sum(enc[:b]):sum(enc[:b + 1])],
+                                            g["out_cache_loc"][sum(text[:b]):sum(text[:b + 1])]]) for b in range(3)]
+                           + [g["decode_out_cache_loc"]])
+    rest = np.setdiff1d(np.arange(1, 97), slots)
+    mr.token_to_kv_pool_allocator.free_slots = torch.from_numpy(np.concatenate([slots, rest])).to(dev)
+    mr.req_to_token_pool.free_slots = g["req_pool_indices"].tolist() + [2]
+    reqs, off = [], 0
+    for b in range(3):
+        toks = ids[off:off + text[b]]
+        off += text[b]
+        if enc[b]:
+            reqs.append(Req(str(b), [0] * enc[b] + toks, num_image_tokens=enc[b]))   # image pad ids first
+        else:
+            reqs.append(Req(str(b), toks))
+    sb = ScheduleBatch(reqs, mr.req_to_token_pool, mr.token_to_kv_pool_allocator, dev, is_encoder_decoder=True)
+    sb.prepare_for_extend()
+    assert sb.extend_lens == text and sb.encoder_lens_cpu == enc and sb.encoder_cached == [False, True, False]
+    assert np.array_equal(sb.out_cache_loc.cpu().numpy(), g["out_cache_loc"])
+    assert np.array_equal(sb.encoder_out_cache_loc.cpu().numpy(), g["encoder_out_cache_loc"])
+    assert np.array_equal(sb.seq_lens.cpu().numpy(), g["text_lens"])
+    batch = sb.get_model_worker_batch()
+    batch.encoder_states = torch.from_numpy(g["cross_attention_states"]).to(dev)
+    out, nxt = worker.forward_batch_generation(batch)
+    want = torch.from_numpy(g["prefill_logits"])
+    dev1 = float((out.next_token_logits.cpu() - want).abs().max() / want.abs().max())
+    assert dev1 <= 1e-4, f"prefill logits deviate {dev1:.2e}"
+    assert np.array_equal(nxt.cpu().numpy(), g["next_ids"])
+    assert torch.allclose(mr.token_to_kv_pool.get_key_buffer(1).cpu(), torch.from_numpy(g["k_buffer1_after"]), atol=2e-5)
+    # decode: encoder K/V come from the pool (cross_attention_states is None from now on)
+    sb.output_ids = nxt
+    sb.prepare_for_decode()
+    assert sb.encoder_cached == [True] * 3
+    assert np.array_equal(sb.out_cache_loc.cpu().numpy(), g["decode_out_cache_loc"])
+    out2, _ = worker.forward_batch_generation(sb.get_model_worker_batch())
+    want2 = torch.from_numpy(g["decode_logits"])
+    dev2 = float((out2.next_token_logits.cpu() - want2).abs().max() / want2.abs().max())
+    assert dev2 <= 1e-4, f"decode logits deviate {dev2:.2e}"
+
+
+def test_row_mask_reproduces_the_reference_quirk():
+    from types import SimpleNamespace
+    from scratchpad_amd.forward_info import ForwardMode
+    from scratchpad_amd.mllama import flat_encoder_result, get_full_text_row_masked_out_mask
+    g = golden.load("tiny_mllama")
+    fb = SimpleNamespace(forward_mode=ForwardMode.EXTEND, extend_seq_lens_cpu=g["text_lens"].tolist(),
+                         seq_lens=torch.from_numpy(g["text_lens"]).long(), seq_lens_cpu=None,
+                         encoder_lens_cpu=g["encoder_lens"].tolist())
+    assert np.array_equal(get_full_text_row_masked_out_mask(fb).long().numpy(), g["row_mask_extend"])
+    fb2 = SimpleNamespace(forward_mode=ForwardMode.DECODE, encoder_lens=torch.from_numpy(g["encoder_lens"]))
+    assert np.array_equal(get_full_text_row_masked_out_mask(fb2).long().numpy(), g["row_mask_decode"])
+    states = torch.arange(2 * 5 * 3, dtype=torch.float32).view(2, 5, 3)
+    flat = flat_encoder_result(states, [4, 0, 2])
+    assert flat.shape == (6, 3) and torch.equal(flat[:4], states[0, :4]) and torch.equal(flat[4:], states[1, :2])

@@ -157,3 +157,32 @@ def test_tiny_llama_logits(name):
     close(logits2, g[pfx + "decode_logits"], atol=2e-5, rtol=1e-5)
     close(kv.k[0], g[pfx + "k_buffer0_after"], atol=1e-5)
     close(kv.v[1], g[pfx + "v_buffer1_after"], atol=1e-5)
+
+
+def test_tiny_mllama_text_model():
+    """cross-attention layers, per-head q/k RMSNorm, tanh gates, row mask, encoder slots first"""
+    from oracle import mllama as omllama
+    g = golden.load("tiny_mllama")
+    hidden, inter, nl, Hq, Hkv, vocab = (int(x) for x in g["cfg"])
+    shape = ollama.LlamaShape(hidden, inter, nl, Hq, Hkv, vocab, False, 500000.0, None, 128, 1e-5)
+    w = {k[3:]: T(v) for k, v in g.items() if k.startswith("w::")}
+    close(ops.rmsnorm(T(g["qnorm_x"]), T(g["qnorm_w"]), 1e-5), g["qnorm_y"], atol=1e-6)
+    kv = ollama.OracleKV(shape, 96, 4, 64)
+    text, enc, req = T(g["text_lens"]), T(g["encoder_lens"]), T(g["req_pool_indices"])
+    kv.req_to_token.copy_(T(g["req_to_token_extend_rows"]))     # decode slot entries are harmless extras
+    start = torch.zeros_like(text)
+    start[1:] = torch.cumsum(text[:-1], 0)
+    common = dict(req_pool_indices=req, encoder_lens=enc)
+    l1 = omllama.forward(shape, [1], w, kv, mode="extend", input_ids=T(g["input_ids"]), positions=T(g["positions"]),
+                         seq_lens=text.long(), out_cache_loc=T(g["out_cache_loc"]), row_mask=T(g["row_mask_extend"]),
+                         extend_seq_lens=text, extend_start_loc=start,
+                         cross_attention_states=T(g["cross_attention_states"]),
+                         encoder_out_cache_loc=T(g["encoder_out_cache_loc"]), **common)
+    close(l1, g["prefill_logits"], atol=2e-5, rtol=1e-5)
+    assert np.array_equal(l1.argmax(-1).numpy(), g["next_ids"])
+    seq2 = text.long() + 1
+    l2 = omllama.forward(shape, [1], w, kv, mode="decode", input_ids=T(g["next_ids"]),
+                         positions=ops.clamp_position(seq2), seq_lens=seq2, out_cache_loc=T(g["decode_out_cache_loc"]),
+                         row_mask=T(g["row_mask_decode"]), **common)
+    close(l2, g["decode_logits"], atol=2e-5, rtol=1e-5)
+    close(kv.k[1], g["k_buffer1_after"], atol=1e-5)
