@@ -276,9 +276,13 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     import torch.distributed as dist
+    # one process per GPU; a box with fewer GPUs than ranks (rehearsals) shares devices round-robin
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # replicas share nothing on the data path: the only cross-rank traffic is the timing barrier
+        # and the max over ranks of the elapsed time, so a host-side (gloo) group is all that is needed
+        dist.init_process_group("gloo")
 
     from scratchpad_amd import _native
     from scratchpad_amd.model_runner import TpModelWorker
@@ -311,7 +315,7 @@ def main():
     elapsed = time.perf_counter() - t0
     seq_sum_end = batch.seq_lens_sum
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

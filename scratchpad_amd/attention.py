@@ -104,6 +104,9 @@ class HipAttnBackend(AttentionBackend):
     # resident workgroups see several waves of work and the ragged tail stays short
     TARGET_ITEMS = 2048
     MIN_CHUNK, MAX_CHUNK = 64, 512
+    # LlamaAttention may hand rotary + KV store to the backend as one kernel (sp_rotary_embedding
+    # with pool arguments); set False to keep the reference's two-step order
+    fused_rope_kv_store = True
 
     def __init__(self, model_runner):
         super().__init__()
@@ -237,6 +240,22 @@ class HipAttnBackend(AttentionBackend):
         if self.is_encoder_decoder and forward_batch.encoder_lens is not None:
             return forward_batch.seq_lens, forward_batch.encoder_lens
         return forward_batch.seq_lens, None
+
+    def rotary_and_store(self, rope, positions, q, k, v, layer: RadixAttention,
+                         forward_batch: "ForwardBatch") -> None:
+        """rotary_emb(positions, q, k) + set_kv_buffer(layer, out_cache_loc, k, v) in one launch
+        (rotary_embedding.py:132-164 followed by pool.py:392-424).  q and k are rotated in place."""
+        pool = forward_batch.token_to_kv_pool
+        if rope.cos_sin_cache.device != q.device or rope.cos_sin_cache.dtype != q.dtype:
+            rope.cos_sin_cache = rope.cos_sin_cache.to(q.device, dtype=q.dtype)
+        if pool.dtype != q.dtype or layer.is_cross_attention:
+            rope(positions, q, k)
+            self._store(layer, forward_batch, k.view(-1, layer.tp_k_head_num, layer.qk_head_dim),
+                        v.view(-1, layer.tp_v_head_num, layer.v_head_dim), True)
+            return
+        kb, vb = pool.get_kv_buffer(layer.layer_id)
+        _native.rotary_embedding(positions, q, k, rope.head_size, rope.cos_sin_cache, rope.is_neox_style,
+                                 value=v, k_buffer=kb, v_buffer=vb, out_cache_loc=forward_batch.out_cache_loc)
 
     @staticmethod
     def _alloc_out(q: torch.Tensor, layer: RadixAttention) -> torch.Tensor:

@@ -107,13 +107,14 @@ def initialize_model_parallel(tensor_model_parallel_size: int = 1, backend: Opti
                               local_rank: int = 0) -> None:
     """parallel_state.py:933-997 (TP groups only): consecutive ranks form a TP group."""
     global _TP
-    world_size = dist.get_world_size() if dist.is_initialized() else 1
-    backend = backend or (dist.get_backend() if dist.is_initialized() else "gloo")
-    assert world_size % tensor_model_parallel_size == 0
-    if not dist.is_initialized():
-        assert tensor_model_parallel_size == 1
+    if tensor_model_parallel_size == 1:
+        # TP=1 engines (also N independent replicas under one launcher) need no process group
         _TP = _SingleRankGroup()
         return
+    assert dist.is_initialized(), "tensor parallelism needs init_distributed_environment() first"
+    world_size = dist.get_world_size()
+    backend = backend or dist.get_backend()
+    assert world_size % tensor_model_parallel_size == 0
     n = world_size // tensor_model_parallel_size
     group_ranks = [list(range(i * tensor_model_parallel_size, (i + 1) * tensor_model_parallel_size))
                    for i in range(n)]

@@ -234,8 +234,15 @@ class LlamaAttention(nn.Module):
                 forward_batch: ForwardBatch) -> torch.Tensor:
         qkv, _ = self.qkv_proj(hidden_states)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
-        q, k = self.rotary_emb(positions, q, k)       # in place on the qkv views
-        attn_output = self.attn(q, k, v, forward_batch)
+        backend = forward_batch.attn_backend
+        if getattr(backend, "fused_rope_kv_store", False):
+            # one launch: rotate q,k in place AND scatter rotated k + v into the KV pool
+            # (= rotary_emb followed by set_kv_buffer; the backend then skips its own store)
+            backend.rotary_and_store(self.rotary_emb, positions, q, k, v, self.attn, forward_batch)
+            attn_output = self.attn(q, k, v, forward_batch, save_kv_cache=False)
+        else:
+            q, k = self.rotary_emb(positions, q, k)       # in place on the qkv views
+            attn_output = self.attn(q, k, v, forward_batch)
         output, _ = self.o_proj(attn_output)
         return output
 
