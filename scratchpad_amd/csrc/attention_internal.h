@@ -26,6 +26,10 @@ struct DecodeArgs {
 
 // decode_attention.hip: launch the split-KV decode kernel (+ merge when num_splits > 1)
 int run_decode(const DecodeArgs& a, int head_dim, int group, int dtype, hipStream_t st);
+// decode_attention.hip: merge of the split partials (shared by the VALU and MFMA decode kernels)
+int run_decode_merge(const DecodeArgs& a, int head_dim, int dtype, hipStream_t st);
+// decode_mfma.hip: matrix-core decode kernel for 16-bit dtypes, G <= 16 (attention kernel only)
+int run_decode_mfma(const DecodeArgs& a, int head_dim, int dtype, hipStream_t st);
 // heads per wave-load: the largest power of two <= rows-per-load that divides Hkv
 int decode_heads_per_load_shift(int num_kv_heads, int head_dim, int dtype, int* head_groups);
 

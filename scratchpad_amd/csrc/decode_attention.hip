@@ -23,6 +23,8 @@
 //
 // Launch geometry depends only on (batch, heads, max_seq_len, chunk): graph-capturable.
 // Workgroups whose chunk starts beyond their request's seq_len exit at once.
+#include <stdlib.h>
+
 #include "sp_common.h"
 #include "attention_internal.h"
 
@@ -409,7 +411,62 @@ static int dispatch_dim(const DecodeArgs& a, int D, int G, hipStream_t st) {
   }
 }
 
+template <typename Tag, int D, int G>
+static int occupancy_of() {
+  typedef DecodeCfg<Tag, D, G> C;
+  const size_t lds = (size_t)C::kLdsFloats * sizeof(float);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)decode_attn_kernel<Tag, D, G>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  int n = -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, decode_attn_kernel<Tag, D, G>, 256, lds) !=
+      hipSuccess)
+    return -1;
+  return n;
+}
+
+int decode_occupancy(int head_dim, int group, int dtype) {
+  if (dtype != SP_BF16 || head_dim != 128) return -1;
+  switch (group) {
+    case 1: return occupancy_of<bf16_tag, 128, 1>();
+    case 2: return occupancy_of<bf16_tag, 128, 2>();
+    case 4: return occupancy_of<bf16_tag, 128, 4>();
+    case 8: return occupancy_of<bf16_tag, 128, 8>();
+    default: return -1;
+  }
+}
+
+template <typename Tag>
+static int merge_dim(const DecodeArgs& a, int D, hipStream_t st) {
+  const dim3 grid((a.bs * a.Hq + 3) / 4);
+  if (D == 128) decode_merge_kernel<Tag, 128><<<grid, 256, 0, st>>>(a);
+  else if (D == 64) decode_merge_kernel<Tag, 64><<<grid, 256, 0, st>>>(a);
+  else return SP_ERR_UNSUPPORTED;
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
+int run_decode_merge(const DecodeArgs& a, int head_dim, int dtype, hipStream_t st) {
+  if (a.num_splits <= 1) return SP_OK;
+  SP_DISPATCH_DTYPE(dtype, return (merge_dim<Tag>(a, head_dim, st)));
+}
+
+// Kernel choice.  Wide groups (G >= 8) go to the matrix-core kernel (decode_mfma.hip): the VALU
+// kernel needs 256 VGPRs there.  SP_DECODE_KERNEL=valu|mfma overrides (A/B measurements only).
+static int decode_kernel_choice(int group, int dtype) {
+  const char* e = getenv("SP_DECODE_KERNEL");  // read per call: tests flip it within one process
+  const int forced = !e ? 0 : (e[0] == 'm' ? 2 : (e[0] == 'v' ? 1 : 0));
+  if (dtype == SP_F32 || group > 16) return 1;
+  if (forced) return forced;
+  return group >= 8 ? 2 : 1;
+}
+
 int run_decode(const DecodeArgs& a, int head_dim, int group, int dtype, hipStream_t st) {
+  if (decode_kernel_choice(a.Hq / a.Hkv, dtype) == 2) {
+    const int rc = run_decode_mfma(a, head_dim, dtype, st);
+    if (rc == SP_OK) return run_decode_merge(a, head_dim, dtype, st);
+    if (rc != SP_ERR_UNSUPPORTED) return rc;
+  }
   SP_DISPATCH_DTYPE(dtype, return (dispatch_dim<Tag>(a, head_dim, group, st)));
 }
 
@@ -438,6 +495,12 @@ extern "C" size_t sp_decode_attention_workspace_bytes(int batch_size, int num_q_
   const int64_t s = num_splits_for(max_seq_len, chunk);
   if (s <= 1) return 16;
   return (size_t)batch_size * num_q_heads * s * (v_head_dim + 1) * sizeof(float) + 16;
+}
+
+// diagnostic (not part of the forward path): resident workgroups per CU the runtime reports for the
+// bf16 D=128 decode kernel of a given group size
+extern "C" SP_API int sp_debug_decode_occupancy(int head_dim, int group, int dtype) {
+  return decode_occupancy(head_dim, group, dtype);
 }
 
 extern "C" size_t sp_decode_plan_bytes(int batch_size, int64_t max_seq_len, int chunk) {

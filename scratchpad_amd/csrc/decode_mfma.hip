@@ -1,0 +1,314 @@
+// Paged decode attention on the matrix cores, for wide GQA groups (16-bit dtypes, G <= 16).
+//
+// The VALU kernel (decode_attention.hip) keeps G x 8 fp32 accumulators and G packed q fragments per
+// lane; at G = 8 that is 256 VGPRs (one wave per SIMD) and twice the vector work per KV byte, and it
+// runs at 2-3 TB/s.  Here the G query heads of one KV head are the COLUMNS of a 16-wide MFMA tile, so
+// the per-lane state is 32 accumulator registers whatever G is, and the vector unit only does the
+// 4-values-per-lane softmax:
+//
+//   * workgroup = 4 waves = (request, split, ONE kv head); each wave walks its share of the split in
+//     tiles of 16 keys;
+//   * K/V rows are gathered exactly as in the VALU kernel - full 256-B lines, 16 B per lane, four rows
+//     per wave-load, next tile's loads issued before the current tile is consumed - then written to a
+//     wave-private 8 KiB LDS tile (16-B chunks XOR-swizzled by row, so the fragment reads below are
+//     conflict-free); no barrier: a wave's own LDS accesses complete in order;
+//   * S^T[16 keys x 16 cols] = K . Q^T with v_mfma_f32_16x16x32 (A = K rows by ds_read_b128, B = Q
+//     fragments held in registers); the accumulator has the head column on lane&15 and 4 keys in
+//     registers, which is exactly the B-operand layout of v_mfma_f32_16x16x16 (k = 4*(lane>>4)+j), so
+//     O^T[16 d x 16 cols] += V^T . P^T takes P straight from registers; the V^T fragment is one
+//     ds_read_b64_tr_b16 (hardware transpose) per 16-d block;
+//   * online softmax per column: 4 in-lane values + two lane exchanges (xor 16, xor 32); the rescale
+//     factor of O^T is lane-local;
+//   * the 4 waves' (m, l, O) are merged through LDS (the tile area is reused), split partials go to
+//     the same workspace / merge kernel as the VALU path.
+#include "attention_internal.h"
+
+namespace sp {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_m __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_m __attribute__((ext_vector_type(8)));
+typedef short s16x4_m __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4_m __attribute__((ext_vector_type(4)));
+
+static constexpr float kLog2eM = 1.4426950408889634f;
+static constexpr float kNegBigM = -1.0e30f;
+
+template <typename Tag>
+__device__ __forceinline__ f32x4_t mfma_qk(const u32x4& a, const u32x4& b, const f32x4_t& c);
+template <>
+__device__ __forceinline__ f32x4_t mfma_qk<bf16_tag>(const u32x4& a, const u32x4& b, const f32x4_t& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_m, a),
+                                                 __builtin_bit_cast(bf16x8_m, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4_t mfma_qk<f16_tag>(const u32x4& a, const u32x4& b, const f32x4_t& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_m, a),
+                                                __builtin_bit_cast(f16x8_m, b), c, 0, 0, 0);
+}
+template <typename Tag>
+__device__ __forceinline__ f32x4_t mfma_pv(const u32x2& a, const u32x2& b, const f32x4_t& c);
+template <>
+__device__ __forceinline__ f32x4_t mfma_pv<bf16_tag>(const u32x2& a, const u32x2& b, const f32x4_t& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_m, a),
+                                                   __builtin_bit_cast(s16x4_m, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4_t mfma_pv<f16_tag>(const u32x2& a, const u32x2& b, const f32x4_t& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_m, a),
+                                               __builtin_bit_cast(f16x4_m, b), c, 0, 0, 0);
+}
+
+template <typename Tag>
+__device__ __forceinline__ uint32_t pack2m(float lo, float hi);
+template <>
+__device__ __forceinline__ uint32_t pack2m<bf16_tag>(float lo, float hi) {
+  bf16x2_t b;
+  b[0] = (__bf16)lo;
+  b[1] = (__bf16)hi;
+  return __builtin_bit_cast(uint32_t, b);
+}
+template <>
+__device__ __forceinline__ uint32_t pack2m<f16_tag>(float lo, float hi) {
+  f16x2_t b;
+  b[0] = (_Float16)lo;
+  b[1] = (_Float16)hi;
+  return __builtin_bit_cast(uint32_t, b);
+}
+
+template <int D>
+struct DmCfg {
+  static constexpr int TK = 16;                    // keys per tile
+  static constexpr int ROW_B = D * 2;              // bytes per K/V row
+  static constexpr int CPR = ROW_B / 16;           // 16-byte chunks per row (16 / 8)
+  static constexpr int RPL = 64 / CPR;             // rows per wave-load (4 / 8)
+  static constexpr int NLD = TK / RPL;             // wave-loads per tile, each for K and for V (4 / 2)
+  static constexpr int KSTEPS = D / 32;            // 16x16x32 k-steps of Q.K^T
+  static constexpr int DBLK = D / 16;              // 16-wide d blocks of O^T
+  static constexpr int TILE_B = TK * ROW_B;        // one K (or V) tile
+  static constexpr int WAVES = 4;
+  static constexpr int kStageBytes = WAVES * 2 * TILE_B;
+  static constexpr int kMergeBytes = WAVES * 16 * (D + 2) * 4;
+  static constexpr int kLdsBytes = kStageBytes > kMergeBytes ? kStageBytes : kMergeBytes;
+};
+
+template <typename Tag, int D>
+__global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
+  typedef DmCfg<D> C;
+  typedef Elem<Tag> E;
+  constexpr int TK = C::TK, ROW_B = C::ROW_B, CPR = C::CPR, RPL = C::RPL, NLD = C::NLD;
+  constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK, TILE_B = C::TILE_B, WAVES = C::WAVES;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  // blockIdx -> (item, kv head); the heads of one token row are adjacent in launch order
+  const int hk = blockIdx.x % a.Hkv;
+  const int item = blockIdx.x / a.Hkv;
+  int b, c;
+  if (a.plan) {
+    if (item >= a.plan[0]) return;
+    b = a.plan[2 + 2 * item];
+    c = a.plan[3 + 2 * item];
+  } else {
+    c = item % a.num_splits;
+    b = item / a.num_splits;
+  }
+  const int seq = (int)load_idx(a.seq_lens, b, a.idx64);
+  const int cs = c * a.chunk;
+  if (cs >= seq) return;
+  const int ce = min(cs + a.chunk, seq);
+  const int nsplit = (seq + a.chunk - 1) / a.chunk;
+  const int64_t req = load_idx(a.req_idx, b, a.idx64);
+  const int64_t kv0 = a.kv_start ? load_idx(a.kv_start, b, a.idx64) : 0;
+  const int32_t* idx_row = a.r2t + req * a.r2t_stride + kv0;
+  const int G = a.Hq / a.Hkv;
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int col = lane & 15, kq = lane >> 4;       // MFMA column (query head) / k quarter
+  char* ldsK = lds + wave * 2 * TILE_B;
+  char* ldsV = ldsK + TILE_B;
+
+  // Q fragments: B operand of S^T = K.Q^T; lane (col, kq) holds Q[head col][32s + 8kq .. +7]
+  u32x4 qf[KSTEPS];
+  {
+    const int hcol = min(col, G - 1);              // padding columns repeat the last head; never stored
+    const char* qp = (const char*)a.q +
+                     ((int64_t)b * a.q_stride + (int64_t)(hk * G + hcol) * D + 8 * kq) * 2;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) qf[s] = ld16(qp + s * 64);
+  }
+  const float cap = a.logit_cap;
+  const float qk_scale = cap > 0.f ? a.sm_scale : a.sm_scale * kLog2eM;
+
+  f32x4_t oacc[DBLK];
+#pragma unroll
+  for (int db = 0; db < DBLK; ++db) oacc[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = kNegBigM, l_run = 0.f;
+
+  // gather mapping: lane -> (row within the wave-load, 16-byte chunk)
+  const int ld_row = lane / CPR, ld_ch = lane % CPR;
+  const int64_t tok_bytes = a.kv_stride * 2;
+  const int64_t head_off = (int64_t)hk * ROW_B;
+  // fragment-read addresses (constant per lane)
+  const int i16 = lane & 15;
+  const int tr_row = 4 * kq + (i16 >> 2);          // V row this lane addresses in a tr read
+
+  // this wave's contiguous share of the split, in whole tiles
+  const int sub = ((ce - cs + WAVES * TK - 1) / (WAVES * TK)) * TK;
+  const int ws = cs + wave * sub;
+  const int we = min(ws + sub, ce);
+
+  int nextidx = (ws + lane < we) ? idx_row[ws + lane] : 0;
+  for (int ps = ws; ps < we; ps += 64) {           // pieces of <= 64 keys: one index register
+    const int n = min(64, we - ps);
+    const int myidx = nextidx;
+    nextidx = (ps + 64 + lane < we) ? idx_row[ps + 64 + lane] : 0;
+    const int ntile = (n + TK - 1) / TK;
+
+    u32x4 kA[NLD], vA[NLD], kB[NLD], vB[NLD];
+    auto issue = [&](u32x4(&kr)[NLD], u32x4(&vr)[NLD], int tile) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int key = tile * TK + i * RPL + ld_row;         // key within the piece
+        const int slot = __shfl(myidx, key & 63, 64);
+        // source chunk is XOR-swizzled by the tile row so that the LDS image is conflict-free
+        const int R = i * RPL + ld_row;
+        const int64_t off = (key < n ? (int64_t)slot : 0) * tok_bytes + head_off +
+                            ((ld_ch ^ (R & (CPR - 1))) * 16);
+        kr[i] = ld16(a.kbuf + off);
+        vr[i] = ld16(a.vbuf + off);
+      }
+    };
+    auto consume = [&](const u32x4(&kr)[NLD], const u32x4(&vr)[NLD], int tile) {
+      // ---- registers -> this wave's LDS tile: position (row R, chunk ld_ch) holds source chunk
+      //      ld_ch ^ R, i.e. logical chunk cg of row R sits at chunk cg ^ R
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int R = i * RPL + ld_row;
+        st16(ldsK + R * ROW_B + ld_ch * 16, kr[i]);
+        st16(ldsV + R * ROW_B + ld_ch * 16, vr[i]);
+      }
+      // ---- S^T = K . Q^T: lane (key = col index of A rows = lane&15, kq)
+      f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      {
+        const int R = lane & 15;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          const int cg = 4 * ks + kq;                          // logical chunk: dims 32ks + 8kq ..
+          const u32x4 kf = ld16(ldsK + R * ROW_B + ((cg ^ (R & (CPR - 1))) * 16));
+          s = mfma_qk<Tag>(kf, qf[ks], s);
+        }
+      }
+      // ---- scale, mask, online softmax for column `col`; this lane holds keys 4kq + j
+      float x[4], mx = kNegBigM;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = s[j] * qk_scale;
+        if (cap > 0.f) v = cap * tanhf(v / cap) * kLog2eM;
+        x[j] = (tile * TK + 4 * kq + j < n) ? v : -INFINITY;
+        mx = fmaxf(mx, x[j]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[j] = __builtin_amdgcn_exp2f(x[j] - m_new);
+        psum += x[j];
+      }
+      psum += __shfl_xor(psum, 16, 64);
+      psum += __shfl_xor(psum, 32, 64);
+      l_run = l_run * alpha + psum;
+      u32x2 pf;  // B operand of O^T += V^T.P^T: P^T[k = 4kq + j][col]
+      pf[0] = pack2m<Tag>(x[0], x[1]);
+      pf[1] = pack2m<Tag>(x[2], x[3]);
+      // ---- O^T[16 d x 16 cols] per d block; V^T fragment by one transposed read:
+      //      lane i of a 16-lane group addresses row 4kq + (i>>2), elements 4(i&3)..+3 of the block
+#pragma unroll
+      for (int db = 0; db < DBLK; ++db) {
+        const int cg = 2 * db + ((i16 & 3) >> 1);             // logical 16-byte chunk of the row
+        const char* vp = ldsV + tr_row * ROW_B + ((cg ^ (tr_row & (CPR - 1))) * 16) + 8 * (i16 & 1);
+        const s16x4_m vt = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_m*)vp);
+        const u32x2 vf = __builtin_bit_cast(u32x2, vt);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[db][r] *= alpha;
+        oacc[db] = mfma_pv<Tag>(vf, pf, oacc[db]);
+      }
+    };
+
+    issue(kA, vA, 0);
+    for (int t = 0; t < ntile; t += 2) {
+      if (t + 1 < ntile) issue(kB, vB, t + 1);
+      consume(kA, vA, t);
+      if (t + 1 < ntile) {
+        if (t + 2 < ntile) issue(kA, vA, t + 2);
+        consume(kB, vB, t + 1);
+      }
+    }
+  }
+
+  // ---- merge the 4 waves through LDS (reusing the tile area): O^T[d][col], m, l per column
+  __syncthreads();  // every wave is done with its tiles
+  float* sm_o = (float*)lds;                       // [WAVES][16 cols][D]
+  float* sm_ml = sm_o + WAVES * 16 * D;            // [WAVES][16 cols][2]
+  {
+    float* dst = sm_o + (wave * 16 + col) * D + 4 * kq;
+#pragma unroll
+    for (int db = 0; db < DBLK; ++db)
+      *(float4*)(dst + 16 * db) = make_float4(oacc[db][0], oacc[db][1], oacc[db][2], oacc[db][3]);
+    if (kq == 0) {
+      sm_ml[(wave * 16 + col) * 2] = m_run;
+      sm_ml[(wave * 16 + col) * 2 + 1] = l_run;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < G * D; i += 256) {
+    const int d = i % D, g = i / D;
+    float M = kNegBigM;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) M = fmaxf(M, sm_ml[(w * 16 + g) * 2]);
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      const float wgt = __builtin_amdgcn_exp2f(sm_ml[(w * 16 + g) * 2] - M);
+      L += sm_ml[(w * 16 + g) * 2 + 1] * wgt;
+      O += sm_o[(w * 16 + g) * D + d] * wgt;
+    }
+    const int h = hk * G + g;
+    const float o = O / L;
+    if (nsplit == 1) {
+      E::store(a.out, (int64_t)b * a.o_stride + (int64_t)h * D + d, o);
+    } else {
+      const int64_t pi = ((int64_t)b * a.Hq + h) * a.num_splits + c;
+      a.part_o[pi * D + d] = o;
+      if (d == 0) a.part_lse[pi] = M + __builtin_amdgcn_logf(L);
+    }
+  }
+}
+
+template <typename Tag, int D>
+static int launch_dm(const DecodeArgs& a, hipStream_t st) {
+  typedef DmCfg<D> C;
+  const unsigned grid = (unsigned)a.bs * a.num_splits * a.Hkv;
+  decode_mfma_kernel<Tag, D><<<dim3(grid), 256, C::kLdsBytes, st>>>(a);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
+// 16-bit dtypes, D in {64,128}, G <= 16.  Launches the attention kernel only; the caller runs the
+// split merge (shared with the VALU path).
+int run_decode_mfma(const DecodeArgs& a, int head_dim, int dtype, hipStream_t st) {
+  const int G = a.Hq / a.Hkv;
+  if (G > 16 || (dtype != SP_BF16 && dtype != SP_F16)) return SP_ERR_UNSUPPORTED;
+  if ((int64_t)a.bs * a.num_splits * a.Hkv > 0x7fffffffLL) return SP_ERR_INVALID_ARG;
+  if (head_dim == 128)
+    return dtype == SP_BF16 ? launch_dm<bf16_tag, 128>(a, st) : launch_dm<f16_tag, 128>(a, st);
+  if (head_dim == 64)
+    return dtype == SP_BF16 ? launch_dm<bf16_tag, 64>(a, st) : launch_dm<f16_tag, 64>(a, st);
+  return SP_ERR_UNSUPPORTED;
+}
+
+}  // namespace sp

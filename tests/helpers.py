@@ -27,15 +27,25 @@ def tol(dtype, kind="attn"):
     return 2.0 ** -8 + 1e-3, 1e-3
 
 
-def assert_close(hip, ref, dtype, kind="attn", what=""):
+def assert_close(hip, ref, dtype, kind="attn", what="", both_rounded=False, vmax=None):
+    """both_rounded: `ref` is itself a HIP output in `dtype` (e.g. another split size): allow one
+    more output quantisation step.
+    vmax: max |V| of the attended rows.  Like the reference's kernels (decode_attention.py:427,
+    extend_attention.py:155 `p = p.to(v.dtype)`) the matrix-core kernels feed P to the P.V product
+    in the KV dtype; that rounding perturbs an output by at most eps_dtype/2 * max|V| (sum p = l),
+    independent of the output's own size.  Half of that bound is allowed on top of the 1e-3 bar."""
     hip = hip.detach().float().cpu().double()
     ref = ref.detach().float().cpu().double()
     assert hip.shape == ref.shape, (hip.shape, ref.shape)
     assert torch.isfinite(hip).all(), f"{what}: non-finite output"
     rtol, ascale = tol(dtype, kind)
+    if both_rounded and dtype != torch.float32:
+        rtol += {torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8}[dtype]
     scale = float(ref.abs().max()) if ref.numel() else 0.0
     err = (hip - ref).abs()
     bound = rtol * ref.abs() + ascale * scale
+    if vmax is not None and dtype != torch.float32:
+        bound = bound + 0.5 * {torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8}[dtype] * 0.5 * float(vmax)
     bad = err > bound
     assert not bool(bad.any()), (
         f"{what}: {int(bad.sum())}/{bad.numel()} out of tolerance, max err {float(err.max()):.3e} "
