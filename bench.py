@@ -358,7 +358,7 @@ def main():
         if os.path.exists(pmc) and args.model == "llama3-8b":
             ratio = json.load(open(pmc))["traffic_over_algorithmic"]
             traffic, traffic_src = int(alg * ratio), "profiles/r01_decode_attn_pmc.txt (PMC ratio x algorithmic)"
-        roofline = {"bound": "hbm", "kernel": "decode_attn_kernel+decode_merge_kernel",
+        roofline = {"bound": "hbm", "kernel": "decode_mfma_kernel+decode_merge_kernel",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "traffic_source": traffic_src,

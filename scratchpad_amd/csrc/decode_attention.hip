@@ -451,14 +451,16 @@ int run_decode_merge(const DecodeArgs& a, int head_dim, int dtype, hipStream_t s
   SP_DISPATCH_DTYPE(dtype, return (merge_dim<Tag>(a, head_dim, st)));
 }
 
-// Kernel choice.  Wide groups (G >= 8) go to the matrix-core kernel (decode_mfma.hip): the VALU
-// kernel needs 256 VGPRs there.  SP_DECODE_KERNEL=valu|mfma overrides (A/B measurements only).
+// Kernel choice.  16-bit dtypes go to the matrix-core kernel (decode_mfma.hip; measured equal or
+// faster than the VALU kernel on every shape tried, 2.3x at G = 8 where the VALU kernel needs 256
+// VGPRs); fp32 and groups wider than 16 stay on the VALU kernel below.
+// SP_DECODE_KERNEL=valu|mfma overrides the choice (A/B measurements and tests only).
 static int decode_kernel_choice(int group, int dtype) {
   const char* e = getenv("SP_DECODE_KERNEL");  // read per call: tests flip it within one process
   const int forced = !e ? 0 : (e[0] == 'm' ? 2 : (e[0] == 'v' ? 1 : 0));
   if (dtype == SP_F32 || group > 16) return 1;
   if (forced) return forced;
-  return group >= 8 ? 2 : 1;
+  return 2;
 }
 
 int run_decode(const DecodeArgs& a, int head_dim, int group, int dtype, hipStream_t st) {

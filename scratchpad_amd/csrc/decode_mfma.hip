@@ -92,7 +92,10 @@ struct DmCfg {
   static constexpr int kLdsBytes = kStageBytes > kMergeBytes ? kStageBytes : kMergeBytes;
 };
 
-template <typename Tag, int D>
+// HPW ("head per wave", Hkv % 4 == 0): the 4 waves take the 4 adjacent KV heads of the SAME keys - the
+// workgroup then reads whole 1 KiB token half-rows, and each wave owns its heads outright: no merge,
+// no barrier anywhere.  Otherwise (few KV heads per rank) the waves split the keys of one head.
+template <typename Tag, int D, bool HPW>
 __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
   typedef DmCfg<D> C;
   typedef Elem<Tag> E;
@@ -100,9 +103,11 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
   constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK, TILE_B = C::TILE_B, WAVES = C::WAVES;
   extern __shared__ __attribute__((aligned(16))) char lds[];
 
-  // blockIdx -> (item, kv head); the heads of one token row are adjacent in launch order
-  const int hk = blockIdx.x % a.Hkv;
-  const int item = blockIdx.x / a.Hkv;
+  // blockIdx -> (item, kv head or head quad); the heads of one token row are adjacent in launch order
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int hgroups = HPW ? a.Hkv / 4 : a.Hkv;
+  const int hk = HPW ? (blockIdx.x % hgroups) * 4 + wave : blockIdx.x % hgroups;
+  const int item = blockIdx.x / hgroups;
   int b, c;
   if (a.plan) {
     if (item >= a.plan[0]) return;
@@ -122,7 +127,6 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
   const int32_t* idx_row = a.r2t + req * a.r2t_stride + kv0;
   const int G = a.Hq / a.Hkv;
 
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int col = lane & 15, kq = lane >> 4;       // MFMA column (query head) / k quarter
   char* ldsK = lds + wave * 2 * TILE_B;
   char* ldsV = ldsK + TILE_B;
@@ -152,9 +156,9 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
   const int i16 = lane & 15;
   const int tr_row = 4 * kq + (i16 >> 2);          // V row this lane addresses in a tr read
 
-  // this wave's contiguous share of the split, in whole tiles
-  const int sub = ((ce - cs + WAVES * TK - 1) / (WAVES * TK)) * TK;
-  const int ws = cs + wave * sub;
+  // this wave's keys: the whole split (HPW) or a contiguous share of it in whole tiles
+  const int sub = HPW ? ce - cs : ((ce - cs + WAVES * TK - 1) / (WAVES * TK)) * TK;
+  const int ws = HPW ? cs : cs + wave * sub;
   const int we = min(ws + sub, ce);
 
   int nextidx = (ws + lane < we) ? idx_row[ws + lane] : 0;
@@ -164,8 +168,8 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
     nextidx = (ps + 64 + lane < we) ? idx_row[ps + 64 + lane] : 0;
     const int ntile = (n + TK - 1) / TK;
 
-    u32x4 kA[NLD], vA[NLD], kB[NLD], vB[NLD];
-    auto issue = [&](u32x4(&kr)[NLD], u32x4(&vr)[NLD], int tile) {
+    u32x4 kr[NLD], vr[NLD];
+    auto issue = [&](int tile) {
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
         const int key = tile * TK + i * RPL + ld_row;         // key within the piece
@@ -178,15 +182,17 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
         vr[i] = ld16(a.vbuf + off);
       }
     };
-    auto consume = [&](const u32x4(&kr)[NLD], const u32x4(&vr)[NLD], int tile) {
-      // ---- registers -> this wave's LDS tile: position (row R, chunk ld_ch) holds source chunk
-      //      ld_ch ^ R, i.e. logical chunk cg of row R sits at chunk cg ^ R
+    auto stage = [&]() {
+      // registers -> this wave's LDS tile: position (row R, chunk ld_ch) holds source chunk
+      // ld_ch ^ R, i.e. logical chunk cg of row R sits at chunk cg ^ R
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
         const int R = i * RPL + ld_row;
         st16(ldsK + R * ROW_B + ld_ch * 16, kr[i]);
         st16(ldsV + R * ROW_B + ld_ch * 16, vr[i]);
       }
+    };
+    auto consume = [&](int tile) {
       // ---- S^T = K . Q^T: lane (key = col index of A rows = lane&15, kq)
       f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
       {
@@ -239,17 +245,44 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
       }
     };
 
-    issue(kA, vA, 0);
-    for (int t = 0; t < ntile; t += 2) {
-      if (t + 1 < ntile) issue(kB, vB, t + 1);
-      consume(kA, vA, t);
-      if (t + 1 < ntile) {
-        if (t + 2 < ntile) issue(kA, vA, t + 2);
-        consume(kB, vB, t + 1);
-      }
+    // one register set: the tile's registers are free as soon as they are in LDS, so the next
+    // tile's gathers are issued right there and fly during this tile's MFMAs and softmax (and under
+    // the other waves of the SIMD: ~100 VGPRs => 4 waves per SIMD)
+    issue(0);
+    for (int t = 0; t < ntile; ++t) {
+      stage();
+      if (t + 1 < ntile) issue(t + 1);
+      consume(t);
     }
   }
 
+  if constexpr (HPW) {
+    // ---- this wave owns heads hk*G .. hk*G+G-1: normalise and write straight from registers
+    //      (lane (col, kq) holds d = 16db + 4kq .. +3 of head col)
+    if (col < G) {
+      const int h = hk * G + col;
+      const float inv = 1.0f / l_run;
+      if (nsplit == 1) {
+        char* op = (char*)a.out + ((int64_t)b * a.o_stride + (int64_t)h * D + 4 * kq) * 2;
+#pragma unroll
+        for (int db = 0; db < DBLK; ++db) {
+          u32x2 w;
+          w[0] = pack2m<Tag>(oacc[db][0] * inv, oacc[db][1] * inv);
+          w[1] = pack2m<Tag>(oacc[db][2] * inv, oacc[db][3] * inv);
+          *(u32x2*)(op + db * 32) = w;
+        }
+      } else {
+        const int64_t pi = ((int64_t)b * a.Hq + h) * a.num_splits + c;
+        float* pp = a.part_o + pi * D + 4 * kq;
+#pragma unroll
+        for (int db = 0; db < DBLK; ++db)
+          *(float4*)(pp + 16 * db) = make_float4(oacc[db][0] * inv, oacc[db][1] * inv,
+                                                 oacc[db][2] * inv, oacc[db][3] * inv);
+        if (kq == 0) a.part_lse[pi] = m_run + __builtin_amdgcn_logf(l_run);
+      }
+    }
+    return;
+  }
   // ---- merge the 4 waves through LDS (reusing the tile area): O^T[d][col], m, l per column
   __syncthreads();  // every wave is done with its tiles
   float* sm_o = (float*)lds;                       // [WAVES][16 cols][D]
@@ -292,8 +325,13 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
 template <typename Tag, int D>
 static int launch_dm(const DecodeArgs& a, hipStream_t st) {
   typedef DmCfg<D> C;
-  const unsigned grid = (unsigned)a.bs * a.num_splits * a.Hkv;
-  decode_mfma_kernel<Tag, D><<<dim3(grid), 256, C::kLdsBytes, st>>>(a);
+  if (a.Hkv % 4 == 0 && a.o_stride % 4 == 0) {
+    const unsigned grid = (unsigned)a.bs * a.num_splits * (a.Hkv / 4);
+    decode_mfma_kernel<Tag, D, true><<<dim3(grid), 256, C::kLdsBytes, st>>>(a);
+  } else {
+    const unsigned grid = (unsigned)a.bs * a.num_splits * a.Hkv;
+    decode_mfma_kernel<Tag, D, false><<<dim3(grid), 256, C::kLdsBytes, st>>>(a);
+  }
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
