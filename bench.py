@@ -38,7 +38,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--bs", type=int, default=256)
     ap.add_argument("--ctx", default="uniform", help='"uniform" = U[128,4096] seed 0, or a fixed length')
-    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama32-1b"])
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama32-1b", "llama3-70b-tp8-rank"],
+                    help="llama3-70b-tp8-rank = one rank's shard of config 4 (no all-reduce): supplementary")
     ap.add_argument("--layers", type=int, default=None, help="override layer count (debug only)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -61,7 +62,8 @@ def build_engine(args, device_index, seed):
     else:
         ctx = torch.full((args.bs,), int(args.ctx), dtype=torch.int64)
     context_len = int(ctx.max()) + total_steps + 4
-    cfg = (ModelConfig.llama3_8b if args.model == "llama3-8b" else ModelConfig.llama32_1b)(context_len)
+    cfg = {"llama3-8b": ModelConfig.llama3_8b, "llama32-1b": ModelConfig.llama32_1b,
+           "llama3-70b-tp8-rank": ModelConfig.llama3_70b_tp8_rank}[args.model](context_len)
     if args.layers:
         cfg.num_hidden_layers = args.layers
     pool_tokens = int(ctx.sum()) + args.bs * total_steps + 64

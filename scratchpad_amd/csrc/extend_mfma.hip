@@ -92,7 +92,8 @@ struct ExtCfg {
   static constexpr int PASSES = BN / RPP;
   static constexpr int KSTEPS = D / 16;            // MFMA k-steps of Q.K^T
   static constexpr int DBLK = D / 32;              // 32-wide d blocks of O^T
-  static constexpr int kLdsBytes = BN * (SK + SV);
+  static constexpr int kTileBytes = BN * (SK + SV);   // one K tile + one V tile
+  static constexpr int kLdsBytes = 2 * kTileBytes;    // double-buffered: one barrier per tile
 };
 
 template <typename Tag, int D, int GK>
@@ -102,8 +103,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK;
   constexpr int BM = 128 / GK;
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  char* ldsK = lds;
-  char* ldsV = lds + BN * SK;
+  // two (K,V) tile buffers: tile t lives in buffer t & 1
 
   const int b = blockIdx.z;
   const int E = a.ext_lens[b];
@@ -165,12 +165,14 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
       vreg[p] = ld16(a.vbuf + off);
     }
   };
-  auto stage = [&]() {
+  auto stage = [&](int buf) {
+    char* dK = lds + buf * C::kTileBytes;
+    char* dV = dK + BN * SK;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int row = p * RPP + st_row;
-      st16(ldsK + row * SK + st_ch * 16, kreg[p]);
-      st16(ldsV + row * SV + st_ch * 16, vreg[p]);
+      st16(dK + row * SK + st_ch * 16, kreg[p]);
+      st16(dV + row * SV + st_ch * 16, vreg[p]);
     }
   };
 
@@ -178,11 +180,16 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   const int i16 = lane & 15, g16 = lane >> 4;
   const int tr_rowq = i16 >> 2, tr_col = ((g16 & 1) * 16 + (i16 & 3) * 4) * 2;  // bytes
 
+  // pipeline: tile t+1's global gathers fly during compute(t); they are written to the OTHER LDS
+  // buffer right after compute(t), and one barrier per tile both publishes tile t+1 and retires
+  // every wave's reads of tile t (whose buffer is overwritten only in iteration t+1)
   prefetch(0);
+  stage(0);
+  __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
-    stage();
-    __syncthreads();
     if (t + 1 < ntiles) prefetch(t + 1);
+    const char* ldsK = lds + (t & 1) * C::kTileBytes;
+    const char* ldsV = ldsK + BN * SK;
     const int key0 = t * BN;
     // a wave skips tiles that lie entirely above its rows' diagonal (wave-uniform)
     const bool visible = wave_live && (!a.causal || key0 <= P + min(r0 + 31, E - 1));
@@ -202,17 +209,31 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
       }
       // ---- scale, mask, online softmax (query row on the lane; keys in registers + lane^32)
       float mx = kNegBigX;
+      // interior tiles (entirely below every row's diagonal and inside the key range) need no mask
+      const bool need_mask = key0 + BN > kv_len || (a.causal && key0 + BN - 1 > P + r0);
+      if (need_mask) {
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          float x = s[kb][r] * qk_scale;
-          if (cap > 0.f) x = cap * tanhf(x / cap) * kLog2eX;
-          x = (key < kv_len && key <= row_limit) ? x : -INFINITY;
-          s[kb][r] = x;
-          mx = fmaxf(mx, x);
-        }
+          for (int r = 0; r < 16; ++r) {
+            const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float x = s[kb][r] * qk_scale;
+            if (cap > 0.f) x = cap * tanhf(x / cap) * kLog2eX;
+            x = (key < kv_len && key <= row_limit) ? x : -INFINITY;
+            s[kb][r] = x;
+            mx = fmaxf(mx, x);
+          }
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float x = s[kb][r] * qk_scale;
+            if (cap > 0.f) x = cap * tanhf(x / cap) * kLog2eX;
+            s[kb][r] = x;
+            mx = fmaxf(mx, x);
+          }
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -228,10 +249,12 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
         }
       psum += __shfl_xor(psum, 32, 64);
       l_run = l_run * alpha + psum;
+      if (!__all(alpha == 1.0f)) {  // the row maxima settle after the first tiles: usually skipped
 #pragma unroll
-      for (int db = 0; db < DBLK; ++db)
+        for (int db = 0; db < DBLK; ++db)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+      }
       // ---- O^T += V^T . P^T
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
@@ -260,7 +283,8 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
         }
       }
     }
-    __syncthreads();  // every wave is done with this tile before the next one overwrites it
+    if (t + 1 < ntiles) stage((t + 1) & 1);
+    __syncthreads();
   }
 
   // ---- epilogue: O[row][head][d] = O^T[d][row] / l ; lane holds 4 consecutive d per register quad

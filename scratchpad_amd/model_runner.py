@@ -65,6 +65,13 @@ class ModelConfig:
                    max_position_embeddings=max(8192, context_len))
 
     @classmethod
+    def llama3_70b_tp8_rank(cls, context_len: int = 8192):
+        """ONE rank's shard of Llama-3-70B at TP=8 expressed as a TP=1 model (8 q heads, 1 kv head,
+        inter/8, vocab/8): the per-rank compute of config 4 without its all-reduces."""
+        return cls(8192, 28672 // 8, 80, 8, 1, 128256 // 8, context_len=context_len, head_dim=128,
+                   max_position_embeddings=max(8192, context_len))
+
+    @classmethod
     def llama3_70b(cls, context_len: int = 8192):
         return cls(8192, 28672, 80, 64, 8, 128256, context_len=context_len,
                    max_position_embeddings=max(8192, context_len))
