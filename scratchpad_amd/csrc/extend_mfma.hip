@@ -201,11 +201,16 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
         const char* kp = ldsK + (kb * 32 + c) * SK + h * 16;
+        // all fragment reads of the block are issued before its first MFMA (distinct registers), so
+        // one LDS latency is exposed per block instead of one per MFMA
+        u32x4 kf[KSTEPS];
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-          const u32x4 kf = ld16(kp + ks * 32);
-          s[kb] = mfma32<Tag>(kf, qf[ks], s[kb]);
-        }
+        for (int ks = 0; ks < KSTEPS; ++ks) kf[ks] = ld16(kp + ks * 32);
+        // keep the scheduler from sinking each read next to its MFMA again (it then reuses one
+        // register quad and waits lgkmcnt(0) before every MFMA)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) s[kb] = mfma32<Tag>(kf[ks], qf[ks], s[kb]);
       }
       // ---- scale, mask, online softmax (query row on the lane; keys in registers + lane^32)
       float mx = kNegBigX;
@@ -258,12 +263,11 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
       // ---- O^T += V^T . P^T
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
+        // V^T fragments of the whole 32-key block first (2 k-steps x DBLK d-blocks, two transposed
+        // reads each), then the MFMAs
+        u32x4 vf[2][DBLK];
 #pragma unroll
         for (int sidx = 0; sidx < 2; ++sidx) {
-          u32x4 pf;  // B operand: registers 8s..8s+7 of the S^T block, rounded to the KV dtype
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            pf[j] = pack2<Tag>(s[kb][8 * sidx + 2 * j], s[kb][8 * sidx + 2 * j + 1]);
           const int keyA = kb * 32 + 16 * sidx + 4 * h + tr_rowq;       // rows for elements 0..3
           const char* vp = ldsV + keyA * SV + tr_col;
 #pragma unroll
@@ -272,14 +276,22 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
                 (__attribute__((address_space(3))) s16x4_t*)(vp + db * 64));
             const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (__attribute__((address_space(3))) s16x4_t*)(vp + 8 * SV + db * 64));
-            u32x4 vf;
             const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
-            vf[0] = lo2[0];
-            vf[1] = lo2[1];
-            vf[2] = hi2[0];
-            vf[3] = hi2[1];
-            oacc[db] = mfma32<Tag>(vf, pf, oacc[db]);
+            vf[sidx][db][0] = lo2[0];
+            vf[sidx][db][1] = lo2[1];
+            vf[sidx][db][2] = hi2[0];
+            vf[sidx][db][3] = hi2[1];
           }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+          u32x4 pf;  // B operand: registers 8s..8s+7 of the S^T block, rounded to the KV dtype
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            pf[j] = pack2<Tag>(s[kb][8 * sidx + 2 * j], s[kb][8 * sidx + 2 * j + 1]);
+#pragma unroll
+          for (int db = 0; db < DBLK; ++db) oacc[db] = mfma32<Tag>(vf[sidx][db], pf, oacc[db]);
         }
       }
     }
