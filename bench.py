@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--layers", type=int, default=None, help="override layer count (debug only)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", action="store_true",
+                    help="run the forward on the overlap worker's thread/stream (tp_worker_client.py)")
     ap.add_argument("--mode", default="decode", choices=["decode", "prefill"],
                     help="decode = the headline metric; prefill = config 3 (ragged prefill, TTFT)")
     ap.add_argument("--prefix", type=int, default=0, help="prefill mode: shared cached prefix length")
@@ -298,7 +300,28 @@ def main():
     if not args.no_graph:
         mr.init_cuda_graphs()
     worker = TpModelWorker(mr)
+    overlap_worker = None
+    if args.overlap:
+        from scratchpad_amd.tp_worker_client import TpModelWorkerClient
+        overlap_worker = TpModelWorkerClient(mr)
     batch = populate_batch(mr, ctx, gen)
+
+    def run_steps(n):
+        """n decode steps; with --overlap the scheduler side runs one step ahead of the results"""
+        if overlap_worker is None:
+            for _ in range(n):
+                engine_step(worker, batch)
+            return
+        pending = 0
+        for _ in range(n):
+            batch.prepare_for_decode()
+            _, placeholders = overlap_worker.forward_batch_generation(batch.get_model_worker_batch())
+            batch.output_ids = placeholders
+            if pending:
+                overlap_worker.resolve_last_batch_result()
+            pending = 1
+        if pending:
+            overlap_worker.resolve_last_batch_result()
 
     def barrier():
         torch.cuda.synchronize()
@@ -306,13 +329,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        engine_step(worker, batch)
+    run_steps(args.warmup)
     barrier()
     seq_sum_start = batch.seq_lens_sum
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        engine_step(worker, batch)
+    run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     seq_sum_end = batch.seq_lens_sum
@@ -325,6 +346,8 @@ def main():
     # stream it is launched on (eager steps continuing the same trace)
     cfg = mr.model_config
     roofline = None
+    if overlap_worker is not None:
+        overlap_worker.close()
     if rank == 0 and args.profile_steps > 0:
         saved = mr.graph_runner
         mr.graph_runner = None
@@ -383,7 +406,7 @@ def main():
         "data": "synthetic (random-init weights, random KV, seeded contexts and slot permutation)",
         "config": {"workload": f"{args.model} TP=1 bf16 continuous-batching decode bs={args.bs} seq_len=1, "
                                f"ctx={'U[128,4096] seed 0' if args.ctx == 'uniform' else args.ctx}, page_size=1, "
-                               f"{'HIP-graph replay' if not args.no_graph else 'eager'}",
+                               f"{'HIP-graph replay' if not args.no_graph else 'eager'}{', overlap worker' if args.overlap else ''}",
                    "batch_size": args.bs, "mean_context": round(avg_seq / args.bs, 1),
                    "layers": cfg.num_hidden_layers, "replicas": world},
         "step_hbm_roofline_tokens_per_sec": round(step_roofline_tok_s, 1),

@@ -1,0 +1,103 @@
+"""Overlap worker: the forward pass runs on its own thread and HIP stream while the scheduler
+prepares the next batch.
+
+Mirrors managers/tp_worker_client.py:43-228: a forward thread pinned to ``forward_stream``, an
+input/output queue pair, and the *future token id* protocol - ``forward_batch_generation`` returns
+negative placeholder ids at once; the forward thread writes the sampled ids into
+``future_token_ids_map`` and resolves placeholders found in the next batch's ``input_ids``
+(``resolve_future_token_ids``, 34-40) before running it.  Every kernel of the hot path launches on
+``torch.cuda.current_stream()``, which is ``forward_stream`` inside the thread.
+"""
+import threading
+from queue import Queue
+from typing import Optional
+
+import torch
+
+from .forward_info import ModelWorkerBatch
+from .model_runner import ModelRunner, TpModelWorker
+
+
+def resolve_future_token_ids(input_ids: torch.Tensor, future_token_ids_map: torch.Tensor) -> None:
+    """tp_worker_client.py:34-40 (in place): ids < 0 are placeholders -k for map[k]."""
+    input_ids[:] = torch.where(input_ids < 0, future_token_ids_map[torch.clamp(-input_ids, min=0)],
+                               input_ids)
+
+
+class TpModelWorkerClient:
+    def __init__(self, model_runner: ModelRunner):
+        self.worker = TpModelWorker(model_runner)
+        self.max_running_requests = model_runner.max_running_requests
+        self.device = model_runner.device
+        self.future_token_ids_ct = 0
+        self.future_token_ids_limit = self.max_running_requests * 3
+        self.future_token_ids_map = torch.empty((self.max_running_requests * 5,), dtype=torch.int64,
+                                                device=self.device)
+        self.input_queue: Queue = Queue()
+        self.output_queue: Queue = Queue()
+        self.forward_stream = torch.cuda.Stream(device=self.device)
+        self.scheduler_stream = torch.cuda.current_stream(self.device)
+        self.error: Optional[BaseException] = None
+        self.forward_thread = threading.Thread(target=self.forward_thread_func, daemon=True)
+        self.forward_thread.start()
+
+    @property
+    def model_runner(self):
+        return self.worker.model_runner
+
+    def forward_thread_func(self):
+        try:
+            with torch.cuda.stream(self.forward_stream):
+                self.forward_thread_func_()
+        except BaseException as e:  # the reference SIGQUITs its parent (110-116); we surface it
+            self.error = e
+            self.output_queue.put((None, None, None))
+
+    @torch.inference_mode()
+    def forward_thread_func_(self):
+        batch_pt = 0
+        batch_lists = [None] * 2
+        while True:
+            model_worker_batch, future_token_ids_ct = self.input_queue.get()
+            if not model_worker_batch:
+                break
+            # keep the previous batch's tensors alive while the GPU may still read them (130-133)
+            batch_lists[batch_pt % 2] = model_worker_batch
+            batch_pt += 1
+            copy_done = torch.cuda.Event()
+            resolve_future_token_ids(model_worker_batch.input_ids, self.future_token_ids_map)
+            logits_output, next_token_ids = self.worker.forward_batch_generation(model_worker_batch)
+            bs = len(model_worker_batch.seq_lens)
+            self.future_token_ids_map[future_token_ids_ct + 1:future_token_ids_ct + bs + 1] = next_token_ids
+            next_token_ids = next_token_ids.to("cpu", non_blocking=True)
+            copy_done.record()
+            self.output_queue.put((copy_done, logits_output, next_token_ids))
+
+    def resolve_last_batch_result(self, launch_done: Optional[threading.Event] = None):
+        """tp_worker_client.py:170-190: wait for the previous batch's results (one step later)."""
+        copy_done, logits_output, next_token_ids = self.output_queue.get()
+        if copy_done is None:
+            raise RuntimeError("forward thread failed") from self.error
+        if launch_done is not None:
+            launch_done.wait()
+        copy_done.synchronize()
+        return logits_output, next_token_ids.tolist()
+
+    def forward_batch_generation(self, model_worker_batch: ModelWorkerBatch):
+        """Enqueue the batch and return placeholder ids (-ct-1 .. -ct-bs) at once (192-220)."""
+        if self.error is not None:
+            raise RuntimeError("forward thread failed") from self.error
+        # the scheduler's writes (req_to_token, allocator slices, input ids) must be visible to
+        # the forward stream before it reads them (203-204)
+        self.scheduler_stream.synchronize()
+        self.input_queue.put((model_worker_batch, self.future_token_ids_ct))
+        bs = len(model_worker_batch.seq_lens)
+        future_next_token_ids = torch.arange(-(self.future_token_ids_ct + 1),
+                                             -(self.future_token_ids_ct + 1 + bs), -1,
+                                             dtype=torch.int64, device=self.device)
+        self.future_token_ids_ct = (self.future_token_ids_ct + bs) % self.future_token_ids_limit
+        return None, future_next_token_ids
+
+    def close(self):
+        self.input_queue.put((None, None))
+        self.forward_thread.join(timeout=30)

@@ -120,3 +120,49 @@ def test_out_of_memory_is_reported_like_the_reference():
                          mr.token_to_kv_pool_allocator, mr.device)
     with pytest.raises(RuntimeError, match="max-running-requests"):
         many.prepare_for_extend()
+
+
+def test_overlap_worker_matches_synchronous_worker():
+    """Forward thread + future-token placeholders (tp_worker_client.py) produce the same greedy
+    tokens as the synchronous worker, while results arrive one step late."""
+    from scratchpad_amd.model_runner import TpModelWorker
+    from scratchpad_amd.schedule_batch import Req, ScheduleBatch
+    from scratchpad_amd.tp_worker_client import TpModelWorkerClient, resolve_future_token_ids
+    ids = torch.tensor([5, -2, 7, -1], device="cuda")
+    fmap = torch.tensor([0, 11, 22, 33], device="cuda")
+    resolve_future_token_ids(ids, fmap)
+    assert ids.tolist() == [5, 22, 7, 11]
+
+    g, pfx, shape, w = smoke_impl.load_case("a")
+    gen = torch.Generator().manual_seed(3)
+    prompts = [torch.randint(0, shape.vocab, (n,), generator=gen).tolist() for n in (6, 9, 4)]
+
+    def run(overlap):
+        mr = smoke_impl.make_runner(shape, w, torch.float32)
+        worker = TpModelWorkerClient(mr) if overlap else TpModelWorker(mr)
+        sb = ScheduleBatch([Req(str(i), list(p)) for i, p in enumerate(prompts)], mr.req_to_token_pool,
+                           mr.token_to_kv_pool_allocator, mr.device)
+        sb.prepare_for_extend()
+        tokens = []
+        _, nxt = worker.forward_batch_generation(sb.get_model_worker_batch())
+        for step in range(5):
+            if overlap:
+                assert bool((nxt < 0).all()), "placeholders until the forward thread resolves them"
+            sb.output_ids = nxt
+            sb.prepare_for_decode()
+            _, nxt_new = worker.forward_batch_generation(sb.get_model_worker_batch())
+            if overlap:      # the result of the PREVIOUS launch becomes available now
+                _, real = worker.resolve_last_batch_result()
+                tokens.append(real)
+            else:
+                tokens.append(nxt.tolist())
+            nxt = nxt_new
+        if overlap:
+            _, real = worker.resolve_last_batch_result()
+            tokens.append(real)
+            worker.close()
+        else:
+            tokens.append(nxt.tolist())
+        return tokens
+
+    assert run(True) == run(False)
