@@ -155,15 +155,25 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   const int64_t tok_bytes = a.kv_stride * 2;
   const int64_t head_off = (int64_t)hk * D * 2 + st_ch * 16;
   u32x4 kreg[PASSES], vreg[PASSES];
-  auto prefetch = [&](int tile) {
+  // slot indices run one tile ahead of the row gathers: the dependent req_to_token -> row chain is
+  // then never waited for inside the loop (the wave is in-order: a wait on a fresh index load at
+  // the top of an iteration stalled the whole tile's compute behind an L2/HBM round trip)
+  int slot_next[PASSES];
+  auto fetch_slots = [&](int tile) {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int key = tile * BN + p * RPP + st_row;
-      const int slot = key < kv_len ? idx_row[key] : 0;   // rows past the end read the dummy slot 0
-      const int64_t off = (int64_t)slot * tok_bytes + head_off;
+      slot_next[p] = key < kv_len ? idx_row[key] : 0;   // rows past the end read the dummy slot 0
+    }
+  };
+  auto prefetch = [&](int tile) {   // gathers of `tile` from slot_next, then the indices of tile+1
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int64_t off = (int64_t)slot_next[p] * tok_bytes + head_off;
       kreg[p] = ld16(a.kbuf + off);
       vreg[p] = ld16(a.vbuf + off);
     }
+    fetch_slots(tile + 1);
   };
   auto stage = [&](int buf) {
     char* dK = lds + buf * C::kTileBytes;
@@ -183,6 +193,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   // pipeline: tile t+1's global gathers fly during compute(t); they are written to the OTHER LDS
   // buffer right after compute(t), and one barrier per tile both publishes tile t+1 and retires
   // every wave's reads of tile t (whose buffer is overwritten only in iteration t+1)
+  fetch_slots(0);
   prefetch(0);
   stage(0);
   __syncthreads();
