@@ -81,6 +81,15 @@ __device__ __forceinline__ uint32_t pack2<f16_tag>(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, b);
 }
 
+// value held by lane ^ 32, by one v_permlane32_swap (VALU) instead of a ds_bpermute round trip:
+// the swap exchanges lanes 32-63 of its first operand with lanes 0-31 of its second
+__device__ __forceinline__ float xchg32(float x) {
+  const uint32_t u = as_u32(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const uint32_t upper_gets = r[0], lower_gets = r[1];
+  return as_f32((threadIdx.x & 32) ? upper_gets : lower_gets);
+}
+
 template <int D>
 struct ExtCfg {
   static constexpr int BN = 64;                    // keys per tile
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
             mx = fmaxf(mx, x);
           }
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = fmaxf(mx, xchg32(mx));
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
           s[kb][r] = p;
           psum += p;
         }
-      psum += __shfl_xor(psum, 32, 64);
+      psum += xchg32(psum);
       l_run = l_run * alpha + psum;
       if (!__all(alpha == 1.0f)) {  // the row maxima settle after the first tiles: usually skipped
 #pragma unroll
