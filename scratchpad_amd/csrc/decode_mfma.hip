@@ -76,6 +76,22 @@ __device__ __forceinline__ uint32_t pack2m<f16_tag>(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, b);
 }
 
+// values held by lane ^ 16 / lane ^ 32 through the gfx950 half-row / half-wave swaps (VALU) instead
+// of ds_bpermute round trips: v_permlane16_swap exchanges the odd 16-lane rows of its first operand
+// with the even rows of its second, v_permlane32_swap lanes 32-63 of the first with 0-31 of the second
+__device__ __forceinline__ float xchg16m(float x) {
+  const uint32_t u = as_u32(x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const uint32_t odd_gets = r[0], even_gets = r[1];
+  return as_f32((threadIdx.x & 16) ? odd_gets : even_gets);
+}
+__device__ __forceinline__ float xchg32m(float x) {
+  const uint32_t u = as_u32(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const uint32_t upper_gets = r[0], lower_gets = r[1];
+  return as_f32((threadIdx.x & 32) ? upper_gets : lower_gets);
+}
+
 template <int D>
 struct DmCfg {
   static constexpr int TK = 16;                    // keys per tile
@@ -213,8 +229,8 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
         x[j] = (tile * TK + 4 * kq + j < n) ? v : -INFINITY;
         mx = fmaxf(mx, x[j]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = fmaxf(mx, xchg16m(mx));
+      mx = fmaxf(mx, xchg32m(mx));
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
@@ -224,8 +240,8 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
         x[j] = __builtin_amdgcn_exp2f(x[j] - m_new);
         psum += x[j];
       }
-      psum += __shfl_xor(psum, 16, 64);
-      psum += __shfl_xor(psum, 32, 64);
+      psum += xchg16m(psum);
+      psum += xchg32m(psum);
       l_run = l_run * alpha + psum;
       u32x2 pf;  // B operand of O^T += V^T.P^T: P^T[k = 4kq + j][col]
       pf[0] = pack2m<Tag>(x[0], x[1]);
