@@ -4,8 +4,10 @@ Mirrors the slot/table bookkeeping of scheduler/schedule_batch.py: ``prepare_for
 (901-1071: request rows, cached-prefix copy, slot allocation, req_to_token scatter by the HIP twin
 of write_req_to_token_pool_triton), ``prepare_for_decode`` (1230-1308: seq_lens += 1, alloc(bs),
 req_to_token[req, seq_len-1] = slot), ``mix_with_running`` (1073-1101) and
-``get_model_worker_batch`` (1399-1459).  Policy, radix cache, retraction, sampling params,
-grammars and multimodal bookkeeping stay with the reference's scheduler (out of scope).
+``get_model_worker_batch`` (1399-1459), the prefix-cache hand-off (``Req.init_next_round_input``
+472-492, ``alloc_token_slots`` 727-754 evicting through ``tree_cache``), ``check_decode_mem`` /
+``retract_decode`` (1103-1211) and ``filter_batch`` / ``merge_batch`` (1309-1397).  Admission
+policy, grammars, penalizers and detokenisation stay with the reference's scheduler (out of scope).
 """
 from dataclasses import dataclass, field
 from typing import List, Optional
@@ -15,6 +17,7 @@ import torch
 from . import _native
 from .forward_info import CaptureHiddenMode, ForwardMode, ModelWorkerBatch
 from .pool import ReqToTokenPool, TokenToKVPoolAllocator
+from .radix_cache import BasePrefixCache, ChunkCache
 
 _bid = 0
 
@@ -27,13 +30,44 @@ class Req:
     output_ids: List[int] = field(default_factory=list)
     prefix_indices: Optional[torch.Tensor] = None   # cached KV slots (radix-cache hit), int
     req_pool_idx: Optional[int] = None
+    last_node: object = None                         # prefix-cache node the request holds a lock on
+    fill_ids_override: Optional[List[int]] = None    # chunked prefill: the tokens of this round
+    finished_reason: object = None
+    sampling_params: object = None                   # sampler.SamplingParams (None = greedy)
+    is_retracted: bool = False
     # encoder-decoder models: the first num_image_tokens ids of origin_input_ids are the image pad
     # ids (mllama.py pad_input_ids 803-816; MultimodalInputs.num_image_tokens)
     num_image_tokens: Optional[int] = None
 
     @property
     def fill_ids(self) -> List[int]:
+        if self.fill_ids_override is not None:
+            return self.fill_ids_override
         return self.origin_input_ids + self.output_ids
+
+    @fill_ids.setter
+    def fill_ids(self, ids: Optional[List[int]]):
+        self.fill_ids_override = ids
+
+    def finished(self) -> bool:
+        return self.finished_reason is not None
+
+    def init_next_round_input(self, tree_cache: Optional[BasePrefixCache] = None):
+        """schedule_batch.py:472-510: look the prompt up in the prefix cache; at least one token
+        is always left to compute so the step produces logits."""
+        self.fill_ids_override = None
+        ids = self.origin_input_ids + self.output_ids
+        if tree_cache is not None:
+            self.prefix_indices, self.last_node = tree_cache.match_prefix(
+                rid=self.rid, key=ids[:max(len(ids) - 1, 0)])
+
+    def reset_for_retract(self):
+        """schedule_batch.py:573-584"""
+        self.prefix_indices = None
+        self.last_node = None
+        self.fill_ids_override = None
+        self.req_pool_idx = None
+        self.is_retracted = True
 
     @property
     def extend_input_len(self) -> int:
@@ -47,8 +81,9 @@ class Req:
 class ScheduleBatch:
     def __init__(self, reqs: List[Req], req_to_token_pool: ReqToTokenPool,
                  token_to_kv_pool_allocator: TokenToKVPoolAllocator, device: str,
-                 is_encoder_decoder: bool = False):
+                 is_encoder_decoder: bool = False, tree_cache: Optional[BasePrefixCache] = None):
         self.is_encoder_decoder = is_encoder_decoder
+        self.tree_cache = tree_cache
         self.encoder_cached = self.encoder_lens = self.encoder_lens_cpu = None
         self.encoder_out_cache_loc = None
         self.reqs = reqs
@@ -73,11 +108,14 @@ class ScheduleBatch:
         return idx
 
     def alloc_token_slots(self, num_tokens: int):
+        if self.tree_cache is not None and self.token_to_kv_pool_allocator.available_size() < num_tokens:
+            self.tree_cache.evict(num_tokens)
         out = self.token_to_kv_pool_allocator.alloc(num_tokens)
         if out is None:
+            evictable = 0 if self.tree_cache is None else self.tree_cache.evictable_size()
             raise RuntimeError(f"Out of memory. Try to lower your batch size.\n"
                                f"Try to allocate {num_tokens} tokens.\n"
-                               f"Avaliable tokens: {self.token_to_kv_pool_allocator.available_size()}\n")
+                               f"Avaliable tokens: {self.token_to_kv_pool_allocator.available_size() + evictable}\n")
         return out
 
     def prepare_for_extend(self):
@@ -193,6 +231,81 @@ class ScheduleBatch:
         self.seq_lens_sum += bs
         self.out_cache_loc = self.alloc_token_slots(bs)
         self.req_to_token_pool.write((self.req_pool_indices, locs), self.out_cache_loc.to(torch.int32))
+
+    def check_decode_mem(self, buf_multiplier: int = 1) -> bool:
+        """schedule_batch.py:1109-1121: one new slot per running request, evicting if needed."""
+        need = len(self.reqs) * buf_multiplier
+        if self.token_to_kv_pool_allocator.available_size() >= need:
+            return True
+        if self.tree_cache is not None:
+            self.tree_cache.evict(need)
+        return self.token_to_kv_pool_allocator.available_size() >= need
+
+    def retract_decode(self, retract_decode_steps: int = 20):
+        """schedule_batch.py:1123-1211: give back the slots of the requests with the fewest output
+        tokens (ties: longest prompt) until the rest can run ``retract_decode_steps`` more steps."""
+        order = sorted(range(len(self.reqs)),
+                       key=lambda i: (len(self.reqs[i].output_ids), -len(self.reqs[i].origin_input_ids)),
+                       reverse=True)
+        seq_lens_cpu = self.seq_lens.cpu().tolist()
+        retracted = []
+        first = True
+        while first or self.token_to_kv_pool_allocator.available_size() < len(order) * retract_decode_steps:
+            if len(order) == 1:
+                assert self.token_to_kv_pool_allocator.available_size() > 0, "No space left for only one request"
+                break
+            first = False
+            idx = order.pop()
+            req = self.reqs[idx]
+            retracted.append(req)
+            row = self.req_to_token_pool.req_to_token[req.req_pool_idx]
+            if self.tree_cache is None or isinstance(self.tree_cache, ChunkCache):
+                self.token_to_kv_pool_allocator.free(row[:seq_lens_cpu[idx]].to(torch.int64))
+                self.req_to_token_pool.free(req.req_pool_idx)
+            else:
+                # the cached prefix stays with the tree; only this request's own slots go back
+                self.token_to_kv_pool_allocator.free(row[req.prefix_len:seq_lens_cpu[idx]].to(torch.int64))
+                self.req_to_token_pool.free(req.req_pool_idx)
+                self.tree_cache.dec_lock_ref(req.last_node)
+                residual = len(order) * retract_decode_steps - self.token_to_kv_pool_allocator.available_size()
+                self.tree_cache.evict(max(0, residual))
+            req.reset_for_retract()
+        self.filter_batch(keep_indices=order)
+        return retracted
+
+    def filter_batch(self, keep_indices: Optional[List[int]] = None):
+        """schedule_batch.py:1309-1359"""
+        if keep_indices is None:
+            keep_indices = [i for i, r in enumerate(self.reqs) if not r.finished()]
+        if len(keep_indices) == 0:
+            self.reqs = []
+            return
+        if len(keep_indices) == len(self.reqs):
+            return
+        keep = torch.tensor(keep_indices, dtype=torch.int64).to(self.device, non_blocking=True)
+        if self.is_encoder_decoder:
+            self.encoder_lens = self.encoder_lens[keep]
+            self.encoder_lens_cpu = [self.encoder_lens_cpu[i] for i in keep_indices]
+        self.reqs = [self.reqs[i] for i in keep_indices]
+        self.req_pool_indices = self.req_pool_indices[keep]
+        self.seq_lens = self.seq_lens[keep]
+        self.out_cache_loc = None
+        self.seq_lens_sum = int(self.seq_lens.sum().item())
+        if self.output_ids is not None:
+            self.output_ids = self.output_ids[keep]
+
+    def merge_batch(self, other: "ScheduleBatch"):
+        """schedule_batch.py:1361-1397"""
+        if self.is_encoder_decoder:
+            self.encoder_lens = torch.cat([self.encoder_lens, other.encoder_lens])
+            self.encoder_lens_cpu.extend(other.encoder_lens_cpu)
+        self.req_pool_indices = torch.cat([self.req_pool_indices, other.req_pool_indices])
+        self.seq_lens = torch.cat([self.seq_lens, other.seq_lens])
+        self.out_cache_loc = None
+        self.seq_lens_sum += other.seq_lens_sum
+        if self.output_ids is not None:
+            self.output_ids = torch.cat([self.output_ids, other.output_ids])
+        self.reqs.extend(other.reqs)
 
     def get_model_worker_batch(self) -> ModelWorkerBatch:
         global _bid

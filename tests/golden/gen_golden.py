@@ -648,10 +648,154 @@ def gen_tiny_mllama():
     _save("tiny_mllama", **out)
 
 
+def gen_radix_cache():
+    """Seeded op trace through the reference's RadixCache (memory/radix_cache.py) with its own
+    ReqToTokenPool / TokenToKVPoolAllocator on CPU; time.time() is replaced by a counter so the
+    LRU order is a function of the op sequence only.  Stored as JSON: ops with inputs + outputs."""
+    import json
+    import random
+    import time as _time
+    from types import SimpleNamespace
+    from scratchpad.memory.pool import ReqToTokenPool, TokenToKVPoolAllocator
+    import scratchpad.memory.radix_cache as rc
+
+    tick = [0.0]
+
+    def fake_time():
+        tick[0] += 1.0
+        return tick[0]
+
+    real_time = _time.time
+    rc.time.time = fake_time
+    try:
+        rnd = random.Random(1234)
+        pool_size, ctx = 400, 64
+        r2t = ReqToTokenPool(16, ctx, "cpu", False)
+        alloc = TokenToKVPoolAllocator(pool_size, torch.float32, "cpu", None)
+        cache = rc.RadixCache(r2t, alloc, page_size=1)
+        ops = []
+        # a small alphabet and shared stems make deep splits likely
+        stems = [[rnd.randrange(6) for _ in range(rnd.randrange(3, 14))] for _ in range(5)]
+
+        def rand_key():
+            k = list(rnd.choice(stems))[: rnd.randrange(1, 14)]
+            k += [rnd.randrange(6) for _ in range(rnd.randrange(0, 12))]
+            return k
+
+        def snap():
+            return {"evictable": cache.evictable_size(), "protected": cache.protected_size(),
+                    "total": cache.total_size(), "available": alloc.available_size(),
+                    "values_sorted": sorted(int(x) for x in cache.all_values_flatten().tolist())
+                    if cache.total_size() else []}
+
+        live = {}      # rid -> SimpleNamespace request holding locks
+        next_rid = [0]
+        for step in range(260):
+            kind = rnd.choices(["insert", "match", "req_begin", "req_chunk", "req_finish", "evict"],
+                               weights=[2, 3, 4, 2, 4, 2])[0]
+            if kind == "insert":
+                key = rand_key()
+                slots = alloc.alloc(len(key))
+                if slots is None:
+                    continue
+                n = cache.insert(key, slots.clone())
+                alloc.free(slots[:n])
+                ops.append({"op": "insert", "key": key, "slots": slots.tolist(), "ret": int(n), "after": snap()})
+            elif kind == "match":
+                key = rand_key()
+                val, node = cache.match_prefix(key)
+                ops.append({"op": "match", "key": key, "value": [int(x) for x in val.tolist()],
+                            "node_key": list(node.key), "after": snap()})
+            elif kind == "req_begin":
+                if r2t.available_size() == 0:
+                    continue
+                ids = rand_key() + [rnd.randrange(6)]
+                req = SimpleNamespace(rid=f"r{next_rid[0]}", origin_input_ids=ids, output_ids=[],
+                                      fill_ids=None, prefix_indices=[], last_node=None, req_pool_idx=None)
+                next_rid[0] += 1
+                # Req.init_next_round_input (schedule_batch.py:472-492) with max prefix = len - 1
+                chunk = rnd.randrange(1, len(ids) + 1)
+                req.fill_ids = ids[:chunk] if chunk < len(ids) else list(ids)
+                prefix, node = cache.match_prefix(req.fill_ids[: max(len(req.fill_ids) - 1, 0)])
+                need = len(req.fill_ids) - len(prefix)
+                if alloc.available_size() < need:
+                    cache.evict(need)
+                if alloc.available_size() < need:
+                    continue
+                req.prefix_indices, req.last_node = prefix, node
+                cache.inc_lock_ref(node)
+                req.req_pool_idx = r2t.alloc(1)[0]
+                new = alloc.alloc(need)
+                r2t.write((req.req_pool_idx, slice(0, len(prefix))), prefix.to(torch.int32))
+                r2t.write((req.req_pool_idx, slice(len(prefix), len(req.fill_ids))), new.to(torch.int32))
+                live[req.rid] = req
+                ops.append({"op": "req_begin", "rid": req.rid, "ids": ids, "fill_len": len(req.fill_ids),
+                            "prefix": [int(x) for x in prefix.tolist()], "new_slots": new.tolist(),
+                            "req_pool_idx": int(req.req_pool_idx), "after": snap()})
+            elif kind == "req_chunk":
+                cands = [r for r in live.values() if len(r.fill_ids) < len(r.origin_input_ids)]
+                if not cands:
+                    continue
+                req = rnd.choice(cands)
+                cache.cache_unfinished_req(req)
+                pre = [int(x) for x in req.prefix_indices.tolist()]
+                # next chunk: extend fill_ids, allocate the new part
+                grow = rnd.randrange(1, len(req.origin_input_ids) - len(req.fill_ids) + 1)
+                old = len(req.fill_ids)
+                if alloc.available_size() < grow:
+                    cache.evict(grow)
+                if alloc.available_size() < grow:
+                    ops.append({"op": "req_chunk", "rid": req.rid, "prefix_after": pre, "grow": 0,
+                                "new_slots": [], "row": r2t.req_to_token[req.req_pool_idx, :old].tolist(),
+                                "after": snap()})
+                    continue
+                req.fill_ids = req.origin_input_ids[: old + grow]
+                new = alloc.alloc(grow)
+                r2t.write((req.req_pool_idx, slice(old, old + grow)), new.to(torch.int32))
+                ops.append({"op": "req_chunk", "rid": req.rid, "prefix_after": pre, "grow": grow,
+                            "new_slots": new.tolist(),
+                            "row": r2t.req_to_token[req.req_pool_idx, : old + grow].tolist(), "after": snap()})
+            elif kind == "req_finish":
+                cands = [r for r in live.values() if len(r.fill_ids) == len(r.origin_input_ids)]
+                if not cands:
+                    continue
+                req = rnd.choice(cands)
+                n_out = rnd.randrange(1, 5)
+                if alloc.available_size() < n_out:
+                    cache.evict(n_out)
+                if alloc.available_size() < n_out:
+                    continue
+                # decode steps: every output token but the last has its KV written
+                outs = [rnd.randrange(6) for _ in range(n_out)]
+                base = len(req.origin_input_ids)
+                dec = alloc.alloc(n_out - 1) if n_out > 1 else torch.empty(0, dtype=torch.int64)
+                if n_out > 1:
+                    r2t.write((req.req_pool_idx, slice(base, base + n_out - 1)), dec.to(torch.int32))
+                req.output_ids = outs
+                cache.cache_finished_req(req)
+                del live[req.rid]
+                ops.append({"op": "req_finish", "rid": req.rid, "output_ids": outs,
+                            "decode_slots": dec.tolist(), "after": snap()})
+            else:
+                n = rnd.randrange(1, 40)
+                cache.evict(n)
+                ops.append({"op": "evict", "n": n, "free_slots": alloc.free_slots.tolist(), "after": snap()})
+        path = os.path.join(HERE, "radix_cache.json")
+        with open(path, "w") as f:
+            json.dump({"pool_size": pool_size, "context_len": ctx, "max_reqs": 16, "ops": ops}, f,
+                      separators=(",", ":"))
+        kinds = {}
+        for o in ops:
+            kinds[o["op"]] = kinds.get(o["op"], 0) + 1
+        print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB, {len(ops)} ops {kinds}")
+    finally:
+        rc.time.time = real_time
+
+
 GENERATORS = {
     "rmsnorm": gen_rmsnorm, "silu_mul": gen_silu_mul, "rotary": gen_rotary, "kv_pool": gen_kv_pool,
     "positions": gen_positions, "decode_attention": gen_decode, "extend_attention": gen_extend,
-    "tiny_llama": gen_tiny_llama, "tiny_mllama": gen_tiny_mllama,
+    "tiny_llama": gen_tiny_llama, "tiny_mllama": gen_tiny_mllama, "radix_cache": gen_radix_cache,
 }
 
 if __name__ == "__main__":

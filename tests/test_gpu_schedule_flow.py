@@ -166,3 +166,117 @@ def test_overlap_worker_matches_synchronous_worker():
         return tokens
 
     assert run(True) == run(False)
+
+
+def _fresh_prefill_logits(shape, w, prompt):
+    """Oracle logits of an uncached, unchunked prefill of `prompt` (its own empty pool)."""
+    okv = ollama.OracleKV(shape, 96, 4, 64)
+    n = len(prompt)
+    loc = torch.arange(1, n + 1)
+    okv.req_to_token[0, :n] = loc.to(torch.int32)
+    return oracle_step(shape, w, okv, "extend", torch.tensor(prompt), torch.tensor([0]), torch.tensor([n]), loc,
+                       torch.tensor([0], dtype=torch.int32), torch.tensor([n], dtype=torch.int32))
+
+
+def test_radix_cache_prefix_reuse_chunked_prefill_and_retraction():
+    """RadixCache as the producer of prefix_indices: a finished request's KV is reused by a later
+    prompt, a chunked prefill continues on the tree's slots, and retraction hands slots back.
+    Logits must equal an uncached prefill of the same prompt (the cache may only change WHERE the KV
+    lives, never its contents)."""
+    from scratchpad_amd.model_runner import TpModelWorker
+    from scratchpad_amd.radix_cache import RadixCache
+    from scratchpad_amd.schedule_batch import Req, ScheduleBatch
+    g, pfx, shape, w = smoke_impl.load_case("a")
+    mr = smoke_impl.make_runner(shape, w, torch.float32)
+    worker = TpModelWorker(mr)
+    alloc, r2t, dev = mr.token_to_kv_pool_allocator, mr.req_to_token_pool, mr.device
+    tree = RadixCache(r2t, alloc)
+    gen = torch.Generator().manual_seed(11)
+    rand = lambda n: torch.randint(0, shape.vocab, (n,), generator=gen).tolist()
+
+    def batch(reqs):
+        return ScheduleBatch(reqs, r2t, alloc, dev, tree_cache=tree)
+
+    # A: plain prefill + 2 decode steps, then finish -> the tree owns prompt + first output token
+    a = Req("a", rand(12))
+    a.init_next_round_input(tree)
+    assert a.prefix_len == 0 and a.last_node is tree.root_node
+    tree.inc_lock_ref(a.last_node)
+    sa = batch([a])
+    sa.prepare_for_extend()
+    out, nxt = worker.forward_batch_generation(sa.get_model_worker_batch())
+    close(out.next_token_logits, _fresh_prefill_logits(shape, w, a.origin_input_ids), "A prefill")
+    for _ in range(2):
+        a.output_ids.append(int(nxt[0]))
+        sa.output_ids = nxt
+        sa.prepare_for_decode()
+        out, nxt = worker.forward_batch_generation(sa.get_model_worker_batch())
+    a.output_ids.append(int(nxt[0]))
+    tree.cache_finished_req(a)
+    assert tree.total_size() == 12 + 2 and tree.evictable_size() == 14 and tree.protected_size() == 0
+    assert alloc.available_size() + tree.total_size() == 96 and r2t.available_size() == 4
+
+    # B shares A's first 8 prompt tokens; C repeats A's prompt + its first output (full hit - 1)
+    b = Req("b", a.origin_input_ids[:8] + rand(5))
+    c = Req("c", a.origin_input_ids + a.output_ids[:1])
+    for r in (b, c):
+        r.init_next_round_input(tree)
+        tree.inc_lock_ref(r.last_node)
+    assert b.prefix_len == 8 and c.prefix_len == 12
+    a_slots = tree.match_prefix(a.origin_input_ids)[0]
+    assert torch.equal(b.prefix_indices, a_slots[:8]) and torch.equal(c.prefix_indices, a_slots)
+    sb = batch([b, c])
+    sb.prepare_for_extend()
+    assert sb.prefix_lens == [8, 12] and sb.extend_lens == [5, 1]
+    out, _ = worker.forward_batch_generation(sb.get_model_worker_batch())
+    close(out.next_token_logits[0:1], _fresh_prefill_logits(shape, w, b.origin_input_ids), "B on cached prefix")
+    close(out.next_token_logits[1:2], _fresh_prefill_logits(shape, w, c.origin_input_ids), "C on cached prefix")
+    assert tree.protected_size() == 12     # the shared path is pinned while B and C run
+
+    # retraction: equal output counts and prompt lengths -> the later request (C) is retracted first
+    sb.output_ids = out.next_token_logits.argmax(-1)
+    before = alloc.available_size()
+    retracted = sb.retract_decode(retract_decode_steps=1)
+    assert [r.rid for r in retracted] == ["c"] and [r.rid for r in sb.reqs] == ["b"]
+    assert c.req_pool_idx is None and c.prefix_indices is None and c.is_retracted
+    assert alloc.available_size() == before + 1      # C's single own slot; its prefix stays cached
+    assert sb.seq_lens.tolist() == [13] and sb.check_decode_mem()
+
+    # D: chunked prefill (7 + 9 tokens) through cache_unfinished_req, sharing B's prompt head
+    b.output_ids = [int(sb.output_ids[0])]
+    tree.cache_finished_req(b)
+    d_ids = b.origin_input_ids[:10] + rand(6)
+    d = Req("d", d_ids)
+    d.init_next_round_input(tree)
+    assert d.prefix_len == 10
+    tree.inc_lock_ref(d.last_node)
+    d.fill_ids = d_ids[:12]
+    sd = batch([d])
+    sd.prepare_for_extend()
+    assert sd.prefix_lens == [10] and sd.extend_lens == [2]
+    worker.forward_batch_generation(sd.get_model_worker_batch())
+    tree.cache_unfinished_req(d)
+    assert d.prefix_len == 12 and tree.match_prefix(d_ids[:12])[0].tolist() == d.prefix_indices.tolist()
+    d.fill_ids = None
+    r2t.free(d.req_pool_idx)       # the scheduler re-allocates the row for the next chunk
+    sd = batch([d])
+    sd.prepare_for_extend()
+    assert sd.prefix_lens == [12] and sd.extend_lens == [4]
+    out, _ = worker.forward_batch_generation(sd.get_model_worker_batch())
+    close(out.next_token_logits, _fresh_prefill_logits(shape, w, d_ids), "D chunked on cached prefix")
+
+    # eviction under pressure: a prompt that needs more than the free slots evicts unlocked leaves
+    d.output_ids = [1]
+    tree.cache_finished_req(d)
+    cached_before = tree.total_size()
+    hog = alloc.alloc(alloc.available_size() - 20)      # leave 20 free slots for a 30-token prompt
+    e = Req("e", rand(30))
+    e.init_next_round_input(tree)
+    tree.inc_lock_ref(e.last_node)
+    se = batch([e])
+    se.prepare_for_extend()
+    assert tree.total_size() < cached_before, "alloc_token_slots evicted through the tree"
+    out, _ = worker.forward_batch_generation(se.get_model_worker_batch())
+    close(out.next_token_logits, _fresh_prefill_logits(shape, w, e.origin_input_ids), "E after eviction")
+    # conservation: every slot is either free, cached, or held by the running request
+    assert alloc.available_size() + tree.total_size() + e.extend_input_len + len(hog) == 96
