@@ -153,6 +153,32 @@ SP_API int sp_extend_attention(void* out, const void* q, const void* k_buffer, c
                         float logit_cap, int causal, int max_extend_len, int64_t max_seq_len,
                         void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
+/* ---- Sampler.  Replaces nn/layers/sampler.py:63-75 (torch.argmax; logits.div_(T) + softmax),
+ *      sampler.py:195-232 (top_k_top_p_min_p_sampling_from_probs_torch, top_p_normalize_probs_torch)
+ *      and the flashinfer calls wrapped by nn/kernels/sampling.py:19-373 (top_k_renorm_probs,
+ *      top_p_renorm_probs, top_k_top_p_sampling_from_probs "joint", min_p_sampling_from_probs).
+ * Rows are [batch_size, vocab] with row_stride elements between rows; probabilities are fp32.
+ * Filter (one definition for sampling and renormalising): rank tokens by (p descending, token id
+ * ascending); a token is kept iff rank < top_k, the mass ranked above it is <= top_p, and
+ * p >= p_max * min_p.  Mass is accumulated exactly as integers floor(p * 2^48), so the result
+ * is independent of summation order.  NULL top_ks / top_ps / min_ps disable that filter.
+ * sp_top_k_top_p_min_p_sample draws, per row, the token whose interval of the kept cumulative
+ * mass (token-id order) contains floor(uniform * kept_mass); uniform[b] in [0,1) is supplied by
+ * the caller (sampler.py:87-90 draws them with torch.rand).  keep_count (nullable) receives the
+ * number of kept tokens per row.  A row with no mass yields token 0.
+ * sp_argmax returns the first maximal index (torch.argmax).                                       */
+SP_API int sp_argmax(const void* logits, int64_t row_stride, int batch_size, int vocab, int64_t* out_ids,
+              int dtype, void* stream);
+SP_API int sp_softmax_temperature(float* logits_inout, int64_t row_stride, const float* temperatures,
+                           int batch_size, int vocab, void* stream);
+SP_API int sp_top_k_top_p_min_p_sample(const float* probs, int64_t row_stride, const int32_t* top_ks,
+                                const float* top_ps, const float* min_ps, const float* uniform,
+                                int batch_size, int vocab, int64_t* out_ids, int32_t* keep_count,
+                                void* stream);
+SP_API int sp_top_k_top_p_min_p_renorm(const float* probs, int64_t row_stride, const int32_t* top_ks,
+                                const float* top_ps, const float* min_ps, int batch_size, int vocab,
+                                float* out, int64_t out_stride, int32_t* keep_count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

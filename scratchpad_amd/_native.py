@@ -44,6 +44,10 @@ SIGNATURES = {
     "sp_extend_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp,
                                    _i32, _i64, _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32,
                                    _i32, _i32, _i64, _vp, _sz, _i32, _vp]),
+    "sp_argmax": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp]),
+    "sp_softmax_temperature": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp]),
+    "sp_top_k_top_p_min_p_sample": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "sp_top_k_top_p_min_p_renorm": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
 }
 
 
@@ -321,3 +325,78 @@ def extend_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
         seq.shape[0], T, Hq, k_buffer.shape[1], D, q.stride(0), out.stride(0), k_buffer.stride(0),
         sm_scale, logit_cap, int(causal), max_extend_len, max_seq_len, workspace.data_ptr(),
         workspace.numel() * workspace.element_size(), _dt(q), _stream()), "sp_extend_attention")
+
+
+# --------------------------------------------------------------------------- sampler
+def _prob_rows(t: torch.Tensor, what: str) -> torch.Tensor:
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError(f"{what}: expected [batch, vocab] with a contiguous vocab dimension")
+    return t
+
+
+def _opt(t: Optional[torch.Tensor], dtype: torch.dtype, bs: int, what: str):
+    if t is None:
+        return None
+    t = t.reshape(-1)
+    if t.shape[0] != bs:
+        raise RuntimeError(f"{what}: expected {bs} entries, got {t.shape[0]}")
+    return t.to(dtype).contiguous()
+
+
+def argmax(logits: torch.Tensor) -> torch.Tensor:
+    """First maximal index per row -> int64 [bs]."""
+    _gpu(logits)
+    logits = _prob_rows(logits, "argmax")
+    out = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
+    _check(load().sp_argmax(logits.data_ptr(), logits.stride(0), logits.shape[0], logits.shape[1],
+                            out.data_ptr(), _dt(logits), _stream()), "sp_argmax")
+    return out
+
+
+def softmax_temperature_(logits: torch.Tensor, temperatures: Optional[torch.Tensor]) -> torch.Tensor:
+    """In place: logits <- softmax(logits / T) (fp32 rows)."""
+    _gpu(logits, temperatures)
+    logits = _prob_rows(logits, "softmax_temperature_")
+    if logits.dtype != torch.float32:
+        raise RuntimeError("softmax_temperature_: fp32 logits expected (LogitsProcessor returns fp32)")
+    temps = _opt(temperatures, torch.float32, logits.shape[0], "temperatures")
+    _check(load().sp_softmax_temperature(logits.data_ptr(), logits.stride(0), _ptr(temps), logits.shape[0],
+                                         logits.shape[1], _stream()), "sp_softmax_temperature")
+    return logits
+
+
+def top_k_top_p_min_p_sample(probs: torch.Tensor, top_ks: Optional[torch.Tensor],
+                             top_ps: Optional[torch.Tensor], min_ps: Optional[torch.Tensor],
+                             uniform: torch.Tensor, return_keep_count: bool = False):
+    _gpu(probs, top_ks, top_ps, min_ps, uniform)
+    probs = _prob_rows(probs, "top_k_top_p_min_p_sample")
+    if probs.dtype != torch.float32:
+        raise RuntimeError("top_k_top_p_min_p_sample: fp32 probabilities expected")
+    bs, vocab = probs.shape
+    ks, ps, ms = (_opt(top_ks, torch.int32, bs, "top_ks"), _opt(top_ps, torch.float32, bs, "top_ps"),
+                  _opt(min_ps, torch.float32, bs, "min_ps"))
+    u = _opt(uniform, torch.float32, bs, "uniform")
+    out = torch.empty(bs, dtype=torch.int64, device=probs.device)
+    cnt = torch.empty(bs, dtype=torch.int32, device=probs.device) if return_keep_count else None
+    _check(load().sp_top_k_top_p_min_p_sample(probs.data_ptr(), probs.stride(0), _ptr(ks), _ptr(ps), _ptr(ms),
+                                              u.data_ptr(), bs, vocab, out.data_ptr(), _ptr(cnt), _stream()),
+           "sp_top_k_top_p_min_p_sample")
+    return (out, cnt) if return_keep_count else out
+
+
+def top_k_top_p_min_p_renorm(probs: torch.Tensor, top_ks: Optional[torch.Tensor] = None,
+                             top_ps: Optional[torch.Tensor] = None, min_ps: Optional[torch.Tensor] = None,
+                             return_keep_count: bool = False):
+    _gpu(probs, top_ks, top_ps, min_ps)
+    probs = _prob_rows(probs, "top_k_top_p_min_p_renorm")
+    if probs.dtype != torch.float32:
+        raise RuntimeError("top_k_top_p_min_p_renorm: fp32 probabilities expected")
+    bs, vocab = probs.shape
+    ks, ps, ms = (_opt(top_ks, torch.int32, bs, "top_ks"), _opt(top_ps, torch.float32, bs, "top_ps"),
+                  _opt(min_ps, torch.float32, bs, "min_ps"))
+    out = torch.empty_like(probs, memory_format=torch.contiguous_format)
+    cnt = torch.empty(bs, dtype=torch.int32, device=probs.device) if return_keep_count else None
+    _check(load().sp_top_k_top_p_min_p_renorm(probs.data_ptr(), probs.stride(0), _ptr(ks), _ptr(ps), _ptr(ms),
+                                              bs, vocab, out.data_ptr(), out.stride(0), _ptr(cnt), _stream()),
+           "sp_top_k_top_p_min_p_renorm")
+    return (out, cnt) if return_keep_count else out

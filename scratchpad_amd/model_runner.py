@@ -12,10 +12,12 @@ from typing import Dict, List, Optional
 
 import torch
 
+from . import _native
 from . import distributed as dist_
 from .attention import HipAttnBackend
 from .forward_info import CaptureHiddenMode, ForwardBatch, ForwardMode, ModelWorkerBatch
 from .llama import LlamaForCausalLM, LogitsProcessorOutput
+from .sampler import Sampler
 from .pool import MHATokenToKVPool, ReqToTokenPool, TokenToKVPoolAllocator
 
 
@@ -178,6 +180,7 @@ class ModelRunner:
         if self.server_args.attention_backend != "hip":
             raise ValueError(f"Invalid attention backend: {self.server_args.attention_backend}")
         self.attn_backend = HipAttnBackend(self)
+        self.sampler = Sampler(tp_group=dist_.get_tp_group())
 
     def init_cuda_graphs(self):
         """model_runner.py:490-504."""
@@ -211,8 +214,12 @@ class ModelRunner:
         raise ValueError(f"Invalid forward mode: {forward_batch.forward_mode}")
 
     def sample(self, logits_output: LogitsProcessorOutput, forward_batch: ForwardBatch) -> torch.Tensor:
-        """Greedy path of nn/layers/sampler.py:63-67."""
-        return torch.argmax(logits_output.next_token_logits, dim=-1)
+        """model_runner.py sample -> nn/layers/sampler.py:24-163.  A batch without sampling_info is
+        greedy (sampler.py:63-67)."""
+        info = forward_batch.sampling_info
+        if info is None:
+            return _native.argmax(logits_output.next_token_logits)
+        return self.sampler(logits_output, info)
 
 
 class HipGraphRunner:

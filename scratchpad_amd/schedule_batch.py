@@ -84,6 +84,8 @@ class ScheduleBatch:
                  is_encoder_decoder: bool = False, tree_cache: Optional[BasePrefixCache] = None):
         self.is_encoder_decoder = is_encoder_decoder
         self.tree_cache = tree_cache
+        # None = every request greedy; sampler.SamplingBatchInfo.from_schedule_batch(batch, vocab) otherwise
+        self.sampling_info = None
         self.encoder_cached = self.encoder_lens = self.encoder_lens_cpu = None
         self.encoder_out_cache_loc = None
         self.reqs = reqs
@@ -293,9 +295,13 @@ class ScheduleBatch:
         self.seq_lens_sum = int(self.seq_lens.sum().item())
         if self.output_ids is not None:
             self.output_ids = self.output_ids[keep]
+        if self.sampling_info is not None:
+            self.sampling_info.filter_batch(keep_indices, keep)
 
     def merge_batch(self, other: "ScheduleBatch"):
         """schedule_batch.py:1361-1397"""
+        if self.sampling_info is not None and other.sampling_info is not None:
+            self.sampling_info.merge_batch(other.sampling_info)
         if self.is_encoder_decoder:
             self.encoder_lens = torch.cat([self.encoder_lens, other.encoder_lens])
             self.encoder_lens_cpu.extend(other.encoder_lens_cpu)
@@ -321,4 +327,5 @@ class ScheduleBatch:
             extend_num_tokens=self.extend_num_tokens, extend_seq_lens=extend_seq_lens,
             extend_prefix_lens=extend_prefix_lens, capture_hidden_mode=CaptureHiddenMode.NULL,
             encoder_cached=self.encoder_cached, encoder_lens=self.encoder_lens,
-            encoder_lens_cpu=self.encoder_lens_cpu, encoder_out_cache_loc=self.encoder_out_cache_loc)
+            encoder_lens_cpu=self.encoder_lens_cpu, encoder_out_cache_loc=self.encoder_out_cache_loc,
+            sampling_info=self.sampling_info)

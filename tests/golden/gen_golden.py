@@ -792,10 +792,67 @@ def gen_radix_cache():
         rc.time.time = real_time
 
 
+def gen_sampling():
+    """The reference's torch sampler functions (nn/layers/sampler.py:195-232) on seeded rows.
+    ``torch.multinomial`` is intercepted so the filtered, sorted distribution the reference would
+    sample from is recorded, and the draw is made by inverse CDF with a recorded uniform."""
+    import scratchpad.nn.layers.sampler as ref_sampler
+
+    g = torch.Generator().manual_seed(2718)
+    bs, vocab = 24, 1000
+    scales = torch.tensor([0.5, 1.0, 2.0, 4.0, 8.0, 1.5] * 4).view(-1, 1)
+    logits = torch.randn(bs, vocab, generator=g) * scales
+    temperatures = torch.tensor([1.0, 0.7, 1.3, 0.5] * 6).view(-1, 1)
+    # rows 20..23: heavy exact ties (probabilities on a coarse grid)
+    counts = torch.randint(1, 5, (4, vocab), generator=g).float()
+    probs = torch.softmax(logits / temperatures, dim=-1)
+    probs[20:] = counts / counts.sum(dim=-1, keepdim=True)
+    top_ks = torch.tensor([1 << 30, 1, 5, 50, 200, 1 << 30, 1 << 30, 20, 3, 1 << 30, 7, 100,
+                           1 << 30, 40, 1 << 30, 2, 64, 1 << 30, 10, 1 << 30, 1 << 30, 30, 1 << 30, 500],
+                          dtype=torch.int32)
+    top_ps = torch.tensor([1.0, 1.0, 0.9, 0.5, 0.95, 0.1, 0.8, 1.0, 0.3, 0.99, 1.0, 0.6,
+                           0.7, 0.2, 0.999, 0.9, 1.0, 0.05, 0.85, 0.4, 1.0, 0.5, 0.25, 0.9])
+    min_ps = torch.tensor([0.0, 0.0, 0.0, 0.05, 0.0, 0.0, 0.3, 0.1, 0.0, 0.02, 0.5, 0.0,
+                           0.0, 0.0, 0.2, 0.0, 0.01, 0.0, 0.0, 0.9, 0.0, 0.0, 1.0, 0.0])
+    uniform = torch.rand(bs, generator=g)
+    captured = {}
+    real_multinomial = torch.multinomial
+
+    def recording_multinomial(weights, num_samples=1, **kw):
+        captured["weights"] = weights.clone()
+        cdf = torch.cumsum(weights.double(), dim=-1)
+        target = uniform.double().view(-1, 1) * cdf[:, -1:]
+        return (cdf <= target).sum(dim=-1, keepdim=True).clamp(max=weights.shape[-1] - 1)
+
+    torch.multinomial = recording_multinomial
+    try:
+        out = {}
+        for tag, need_min_p in (("minp", True), ("nominp", False)):
+            ids = ref_sampler.top_k_top_p_min_p_sampling_from_probs_torch(
+                probs.clone(), top_ks, top_ps, min_ps, need_min_p)
+            w = captured["weights"]
+            order = probs.sort(dim=-1, descending=True)[1]
+            keep = torch.zeros(bs, vocab, dtype=torch.bool).scatter_(1, order, w > 0)
+            out[f"{tag}_keep"] = keep
+            out[f"{tag}_keep_count"] = (w > 0).sum(-1)
+            out[f"{tag}_ids"] = ids.to(torch.int64)
+            out[f"{tag}_sorted_weights"] = w
+    finally:
+        torch.multinomial = real_multinomial
+    out["top_p_normalized"] = ref_sampler.top_p_normalize_probs_torch(probs.clone(), top_ps)
+    lp = torch.log_softmax(logits, dim=-1)
+    tv, ti = ref_sampler.get_top_logprobs(lp, [0, 3, 5, 1] * 6)
+    out["top_logprobs_val"] = torch.tensor([v + [0.0] * (5 - len(v)) for v in tv])
+    out["top_logprobs_idx"] = torch.tensor([i + [-1] * (5 - len(i)) for i in ti])
+    _save("sampling", logits=logits, temperatures=temperatures, probs=probs, top_ks=top_ks, top_ps=top_ps,
+          min_ps=min_ps, uniform=uniform, **out)
+
+
 GENERATORS = {
     "rmsnorm": gen_rmsnorm, "silu_mul": gen_silu_mul, "rotary": gen_rotary, "kv_pool": gen_kv_pool,
     "positions": gen_positions, "decode_attention": gen_decode, "extend_attention": gen_extend,
     "tiny_llama": gen_tiny_llama, "tiny_mllama": gen_tiny_mllama, "radix_cache": gen_radix_cache,
+    "sampling": gen_sampling,
 }
 
 if __name__ == "__main__":

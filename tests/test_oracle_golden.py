@@ -186,3 +186,63 @@ def test_tiny_mllama_text_model():
                          row_mask=T(g["row_mask_decode"]), **common)
     close(l2, g["decode_logits"], atol=2e-5, rtol=1e-5)
     close(kv.k[1], g["k_buffer1_after"], atol=1e-5)
+
+
+# ---------------------------------------------------------------- sampler (oracle/sampling.py)
+def test_sampling_reference_layer_matches_reference_run():
+    from oracle import sampling as osamp
+    g = golden.load("sampling")
+    probs = torch.from_numpy(g["probs"])
+    top_ks, top_ps, min_ps = (torch.from_numpy(g[k]) for k in ("top_ks", "top_ps", "min_ps"))
+    sm = osamp.softmax_temperature(torch.from_numpy(g["logits"]), torch.from_numpy(g["temperatures"]))
+    assert torch.equal(sm[:20], probs[:20])          # rows 20.. were overwritten with tied grids
+    for tag, mp in (("minp", min_ps), ("nominp", None)):
+        w, idx = osamp.filter_sorted_reference(probs.clone(), top_ks, top_ps, mp)
+        assert torch.equal(w, torch.from_numpy(g[f"{tag}_sorted_weights"]))
+        assert torch.equal((w > 0).sum(-1), torch.from_numpy(g[f"{tag}_keep_count"]))
+    assert torch.equal(osamp.top_p_normalize_reference(probs.clone(), top_ps),
+                       torch.from_numpy(g["top_p_normalized"]))
+
+
+def test_sampling_integer_definition_agrees_with_reference_filter():
+    """Layer 2 (sort-free, integer mass) keeps the same tokens as the reference's sort + fp32 cumsum;
+    a difference is only tolerated for tokens whose exclusive cumulative mass is within fp32
+    cumsum noise of top_p, and (tied rows) in WHICH of several equal tokens is kept."""
+    from oracle import sampling as osamp
+    g = golden.load("sampling")
+    probs = g["probs"].astype(np.float32)
+    for tag, use_minp in (("minp", True), ("nominp", False)):
+        ref_keep = g[f"{tag}_keep"].astype(bool)
+        for b in range(probs.shape[0]):
+            keep, total = osamp.select(probs[b], int(g["top_ks"][b]), float(g["top_ps"][b]),
+                                       float(g["min_ps"][b]) if use_minp else 0.0)
+            ref = ref_keep[b]
+            if b < 20:
+                if not np.array_equal(keep, ref):
+                    diff = np.flatnonzero(keep != ref)
+                    order = np.argsort(-probs[b].astype(np.float64), kind="stable")
+                    excl = np.concatenate([[0.0], np.cumsum(probs[b][order].astype(np.float64))[:-1]])
+                    pos = {int(t): i for i, t in enumerate(order)}
+                    assert all(abs(excl[pos[int(t)]] - float(g["top_ps"][b])) < 4e-6 for t in diff), (tag, b)
+            else:       # tied rows: same number kept, same multiset of kept probabilities
+                assert keep.sum() == ref.sum(), (tag, b)
+                assert np.array_equal(np.sort(probs[b][keep]), np.sort(probs[b][ref])), (tag, b)
+            assert total == sum(int(x) for x in osamp.fx(probs[b][keep]))
+
+
+def test_sampling_inverse_cdf_covers_the_kept_distribution():
+    """u on a regular grid of N points must hit token i round(N * p_i) times (+-1): the draw is an
+    exact inverse CDF of the renormalised kept distribution, and never returns a dropped token."""
+    from oracle import sampling as osamp
+    g = golden.load("sampling")
+    probs = g["probs"].astype(np.float32)
+    N = 2000
+    for b in (2, 3, 8, 13, 21):
+        k, p, m = int(g["top_ks"][b]), float(g["top_ps"][b]), float(g["min_ps"][b])
+        want = osamp.renorm(probs[b], k, p, m)
+        hits = np.zeros(probs.shape[1], dtype=np.int64)
+        for i in range(N):
+            hits[osamp.sample(probs[b], k, p, m, (i + 0.5) / N)] += 1
+        assert hits[want == 0].sum() == 0
+        assert np.abs(hits - N * want.astype(np.float64)).max() <= 1.0 + 1e-6, b
+        assert abs(float(want.sum()) - 1.0) < 1e-5
