@@ -11,8 +11,10 @@ itself (sp_extend_attention with causal=0 / sp_decode_attention over the encoder
 decoder self-attention behind the encoder slots (kv_start = encoder_lens).  The tanh gates and the
 row mask are the reference's own torch elementwise ops.
 
-The vision tower + projector (mllama.py:181-466, 792-799) are NOT hosted here:
-``forward`` takes the projected, flattened ``cross_attention_states`` as an argument.
+The vision tower lives in mllama_vision.py (its attention runs on the same extend kernel).
+``MllamaForConditionalGeneration.forward`` either receives the projected, flattened
+``cross_attention_states`` or computes them from ``forward_batch.mm_inputs`` exactly where the
+reference does (mllama.py:818-877, 961-976).
 """
 from typing import List, Optional
 
@@ -210,6 +212,59 @@ class MllamaForConditionalGeneration(nn.Module):
         self.language_model = MllamaForCausalLM(text_config, dtype)
         self.logits_processor = LogitsProcessor(text_config)
         self.capture_mode = False
+        vision_config = getattr(config, "vision_config", None)
+        self.vision_model = None
+        if vision_config is not None:
+            from .mllama_vision import MllamaVisionModel
+            self.vision_model = MllamaVisionModel(vision_config, dtype)
+            self.multi_modal_projector = nn.Linear(vision_config.vision_output_dim, text_config.hidden_size,
+                                                   bias=True, dtype=dtype)
+            self.image_size = vision_config.image_size
+            self.max_num_tiles = vision_config.max_num_tiles
+
+    def pad_input_ids(self, input_ids: List[int], mm_inputs) -> List[int]:
+        """mllama.py:803-816: one pad id per vision position, in front of the text ids."""
+        pixel_values = torch.cat([item.pixel_values for item in mm_inputs.mm_items], dim=0)
+        pad_values = [item.pad_value for item in mm_inputs.mm_items]
+        image_len = pixel_values.shape[1] * pixel_values.shape[2] * self.vision_model.num_patches
+        mm_inputs.num_image_tokens = image_len
+        reps = (image_len + len(pad_values)) // len(pad_values)
+        return (pad_values * reps)[:image_len] + input_ids
+
+    def _batch_image_inputs(self, forward_batch: ForwardBatch):
+        """mllama.py:818-877: stack the pixel tiles of the requests whose encoder is not cached."""
+        if forward_batch.forward_mode.is_decode() or all(forward_batch.encoder_cached):
+            return None, None, None, None
+        todo = [(k, mm) for k, mm in enumerate(forward_batch.mm_inputs or [])
+                if mm is not None and not forward_batch.encoder_cached[k]]
+        if not todo:
+            return None, None, None, None
+        pix = [torch.cat([item.pixel_values for item in mm.mm_items], dim=0) for _, mm in todo]
+        n_img = max(p.shape[1] for p in pix)
+        n_tile = max(p.shape[2] for p in pix)
+        if n_img * n_tile == 0:
+            return None, None, None, None
+        dev = forward_batch.out_cache_loc.device
+        images = torch.zeros(len(todo), n_img, n_tile, 3, self.image_size, self.image_size,
+                             dtype=torch.float32, device=dev)
+        ar_ids = torch.ones(len(todo), n_img, dtype=torch.int64, device=dev)
+        ar_mask = torch.zeros(len(todo), n_img, n_tile, dtype=torch.int64)
+        need = []
+        for i, ((k, mm), p) in enumerate(zip(todo, pix)):
+            need.append(int(forward_batch.encoder_lens_cpu[k]))
+            first = mm.mm_items[0]
+            for j in range(p.shape[1]):
+                tiles = p[0, j]
+                images[i, j, :tiles.shape[0]] = tiles
+                ar_ids[i, j] = first.aspect_ratio_id[0, j]
+                ar_mask[i, j, :tiles.shape[0]] = first.aspect_ratio_mask[0, j]
+        return images, ar_ids, ar_mask, need
+
+    @torch.no_grad()
+    def encode_images(self, images, ar_ids, ar_mask, encoder_lens_need: List[int]) -> torch.Tensor:
+        """mllama.py:961-976: vision tower -> projector -> flat [sum(encoder_lens_need), hidden]."""
+        states = self.multi_modal_projector(self.vision_model(images, ar_ids, ar_mask))
+        return flat_encoder_result(states.view(states.shape[0], -1, states.shape[-1]), encoder_lens_need)
 
     @torch.no_grad()
     def forward(self, input_ids, positions, forward_batch: ForwardBatch,
@@ -223,8 +278,12 @@ class MllamaForConditionalGeneration(nn.Module):
         needs_encoder = (not forward_batch.forward_mode.is_decode()
                          and not all(forward_batch.encoder_cached))
         if needs_encoder and cross_attention_states is None:
-            raise RuntimeError("uncached image tokens in the batch but no cross_attention_states: the "
-                               "vision tower is not hosted by this package (SURVEY.md 8f)")
+            if self.vision_model is None or not forward_batch.mm_inputs:
+                raise RuntimeError("uncached image tokens in the batch but neither cross_attention_states "
+                                   "nor (vision_config + forward_batch.mm_inputs) to compute them from")
+            images, ar_ids, ar_mask, need = self._batch_image_inputs(forward_batch)
+            if images is not None:
+                cross_attention_states = self.encode_images(images, ar_ids, ar_mask, need)
         hidden_states = self.language_model(
             input_ids=input_ids, positions=positions, cross_attention_states=cross_attention_states,
             cross_attention_mask=None, full_text_row_masked_out_mask=mask, forward_batch=forward_batch,
@@ -232,7 +291,15 @@ class MllamaForConditionalGeneration(nn.Module):
         return self.logits_processor(input_ids, hidden_states, self.language_model.lm_head, forward_batch)
 
     def load_full_state_dict(self, full):
-        """tp=1 state_dict of the reference's MllamaForCausalLM (keys 'model.*', 'lm_head.*')."""
+        """tp=1 state_dict of the reference's MllamaForCausalLM (keys 'model.*', 'lm_head.*'); keys
+        'vision_model.*' / 'multi_modal_projector.*' are loaded too when a vision tower is present."""
+        if self.vision_model is not None and any(k.startswith("vision_model.") for k in full):
+            self.vision_model.load_full_state_dict(
+                {k[len("vision_model."):]: v for k, v in full.items() if k.startswith("vision_model.")})
+            for name in ("weight", "bias"):
+                key = "multi_modal_projector." + name
+                if key in full:
+                    getattr(self.multi_modal_projector, name).data.copy_(full[key])
         own = dict(self.language_model.named_parameters())
         mods = dict(self.language_model.named_modules())
         for name, param in own.items():

@@ -848,11 +848,64 @@ def gen_sampling():
           min_ps=min_ps, uniform=uniform, **out)
 
 
+def gen_mllama_vision():
+    """The reference's MllamaVisionModel (nn/models/llama/mllama.py:283-466) + multi_modal_projector
+    shape on CPU, tiny config: 28x28 images, 14x14 patches (4 + class token = 5 patches, padded to 8),
+    hidden 32, 2 heads (head size 16), 3 local + 2 global (gated) layers, up to 4 tiles.
+    Two batches: all tiles real / some tiles padding, so both branches of the tile mask are recorded.
+    Also a stand-alone VisionAttention call with cu_seqlens (the context_attention_fwd path) computed
+    densely here per sequence, since that Triton kernel is CUDA-only."""
+    import transformers.models.mllama.configuration_mllama as cm
+    import scratchpad.nn.models.llama.mllama as M
+    import torch.distributed as dist
+    from scratchpad.distributed import init_distributed_environment, initialize_model_parallel
+
+    if not dist.is_initialized():
+        init_distributed_environment(world_size=1, rank=0, distributed_init_method="tcp://127.0.0.1:29519",
+                                     local_rank=0, backend="gloo")
+        initialize_model_parallel(1)
+    torch.manual_seed(271)
+    cfg = cm.MllamaVisionConfig(hidden_size=32, hidden_act="gelu", num_hidden_layers=3, num_global_layers=2,
+                                attention_heads=2, num_channels=3, intermediate_size=64, vision_output_dim=96,
+                                image_size=28, patch_size=14, norm_eps=1e-5, max_num_tiles=4,
+                                intermediate_layers_indices=[0, 2],
+                                supported_aspect_ratios=[[1, 1], [1, 2], [1, 3], [1, 4], [2, 1], [2, 2], [3, 1], [4, 1]])
+    model = M.MllamaVisionModel(cfg).eval()
+    g = torch.Generator().manual_seed(272)
+    weights = {}
+    for name, prm in model.named_parameters():
+        if name.endswith("gate") or "gate_attn" in name or "gate_ffn" in name:
+            prm.data = torch.tensor([0.6 if "ffn" in name else -0.4]) if prm.numel() == 1 else prm.data
+        elif "layernorm" in name and name.endswith("weight"):
+            prm.data = _grid(1.0 + 0.1 * torch.randn(prm.shape, generator=g))
+        elif name.endswith("bias"):
+            prm.data = _grid(0.05 * torch.randn(prm.shape, generator=g), step=1024.0)
+        else:
+            prm.data = _grid(torch.randn(prm.shape, generator=g) * 0.08, step=1024.0, lim=255.0)
+        weights["w." + name] = prm.data.clone()
+    out = dict(weights)
+    out["cfg"] = np.array([cfg.hidden_size, cfg.attention_heads, cfg.intermediate_size, cfg.num_hidden_layers,
+                           cfg.num_global_layers, cfg.image_size, cfg.patch_size, cfg.max_num_tiles,
+                           cfg.max_aspect_ratio_id, cfg.num_channels], dtype=np.int64)
+    out["intermediate_layers_indices"] = np.array(cfg.intermediate_layers_indices, dtype=np.int64)
+    for tag, ar_ids, ar_mask in (("full", [[6], [4]], [[[1, 1, 1, 1]], [[1, 1, 1, 1]]]),
+                                 ("ragged", [[2], [1]], [[[1, 1, 0, 0]], [[1, 0, 0, 0]]])):
+        pixels = _grid(torch.randn(2, 1, 4, 3, 28, 28, generator=g))
+        ids = torch.tensor(ar_ids, dtype=torch.int64)
+        mask = torch.tensor(ar_mask, dtype=torch.int64)
+        pixels = pixels * mask.view(2, 1, 4, 1, 1, 1)        # the processor zero-fills unused tiles
+        y = model(pixels, ids, mask)
+        out.update({f"{tag}_pixel_values": pixels, f"{tag}_aspect_ratio_ids": ids,
+                    f"{tag}_aspect_ratio_mask": mask, f"{tag}_out": y})
+        print(tag, tuple(y.shape), float(y.abs().max()))
+    _save("mllama_vision", **out)
+
+
 GENERATORS = {
     "rmsnorm": gen_rmsnorm, "silu_mul": gen_silu_mul, "rotary": gen_rotary, "kv_pool": gen_kv_pool,
     "positions": gen_positions, "decode_attention": gen_decode, "extend_attention": gen_extend,
     "tiny_llama": gen_tiny_llama, "tiny_mllama": gen_tiny_mllama, "radix_cache": gen_radix_cache,
-    "sampling": gen_sampling,
+    "sampling": gen_sampling, "mllama_vision": gen_mllama_vision,
 }
 
 if __name__ == "__main__":

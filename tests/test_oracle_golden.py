@@ -246,3 +246,17 @@ def test_sampling_inverse_cdf_covers_the_kept_distribution():
         assert hits[want == 0].sum() == 0
         assert np.abs(hits - N * want.astype(np.float64)).max() <= 1.0 + 1e-6, b
         assert abs(float(want.sum()) - 1.0) < 1e-5
+
+
+# ---------------------------------------------------------------- Mllama vision tower
+@pytest.mark.parametrize("tag", ["full", "ragged"])
+def test_mllama_vision_oracle_matches_reference_run(tag):
+    from oracle import mllama_vision as ov
+    g = golden.load("mllama_vision")
+    sh = ov.VisionShape.from_fixture(g)
+    w = {k[2:]: torch.from_numpy(np.asarray(v, dtype=np.float32)) for k, v in g.items() if k.startswith("w.")}
+    out = ov.forward(sh, w, torch.from_numpy(g[f"{tag}_pixel_values"]),
+                     torch.from_numpy(g[f"{tag}_aspect_ratio_ids"]), torch.from_numpy(g[f"{tag}_aspect_ratio_mask"]))
+    want = torch.from_numpy(g[f"{tag}_out"])
+    assert out.shape == want.shape
+    assert float((out - want).abs().max()) <= 2e-5 * float(want.abs().max())
