@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 1
+#define SP_ABI_VERSION 2
 #define SP_API __attribute__((visibility("default")))
 
 typedef enum { SP_F32 = 0, SP_F16 = 1, SP_BF16 = 2 } sp_dtype;
@@ -137,7 +137,11 @@ SP_API int sp_decode_attention(void* out, const void* q, const void* k_buffer, c
  * req_to_token[req_pool_indices[b], kv_start[b] + ...]; the new tokens' K/V must already be in
  * the pool (KV store precedes the kernel, triton_backend.py:131-134).  causal = 0 gives the
  * cross-attention form: every row attends to all seq_lens[b] kv positions
- * (flashinfer_backend.py:408-417).  q,o: [T, Hq, D]; extend_* are int32 [bs].
+ * (flashinfer_backend.py:408-417).  window_left >= 0 (causal only) is the sliding window of
+ * flashinfer_backend.py:413: the row at kv position p sees keys [p - window_left, p]; -1 = no
+ * window.  (Decode needs no such argument: the caller passes kv_start = seq_len - min(seq_len,
+ * window + 1) and that length, flashinfer_backend.py:559-577.)
+ * q,o: [T, Hq, D]; extend_* are int32 [bs].
  * num_tokens = sum(extend_seq_lens) (host-known: ForwardBatch.extend_num_tokens) and
  * max_extend_len >= max(extend_seq_lens), max_seq_len >= max(seq_lens) fix the launch geometry.
  * workspace: sp_extend_attention_workspace_bytes().                                              */
@@ -150,8 +154,9 @@ SP_API int sp_extend_attention(void* out, const void* q, const void* k_buffer, c
                         const int32_t* extend_start_loc, int batch_size, int64_t num_tokens,
                         int num_q_heads, int num_kv_heads, int head_dim, int64_t q_stride,
                         int64_t out_stride, int64_t kv_buffer_stride, float sm_scale,
-                        float logit_cap, int causal, int max_extend_len, int64_t max_seq_len,
-                        void* workspace, size_t workspace_bytes, int dtype, void* stream);
+                        float logit_cap, int causal, int window_left, int max_extend_len,
+                        int64_t max_seq_len, void* workspace, size_t workspace_bytes, int dtype,
+                        void* stream);
 
 /* ---- Sampler.  Replaces nn/layers/sampler.py:63-75 (torch.argmax; logits.div_(T) + softmax),
  *      sampler.py:195-232 (top_k_top_p_min_p_sampling_from_probs_torch, top_p_normalize_probs_torch)

@@ -210,7 +210,8 @@ def extend_attention(q: torch.Tensor, k_buffer: torch.Tensor, v_buffer: torch.Te
                      k_extend: Optional[torch.Tensor] = None,
                      v_extend: Optional[torch.Tensor] = None,
                      causal: bool = True,
-                     kv_start: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     kv_start: Optional[torch.Tensor] = None,
+                     window_left: int = -1) -> torch.Tensor:
     """extend_attention_fwd - nn/attention/triton_attn/extend_attention.py:16-327.
 
     Row t (0-based within the request's new tokens) of request b attends to the cached prefix
@@ -218,7 +219,10 @@ def extend_attention(q: torch.Tensor, k_buffer: torch.Tensor, v_buffer: torch.Te
     tokens' K/V are read from the pool as well (they were stored before the call,
     triton_backend.py:131-134), which is numerically identical.  ``causal=False`` +
     ``kv_start`` give the encoder-decoder cross-attention form
-    (flashinfer_backend.py:400-417): every row attends to kv [kv_start, kv_start+seq_len)."""
+    (flashinfer_backend.py:400-417): every row attends to kv [kv_start, kv_start+seq_len).
+    ``window_left >= 0`` is flashinfer's sliding window (third-party v0.2.3, absent here; call site
+    flashinfer_backend.py:408-417, documented semantics: the row at kv position p attends to
+    [p - window_left, p]) - PARITY UNPINNED by the reference, which holds no test of it."""
     T, Hq, D = q.shape
     Hkv = k_buffer.shape[1]
     Dv = v_buffer.shape[2]
@@ -244,6 +248,8 @@ def extend_attention(q: torch.Tensor, k_buffer: torch.Tensor, v_buffer: torch.Te
             col = torch.arange(L).view(1, L)
             row = torch.arange(E).view(E, 1) + P
             s = s.masked_fill(col > row, float("-inf"))
+            if window_left >= 0:
+                s = s.masked_fill(col < row - window_left, float("-inf"))
         p, denom = _softmax_parts(s, q.dtype)
         o[s0:s0 + E] = (torch.einsum("hgel,lhd->hged", p, v) / denom).permute(2, 0, 1, 3).reshape(E, Hq, Dv)
     return o.to(q.dtype)

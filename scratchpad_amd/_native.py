@@ -43,7 +43,7 @@ SIGNATURES = {
     "sp_extend_attention_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32]),
     "sp_extend_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp,
                                    _i32, _i64, _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32,
-                                   _i32, _i32, _i64, _vp, _sz, _i32, _vp]),
+                                   _i32, _i32, _i32, _i64, _vp, _sz, _i32, _vp]),
     "sp_argmax": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp]),
     "sp_softmax_temperature": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp]),
     "sp_top_k_top_p_min_p_sample": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
@@ -69,7 +69,7 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.sp_abi_version() != 1:
+    if lib.sp_abi_version() != 2:
         raise RuntimeError("libscratchpad_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -304,8 +304,9 @@ def extend_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
                      extend_seq_lens: torch.Tensor, extend_start_loc: torch.Tensor,
                      sm_scale: float, logit_cap: float, causal: bool, max_extend_len: int,
                      max_seq_len: int, workspace: torch.Tensor,
-                     kv_start: Optional[torch.Tensor] = None) -> None:
-    """q, out: [T, Hq, D]; the new tokens' K/V must already be in the pool."""
+                     kv_start: Optional[torch.Tensor] = None, window_left: int = -1) -> None:
+    """q, out: [T, Hq, D]; the new tokens' K/V must already be in the pool.  window_left >= 0:
+    causal rows see only the window_left keys before their own position (and themselves)."""
     _gpu(out, q, k_buffer, v_buffer, req_to_token, req_pool_indices, seq_lens, extend_seq_lens,
          extend_start_loc, workspace, kv_start)
     T, Hq, D = q.shape
@@ -323,7 +324,7 @@ def extend_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
         req_to_token.stride(0), req.data_ptr(), seq.data_ptr(), _ptr(kv_start), idx64,
         extend_seq_lens.contiguous().data_ptr(), extend_start_loc.contiguous().data_ptr(),
         seq.shape[0], T, Hq, k_buffer.shape[1], D, q.stride(0), out.stride(0), k_buffer.stride(0),
-        sm_scale, logit_cap, int(causal), max_extend_len, max_seq_len, workspace.data_ptr(),
+        sm_scale, logit_cap, int(causal), int(window_left), max_extend_len, max_seq_len, workspace.data_ptr(),
         workspace.numel() * workspace.element_size(), _dt(q), _stream()), "sp_extend_attention")
 
 

@@ -122,7 +122,13 @@ class HipAttnBackend(AttentionBackend):
         self.is_encoder_decoder = bool(getattr(cfg, "is_encoder_decoder", False))
         self.forward_metadata = None
         self._workspace = torch.empty(0, dtype=torch.uint8, device=self.device)
-        self._plans = [torch.empty(0, dtype=torch.int32, device=self.device) for _ in range(2)]
+        self._plans = [torch.empty(0, dtype=torch.int32, device=self.device) for _ in range(3)]
+        # Gemma-2 style models: some layers see only the last `sliding_window_size` keys + themselves
+        # (the reference keeps a second flashinfer wrapper for them, flashinfer_backend.py:76-83)
+        sw = getattr(model_runner, "sliding_window_size", None)
+        self.sliding_window_size = sw if sw not in (None, -1) else None
+        self._window = None            # (lens, kv_start) of the windowed layers, this step
+        self._graph_window = None
         self._graph_workspace = None
         self._graph_plans = None
         self._graph_chunk = None
@@ -152,7 +158,8 @@ class HipAttnBackend(AttentionBackend):
         121-131).  Built once per step, read by every layer's launch."""
         need = _native.decode_plan_bytes(bs, max_len, chunk) // 4
         out = []
-        for i, lens in enumerate((seq_lens, encoder_lens)):
+        window_lens = None if self._window is None else self._window[0]
+        for i, lens in enumerate((seq_lens, encoder_lens, window_lens)):
             if lens is None:
                 out.append(None)
                 continue
@@ -181,6 +188,7 @@ class HipAttnBackend(AttentionBackend):
             ws = self._ensure_workspace(_native.decode_workspace_bytes(
                 bs, self.num_head, self.v_head_dim, max_len, chunk))
             enc = forward_batch.encoder_lens if self.is_encoder_decoder else None
+            self._window = self._window_of(forward_batch.seq_lens)
             plans = self._build_plans(self._plans, bs, forward_batch.seq_lens, enc, max_len, chunk)
             self.forward_metadata = (chunk, max_len, ws, plans)
         else:
@@ -205,12 +213,16 @@ class HipAttnBackend(AttentionBackend):
                                                 self.cuda_graph_max_seq_len, self._graph_chunk)
         self._graph_workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         n = _native.decode_plan_bytes(max_bs, self.cuda_graph_max_seq_len, self._graph_chunk) // 4
-        self._graph_plans = [torch.empty(n, dtype=torch.int32, device=self.device) for _ in range(2)]
+        self._graph_plans = [torch.empty(n, dtype=torch.int32, device=self.device) for _ in range(3)]
+        if self.sliding_window_size is not None:
+            self._graph_window = tuple(torch.ones(max_bs, dtype=torch.int32, device=self.device)
+                                       for _ in range(2))
 
     def init_forward_metadata_capture_cuda_graph(self, bs, num_tokens, req_pool_indices, seq_lens,
                                                  encoder_lens, forward_mode, spec_info=None):
         assert forward_mode.is_decode(), "only decode is captured"
         assert spec_info is None, "speculative decoding is out of scope"
+        self._window = self._window_of(seq_lens, self._graph_window, bs)
         plans = self._build_plans(self._graph_plans, bs, seq_lens, encoder_lens,
                                   self.cuda_graph_max_seq_len, self._graph_chunk)
         self.forward_metadata = (self._graph_chunk, self.cuda_graph_max_seq_len,
@@ -223,6 +235,7 @@ class HipAttnBackend(AttentionBackend):
         # static input buffers; only the split plan (static buffer, fixed address) is rebuilt for
         # this step's lengths, ahead of the replay - where the reference recomputes start_loc /
         # kv_indices (triton_backend.py:103-113, flashinfer_backend.py:330-373)
+        self._window = self._window_of(seq_lens[:bs], self._graph_window, bs)
         plans = self._build_plans(self._graph_plans, bs, seq_lens[:bs],
                                   None if encoder_lens is None else encoder_lens[:bs],
                                   self.cuda_graph_max_seq_len, self._graph_chunk)
@@ -233,8 +246,30 @@ class HipAttnBackend(AttentionBackend):
         return 1  # padded rows attend to the dummy slot 0 only (triton_backend.py:115-116)
 
     # ---------------------------------------------------------------- forward
+    def _window_of(self, seq_lens: torch.Tensor, static=None, bs: Optional[int] = None):
+        """Decode kv range of the sliding-window layers (flashinfer_backend.py:559-577):
+        lens = min(seq_lens, window + 1), kv_start = seq_lens - lens.  With ``static`` buffers (graph
+        capture / replay) the values are written in place so the captured launches see them."""
+        if self.sliding_window_size is None:
+            return None
+        lens = torch.clamp(seq_lens, max=self.sliding_window_size + 1)
+        start = seq_lens - lens
+        if static is None:
+            return lens, start
+        static[0][:bs].copy_(lens)
+        static[1][:bs].copy_(start)
+        return static[0][:bs], static[1][:bs]
+
+    def _is_windowed(self, layer: RadixAttention) -> bool:
+        return layer.sliding_window_size not in (-1, None) and not layer.is_cross_attention
+
     def _kv_window(self, layer: RadixAttention, forward_batch: "ForwardBatch"):
         """(seq_lens, kv_start) for this layer: flashinfer_backend.py:593-621, 792-828."""
+        if self._is_windowed(layer) and forward_batch.forward_mode.is_decode():
+            if self._window is None or layer.sliding_window_size != self.sliding_window_size:
+                raise RuntimeError("sliding-window layer but the runner declares no (or another) "
+                                   "sliding_window_size")
+            return self._window
         if layer.is_cross_attention:
             return forward_batch.encoder_lens, None
         if self.is_encoder_decoder and forward_batch.encoder_lens is not None:
@@ -274,8 +309,6 @@ class HipAttnBackend(AttentionBackend):
 
     def forward_extend(self, q, k, v, layer: RadixAttention, forward_batch: "ForwardBatch",
                        save_kv_cache: bool = True):
-        if layer.sliding_window_size not in (-1, None):
-            raise NotImplementedError("sliding-window attention (Gemma) is out of scope")
         if layer.qk_head_dim != layer.v_head_dim:
             raise NotImplementedError("v_head_dim != head_dim (MLA) is out of scope")
         q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
@@ -291,13 +324,12 @@ class HipAttnBackend(AttentionBackend):
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), kb, vb,
             forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices, seq_lens,
             forward_batch.extend_seq_lens, forward_batch.extend_start_loc, layer.scaling,
-            layer.logit_cap, not layer.is_cross_attention, max_extend, max_len, ws, kv_start)
+            layer.logit_cap, not layer.is_cross_attention, max_extend, max_len, ws, kv_start,
+            window_left=layer.sliding_window_size if self._is_windowed(layer) else -1)
         return o
 
     def forward_decode(self, q, k, v, layer: RadixAttention, forward_batch: "ForwardBatch",
                        save_kv_cache: bool = True):
-        if layer.sliding_window_size not in (-1, None):
-            raise NotImplementedError("sliding-window attention (Gemma) is out of scope")
         if layer.qk_head_dim != layer.v_head_dim:
             raise NotImplementedError("v_head_dim != head_dim (MLA) is out of scope")
         q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
@@ -305,7 +337,7 @@ class HipAttnBackend(AttentionBackend):
         self._store(layer, forward_batch, k, v, save_kv_cache)
         chunk, max_len, ws, plans = self.forward_metadata
         seq_lens, kv_start = self._kv_window(layer, forward_batch)
-        plan = plans[1] if layer.is_cross_attention else plans[0]
+        plan = plans[2] if self._is_windowed(layer) else (plans[1] if layer.is_cross_attention else plans[0])
         kb, vb = forward_batch.token_to_kv_pool.get_kv_buffer(layer.layer_id)
         _native.decode_attention(
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),

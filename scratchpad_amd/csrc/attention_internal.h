@@ -40,6 +40,6 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
                     int idx64, const int32_t* extend_seq_lens, const int32_t* extend_start_loc,
                     int batch_size, int num_q_heads, int num_kv_heads, int head_dim, int64_t q_stride,
                     int64_t out_stride, int64_t kv_buffer_stride, float sm_scale, float logit_cap,
-                    int causal, int max_extend_len, int dtype, hipStream_t st);
+                    int causal, int window_left, int max_extend_len, int dtype, hipStream_t st);
 
 }  // namespace sp

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void expand_rows_kernel(
     int32_t* __restrict__ row_req, int32_t* __restrict__ row_len, int32_t* __restrict__ row_kv0,
     const void* __restrict__ req_pool_indices, const void* __restrict__ seq_lens,
     const void* __restrict__ kv_start, int idx64, const int32_t* __restrict__ extend_seq_lens,
-    const int32_t* __restrict__ extend_start_loc, int causal, int64_t num_tokens) {
+    const int32_t* __restrict__ extend_start_loc, int causal, int window, int64_t num_tokens) {
   const int b = blockIdx.x;
   const int e = extend_seq_lens[b];
   const int64_t s0 = extend_start_loc[b];
@@ -31,8 +31,10 @@ __global__ __launch_bounds__(256) void expand_rows_kernel(
     const int64_t t = s0 + i;
     if (t >= num_tokens) break;  // never write beyond the caller's buffers
     row_req[t] = req;
-    row_len[t] = causal ? prefix + i + 1 : seq;
-    row_kv0[t] = kv0;
+    const int vis = causal ? prefix + i + 1 : seq;                 // keys [0, vis)
+    const int len = (causal && window >= 0) ? min(vis, window + 1) : vis;   // ... the last `len` of them
+    row_len[t] = len;
+    row_kv0[t] = kv0 + (vis - len);
   }
 }
 
@@ -56,9 +58,9 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
                                    int64_t num_tokens, int num_q_heads, int num_kv_heads,
                                    int head_dim, int64_t q_stride, int64_t out_stride,
                                    int64_t kv_buffer_stride, float sm_scale, float logit_cap,
-                                   int causal, int max_extend_len, int64_t max_seq_len,
-                                   void* workspace, size_t workspace_bytes, int dtype,
-                                   void* stream) {
+                                   int causal, int window_left, int max_extend_len,
+                                   int64_t max_seq_len, void* workspace, size_t workspace_bytes,
+                                   int dtype, void* stream) {
   SP_CHECK_ARG(out && q && k_buffer && v_buffer && req_to_token && req_pool_indices && seq_lens);
   SP_CHECK_ARG(extend_seq_lens && extend_start_loc && batch_size >= 0 && num_tokens >= 0);
   SP_CHECK_ARG(num_q_heads > 0 && num_kv_heads > 0 && num_q_heads % num_kv_heads == 0);
@@ -85,7 +87,7 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
                                    req_pool_indices, seq_lens, kv_start, idx64, extend_seq_lens,
                                    extend_start_loc, batch_size, num_q_heads, num_kv_heads, head_dim,
                                    q_stride, out_stride, kv_buffer_stride, sm_scale, logit_cap, causal,
-                                   max_extend_len, dtype, st);
+                                   window_left, max_extend_len, dtype, st);
     if (rc != SP_ERR_UNSUPPORTED) return rc;
   }
 
@@ -94,7 +96,7 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
   int32_t* row_kv0 = row_len + num_tokens;
   expand_rows_kernel<<<dim3(batch_size), 256, 0, st>>>(row_req, row_len, row_kv0, req_pool_indices,
                                                        seq_lens, kv_start, idx64, extend_seq_lens,
-                                                       extend_start_loc, causal, num_tokens);
+                                                       extend_start_loc, causal, window_left, num_tokens);
   SP_LAUNCH_CHECK();
 
   DecodeArgs a;

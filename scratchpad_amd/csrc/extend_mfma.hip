@@ -46,6 +46,7 @@ struct ExtendArgs {
   int64_t q_stride, o_stride, kv_stride;  // elements
   float sm_scale, logit_cap;
   int causal;
+  int window;   // sliding window: a row at kv position p sees keys [p - window, p]; < 0 = unlimited
 };
 
 static constexpr float kLog2eX = 1.4426950408889634f;
@@ -131,6 +132,9 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   // keys this workgroup can see: the prefix and new tokens up to its last row (causal), else all
   const int kv_len = a.causal ? min(L, P + min(row0 + BM, E)) : L;
   const int ntiles = (kv_len + BN - 1) / BN;
+  // sliding window (causal only): the first row of the block reaches furthest back
+  const bool windowed = a.causal && a.window >= 0;
+  const int tbeg = windowed ? max(0, P + row0 - a.window) / BN : 0;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int c = lane & 31, h = lane >> 5;
@@ -151,6 +155,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   const float cap = a.logit_cap;
   const float qk_scale = cap > 0.f ? a.sm_scale : a.sm_scale * kLog2eX;
   const int row_limit = a.causal ? P + my_row : 0x7fffffff;   // last visible key index
+  const int row_first = windowed ? P + my_row - a.window : 0;  // first visible key index (may be < 0)
 
   f32x16 oacc[DBLK];
 #pragma unroll
@@ -202,17 +207,18 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   // pipeline: tile t+1's global gathers fly during compute(t); they are written to the OTHER LDS
   // buffer right after compute(t), and one barrier per tile both publishes tile t+1 and retires
   // every wave's reads of tile t (whose buffer is overwritten only in iteration t+1)
-  fetch_slots(0);
-  prefetch(0);
-  stage(0);
+  fetch_slots(tbeg);
+  prefetch(tbeg);
+  stage(tbeg & 1);
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = tbeg; t < ntiles; ++t) {
     if (t + 1 < ntiles) prefetch(t + 1);
     const char* ldsK = lds + (t & 1) * C::kTileBytes;
     const char* ldsV = ldsK + BN * SK;
     const int key0 = t * BN;
     // a wave skips tiles that lie entirely above its rows' diagonal (wave-uniform)
-    const bool visible = wave_live && (!a.causal || key0 <= P + min(r0 + 31, E - 1));
+    const bool visible = wave_live && (!a.causal || key0 <= P + min(r0 + 31, E - 1)) &&
+                         (!windowed || key0 + BN - 1 >= P + r0 - a.window);
     if (visible) {
       // ---- S^T = K . Q^T for the two 32-key blocks of the tile
       f32x16 s[2];
@@ -235,7 +241,8 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
       // ---- scale, mask, online softmax (query row on the lane; keys in registers + lane^32)
       float mx = kNegBigX;
       // interior tiles (entirely below every row's diagonal and inside the key range) need no mask
-      const bool need_mask = key0 + BN > kv_len || (a.causal && key0 + BN - 1 > P + r0);
+      const bool need_mask = key0 + BN > kv_len || (a.causal && key0 + BN - 1 > P + r0) ||
+                             (windowed && key0 < P + min(r0 + 31, E - 1) - a.window);
       if (need_mask) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
             const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             float x = s[kb][r] * qk_scale;
             if (cap > 0.f) x = cap * tanhf(x / cap) * kLog2eX;
-            x = (key < kv_len && key <= row_limit) ? x : -INFINITY;
+            x = (key < kv_len && key <= row_limit && key >= row_first) ? x : -INFINITY;
             s[kb][r] = x;
             mx = fmaxf(mx, x);
           }
@@ -365,7 +372,7 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
                     int idx64, const int32_t* extend_seq_lens, const int32_t* extend_start_loc,
                     int batch_size, int num_q_heads, int num_kv_heads, int head_dim, int64_t q_stride,
                     int64_t out_stride, int64_t kv_buffer_stride, float sm_scale, float logit_cap,
-                    int causal, int max_extend_len, int dtype, hipStream_t st) {
+                    int causal, int window_left, int max_extend_len, int dtype, hipStream_t st) {
   if (dtype != SP_F16 && dtype != SP_BF16) return SP_ERR_UNSUPPORTED;
   if (head_dim != 64 && head_dim != 128) return SP_ERR_UNSUPPORTED;
   if (batch_size > 65535 || num_kv_heads * 2 > 65535) return SP_ERR_UNSUPPORTED;
@@ -377,6 +384,7 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
   a.ext_start = extend_start_loc; a.bs = batch_size; a.Hq = num_q_heads; a.Hkv = num_kv_heads;
   a.q_stride = q_stride; a.o_stride = out_stride; a.kv_stride = kv_buffer_stride;
   a.sm_scale = sm_scale; a.logit_cap = logit_cap; a.causal = causal;
+  a.window = causal ? window_left : -1;
   const int G = num_q_heads / num_kv_heads;
   if (max_extend_len <= 0) return SP_OK;
   if (dtype == SP_BF16) {

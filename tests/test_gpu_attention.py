@@ -214,12 +214,13 @@ def test_decode_rejects_bad_arguments(nat):
 
 
 # ----------------------------------------------------------------------------------- extend
-def run_extend(nat, q, kb, vb, r2t, req, seq, ext, start, scale, cap=0.0, causal=True, kv_start=None):
+def run_extend(nat, q, kb, vb, r2t, req, seq, ext, start, scale, cap=0.0, causal=True, kv_start=None,
+               window_left=-1):
     T_, Hq, D = q.shape
     ws = torch.empty(nat.extend_workspace_bytes(T_, len(seq), Hq, D, q.dtype), dtype=torch.uint8, device=DEV)
     o = torch.full_like(q, float("nan"))
     nat.extend_attention(o, q, kb, vb, r2t, req, seq, ext, start, scale, cap, causal,
-                         int(ext.max()), int(seq.max()), ws, kv_start)
+                         int(ext.max()), int(seq.max()), ws, kv_start, window_left=window_left)
     return o
 
 
@@ -311,3 +312,94 @@ def test_extend_last_row_equals_decode(nat):
     pd = dict(p); pd["q"] = q[last].contiguous()
     od = run_decode(nat, pd, 0.09, chunk=64)
     assert_close(o[last], od.float(), dtype, what="extend last row vs decode")
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("window", [0, 7, 64, 200, 4096])
+def test_extend_sliding_window(nat, dt, window):
+    """window_left (flashinfer_backend.py:413): the row at kv position p sees [p - window, p].
+    fp32 runs the row-stream path, 16-bit the MFMA kernel (first tile / lower mask / skipped tiles)."""
+    dtype = DTYPES[dt]
+    Hq, Hkv, D = 8, 2, 128
+    pre = [0, 64, 300, 0, 5, 129]
+    ext = [130, 1, 70, 1, 257, 33]
+    p, q, ext_t, start = extend_problem(41, Hq, Hkv, D, pre, ext, dtype)
+    scale = D ** -0.5
+    o = run_extend(nat, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"],
+                   p["seq_lens"], ext_t, start, scale, window_left=window)
+    c = cpu(p)
+    ref = ops.extend_attention(q.cpu().float(), c["k_buffer"].float(), c["v_buffer"].float(),
+                               c["req_to_token"], c["req_pool_indices"], c["seq_lens"], ext_t.cpu(),
+                               start.cpu(), scale, window_left=window)
+    assert_close(o, ref, dtype, what=f"extend window {window}")
+    if window >= 4096:      # wider than every sequence: identical to no window at all
+        full = run_extend(nat, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"],
+                          p["seq_lens"], ext_t, start, scale)
+        assert torch.equal(o, full)
+    if window == 0:         # only itself: the output is its own V row
+        tok = 0
+        for b in range(len(ext)):
+            req = int(c["req_pool_indices"][b])
+            for t in range(ext[b]):
+                slot = int(c["req_to_token"][req, pre[b] + t])
+                want = c["v_buffer"][slot].float().repeat_interleave(Hq // Hkv, dim=0)
+                assert torch.allclose(o[tok].float().cpu(), want, atol=0, rtol=0)
+                tok += 1
+
+
+def test_backend_sliding_window_layers_decode_and_extend():
+    """HipAttnBackend with a runner-level sliding_window_size: windowed layers read the last
+    window + 1 keys in decode (kv_start = seq_len - len, flashinfer_backend.py:559-577) with their own
+    split plan, full layers are unaffected; extend passes window_left."""
+    from types import SimpleNamespace
+    from scratchpad_amd.attention import HipAttnBackend, RadixAttention
+    from scratchpad_amd.forward_info import ForwardMode
+    dtype = torch.bfloat16
+    Hq, Hkv, D, W = 8, 2, 128, 37
+    seq = [5, 38, 39, 500, 120]
+    bs = len(seq)
+    p = paged_problem(51, bs, Hq, Hkv, D, seq, dtype, DEV)
+    pool = SimpleNamespace(dtype=dtype, get_value_buffer=lambda l: p["v_buffer"],
+                           get_kv_buffer=lambda l: (p["k_buffer"], p["v_buffer"]))
+    cfg = SimpleNamespace(num_attention_heads=Hq, head_dim=D, context_len=1024,
+                          get_num_kv_heads=lambda tp: Hkv)
+    mr = SimpleNamespace(model_config=cfg, tp_size=1, token_to_kv_pool=pool, device=DEV, sliding_window_size=W)
+    be = HipAttnBackend(mr)
+    local = RadixAttention(Hq, D, D ** -0.5, Hkv, layer_id=0, sliding_window_size=W)
+    full = RadixAttention(Hq, D, D ** -0.5, Hkv, layer_id=1)
+    r2t_pool = SimpleNamespace(req_to_token=p["req_to_token"])
+    fb = SimpleNamespace(forward_mode=ForwardMode.DECODE, batch_size=bs, seq_lens=p["seq_lens"],
+                         seq_lens_cpu=p["seq_lens"].cpu(), seq_lens_sum=sum(seq), encoder_lens=None,
+                         encoder_lens_cpu=None, req_pool_indices=p["req_pool_indices"],
+                         token_to_kv_pool=pool, req_to_token_pool=r2t_pool, out_cache_loc=None)
+    be.init_forward_metadata(fb)
+    c = cpu(p)
+    q = p["q"]
+    o_local = be.forward_decode(q.reshape(bs, -1), None, None, local, fb, save_kv_cache=False).view(bs, Hq, D)
+    o_full = be.forward_decode(q.reshape(bs, -1), None, None, full, fb, save_kv_cache=False).view(bs, Hq, D)
+    lens = torch.clamp(c["seq_lens"], max=W + 1)
+    ref_local = ops.decode_attention(q.cpu().float(), c["k_buffer"].float(), c["v_buffer"].float(), c["req_to_token"],
+                                     c["req_pool_indices"], lens, D ** -0.5, kv_start=c["seq_lens"] - lens)
+    ref_full = ops.decode_attention(q.cpu().float(), c["k_buffer"].float(), c["v_buffer"].float(), c["req_to_token"],
+                                    c["req_pool_indices"], c["seq_lens"], D ** -0.5)
+    assert_close(o_local, ref_local, dtype, what="windowed decode layer")
+    assert_close(o_full, ref_full, dtype, what="full decode layer next to it")
+    assert torch.equal(o_local[:2], o_full[:2]), "sequences shorter than the window are untouched"
+
+    # extend through the same backend: each request's last 3 tokens are new
+    ext = [3] * bs
+    ext_t = torch.tensor(ext, dtype=torch.int32, device=DEV)
+    start = torch.arange(0, 3 * bs, 3, dtype=torch.int32, device=DEV)
+    qe = torch.randn(3 * bs, Hq, D, generator=torch.Generator().manual_seed(52)).to(dtype).to(DEV)
+    fbe = SimpleNamespace(forward_mode=ForwardMode.EXTEND, batch_size=bs, seq_lens=p["seq_lens"],
+                          seq_lens_cpu=p["seq_lens"].cpu(), seq_lens_sum=sum(seq), encoder_lens=None,
+                          encoder_lens_cpu=None, req_pool_indices=p["req_pool_indices"],
+                          token_to_kv_pool=pool, req_to_token_pool=r2t_pool, out_cache_loc=None,
+                          extend_seq_lens=ext_t, extend_start_loc=start, extend_seq_lens_cpu=ext,
+                          extend_prefix_lens_cpu=[s - 3 for s in seq], extend_num_tokens=3 * bs)
+    be.init_forward_metadata(fbe)
+    oe = be.forward_extend(qe.reshape(3 * bs, -1), None, None, local, fbe, save_kv_cache=False).view(-1, Hq, D)
+    ref = ops.extend_attention(qe.cpu().float(), c["k_buffer"].float(), c["v_buffer"].float(), c["req_to_token"],
+                               c["req_pool_indices"], c["seq_lens"], ext_t.cpu(), start.cpu(), D ** -0.5,
+                               window_left=W)
+    assert_close(oe, ref, dtype, what="windowed extend layer")
