@@ -1,0 +1,27 @@
+#!/bin/bash
+# Full GPU check + the measurements quoted in DESIGN.md / BASELINE.md (run on the GPU box via gpurun).
+set -o pipefail
+mkdir -p gpurun_out/report
+R=gpurun_out/report
+if [ "$1" != "--profile-only" ]; then
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > $R/tests.log 2>&1 || { tail -30 $R/tests.log; exit 1; }
+tail -3 $R/tests.log
+timeout -k 10 400 python bench.py > $R/bench_decode.json 2> $R/bench_decode.err || { tail -20 $R/bench_decode.err; exit 1; }
+tail -1 $R/bench_decode.json | cut -c1-400
+timeout -k 10 400 python bench.py --mode prefill > $R/bench_prefill.json 2> $R/bench_prefill.err || { tail -20 $R/bench_prefill.err; exit 1; }
+tail -1 $R/bench_prefill.json | cut -c1-300
+timeout -k 10 200 python tools/bench_extend_attn.py > $R/extend_attn.log 2>&1 || { tail -20 $R/extend_attn.log; exit 1; }
+tail -8 $R/extend_attn.log
+timeout -k 10 200 python tools/bench_sampling.py > $R/sampling.log 2>&1 || { tail -20 $R/sampling.log; exit 1; }
+tail -8 $R/sampling.log
+fi
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$R/prof -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 4 --no-cpu-baseline > $GRAFT_REPO_ROOT/$R/prof_bench.json 2> $GRAFT_REPO_ROOT/$R/prof.err || { tail -20 $GRAFT_REPO_ROOT/$R/prof.err; exit 1; }
+cd $GRAFT_REPO_ROOT
+STATS=$(find $R/prof -name "*kernel_stats.csv" | head -1)
+TRACE=$(find $R/prof -name "*kernel_trace.csv" | head -1)
+python tools/prof_summary.py $STATS 22 > $R/kernel_stats.txt
+python tools/prof_summary.py --steady $TRACE decode_mfma_kernel decode_merge_kernel >> $R/kernel_stats.txt
+tail -1 $R/prof_bench.json | cut -c1-300 >> $R/kernel_stats.txt
+rm -rf $R/prof
+cat $R/kernel_stats.txt
