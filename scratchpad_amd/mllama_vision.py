@@ -21,7 +21,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .vision import ColumnParallelLinear, RowParallelLinear, VisionAttention
+from .vision import ColumnParallelLinear, RowParallelLinear, VisionAttention, VisionAttnPlan
 
 
 class Conv2dPatch(nn.Module):
@@ -107,8 +107,8 @@ class MllamaVisionEncoderLayer(nn.Module):
             self.gate_attn = nn.Parameter(torch.ones(1, dtype=dtype) * 0.7853981633974483)
             self.gate_ffn = nn.Parameter(torch.ones(1, dtype=dtype) * 0.7853981633974483)
 
-    def forward(self, hidden_state: torch.Tensor, pad_rows: Optional[torch.Tensor] = None):
-        h = self.self_attn(self.input_layernorm(hidden_state), pad_rows=pad_rows)
+    def forward(self, hidden_state: torch.Tensor, plan: Optional[VisionAttnPlan] = None):
+        h = self.self_attn(self.input_layernorm(hidden_state), plan=plan)
         hidden_state = hidden_state + (self.gate_attn.tanh() * h if self.is_gated else h)
         h = self.mlp(self.post_attention_layernorm(hidden_state))
         return hidden_state + (self.gate_ffn.tanh() * h if self.is_gated else h)
@@ -123,12 +123,12 @@ class MllamaVisionEncoder(nn.Module):
         self.layers = nn.ModuleList(MllamaVisionEncoderLayer(config, is_gated, dtype) for _ in range(num_layers))
         self.output_hidden_states = list(output_hidden_states or [])
 
-    def forward(self, hidden_states: torch.Tensor, pad_rows: Optional[torch.Tensor] = None):
+    def forward(self, hidden_states: torch.Tensor, plan: Optional[VisionAttnPlan] = None):
         taps = []
         for i, layer in enumerate(self.layers):
             if i in self.output_hidden_states:
                 taps.append(hidden_states)
-            hidden_states = layer(hidden_states, pad_rows)
+            hidden_states = layer(hidden_states, plan)
         if len(self.layers) - 1 in self.output_hidden_states:
             taps.append(hidden_states)
         return hidden_states, tuple(taps)
@@ -182,11 +182,12 @@ class MllamaVisionModel(nn.Module):
             raise NotImplementedError("patch count already a multiple of 8: the reference's mask marks "
                                       "every position as padding in that case (mllama.py:403-410)")
         x = F.pad(x, (0, 0, 0, Pp - P))
-        pad_rows = padding_positions(aspect_ratio_mask.reshape(n, T), P, Pp)
-        x, taps = self.transformer(x.reshape(n, T * Pp, E), pad_rows)
+        # one attention plan for all 40 layers (the reference rebuilds its [n,1,S,S] mask per forward too)
+        plan = VisionAttnPlan(n, T * Pp, x.device, pad_rows=padding_positions(aspect_ratio_mask.reshape(n, T), P, Pp))
+        x, taps = self.transformer(x.reshape(n, T * Pp, E), plan)
         x = self.layernorm_post(x).reshape(n, T, Pp, E)
         x = self.post_tile_positional_embedding(x, ids).reshape(n, T * Pp, E)
-        x, _ = self.global_transformer(x, pad_rows)
+        x, _ = self.global_transformer(x, plan)
         x = x.reshape(n, T, Pp, E)[:, :, :P]
         taps = torch.stack(taps, dim=-1).reshape(n, T, Pp, -1)[:, :, :P]
         return torch.cat([x, taps], dim=-1).reshape(B, M, T, P, -1)

@@ -74,6 +74,13 @@ class ModelConfig:
                    max_position_embeddings=max(8192, context_len))
 
     @classmethod
+    def mllama_11b_text(cls, context_len: int = 8192):
+        """Llama-3.2-11B-Vision text model: Llama-3-8B widths, 40 layers of which 8 cross-attend."""
+        return cls(4096, 14336, 40, 32, 8, 128256, context_len=context_len,
+                   cross_attention_layers=[3, 8, 13, 18, 23, 28, 33, 38],
+                   max_position_embeddings=max(8192, context_len))
+
+    @classmethod
     def llama3_70b(cls, context_len: int = 8192):
         return cls(8192, 28672, 80, 64, 8, 128256, context_len=context_len,
                    max_position_embeddings=max(8192, context_len))
@@ -244,18 +251,30 @@ class HipGraphRunner:
         self.seq_lens = torch.full((self.max_bs,), self.seq_len_fill_value, dtype=torch.int32, device=dev)
         self.out_cache_loc = torch.zeros((self.max_bs,), dtype=torch.int64, device=dev)
         self.positions = torch.zeros((self.max_bs,), dtype=torch.int64, device=dev)
+        # encoder-decoder models (cuda_graph_runner.py:201-208): encoder_lens is a graph input too;
+        # fill value 0 = "no encoder tokens" for padded rows (their cross-attention rows stay zero)
+        self.is_encoder_decoder = model_runner.model_config.is_encoder_decoder
+        self.encoder_lens = (torch.zeros((self.max_bs,), dtype=torch.int32, device=dev)
+                             if self.is_encoder_decoder else None)
         self.pool = None
         self.capture()
 
     def can_run(self, forward_batch: ForwardBatch) -> bool:
-        # encoder-decoder batches carry encoder_lens, which this runner does not capture yet
-        return forward_batch.batch_size <= self.max_bs and forward_batch.encoder_lens is None
+        return (forward_batch.batch_size <= self.max_bs
+                and (forward_batch.encoder_lens is None) == (self.encoder_lens is None))
 
     def capture(self):
-        for bs in reversed(self.capture_bs):
-            graph, out = self.capture_one_batch_size(bs)
-            self.graphs[bs] = graph
-            self.output_buffers[bs] = out
+        model = self.model_runner.model
+        if self.is_encoder_decoder:
+            model.capture_mode = True      # cross-attention is always part of the captured step
+        try:
+            for bs in reversed(self.capture_bs):
+                graph, out = self.capture_one_batch_size(bs)
+                self.graphs[bs] = graph
+                self.output_buffers[bs] = out
+        finally:
+            if self.is_encoder_decoder:
+                model.capture_mode = False
 
     def capture_one_batch_size(self, bs: int):
         mr = self.model_runner
@@ -266,8 +285,14 @@ class HipGraphRunner:
             positions=self.positions[:bs], req_to_token_pool=mr.req_to_token_pool,
             token_to_kv_pool=mr.token_to_kv_pool, attn_backend=mr.attn_backend,
             capture_hidden_mode=CaptureHiddenMode.NULL)
+        enc = None
+        if self.is_encoder_decoder:
+            enc = self.encoder_lens[:bs]
+            fb.encoder_lens = enc
+            fb.encoder_lens_cpu = [0] * bs
+            fb.encoder_cached = [True] * bs
         mr.attn_backend.init_forward_metadata_capture_cuda_graph(
-            bs, bs, fb.req_pool_indices, fb.seq_lens, None, ForwardMode.DECODE, None)
+            bs, bs, fb.req_pool_indices, fb.seq_lens, enc, ForwardMode.DECODE, None)
 
         def run_once():
             return mr.model.forward(fb.input_ids, fb.positions, fb)
@@ -293,6 +318,10 @@ class HipGraphRunner:
         if bs != raw_bs:
             self.seq_lens.fill_(self.seq_len_fill_value)
             self.out_cache_loc.zero_()
+            if self.encoder_lens is not None:
+                self.encoder_lens.zero_()
+        if self.encoder_lens is not None:
+            self.encoder_lens[:raw_bs].copy_(forward_batch.encoder_lens)
         self.input_ids[:raw_bs].copy_(forward_batch.input_ids)
         self.req_pool_indices[:raw_bs].copy_(forward_batch.req_pool_indices)
         self.seq_lens[:raw_bs].copy_(forward_batch.seq_lens)
@@ -300,7 +329,7 @@ class HipGraphRunner:
         self.positions[:raw_bs].copy_(forward_batch.positions)
         self.model_runner.attn_backend.init_forward_metadata_replay_cuda_graph(
             bs, self.req_pool_indices, self.seq_lens,
-            forward_batch.seq_lens_sum + (bs - raw_bs) * self.seq_len_fill_value, None,
+            forward_batch.seq_lens_sum + (bs - raw_bs) * self.seq_len_fill_value, self.encoder_lens,
             ForwardMode.DECODE, None, forward_batch.seq_lens_cpu)
         self.graphs[bs].replay()
         out = self.output_buffers[bs]

@@ -47,42 +47,97 @@ class _Workspace:
         return cur
 
 
-def varlen_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, seq_lens: Sequence[int],
+class VarlenPlan:
+    """Launch arguments of one cache-less attention problem, on the device.  A ViT runs the same
+    problem in every layer: build the plan once per forward and hand it to each call (no per-layer
+    host work or H2D copies)."""
+
+    def __init__(self, seq_lens: Sequence[int], device, kv_rows: int,
+                 key_index: Optional[torch.Tensor] = None, key_lens: Optional[Sequence[int]] = None):
+        self.seq_lens = [int(n) for n in seq_lens]
+        self.n_seq = len(self.seq_lens)
+        self.total = sum(self.seq_lens)
+        ext = torch.tensor(self.seq_lens, dtype=torch.int32)
+        start = torch.zeros(self.n_seq, dtype=torch.int32)
+        if self.n_seq > 1:
+            start[1:] = torch.cumsum(ext, 0)[:-1]
+        if key_index is None:      # self-attention: sequence b's keys are its own rows
+            max_keys = max(self.seq_lens) if self.seq_lens else 0
+            rows = torch.arange(max(max_keys, 1), dtype=torch.int32).unsqueeze(0) + start.unsqueeze(1)
+            key_index = rows.clamp_(max=max(kv_rows - 1, 0))
+            key_lens = self.seq_lens
+        self.key_lens = [int(n) for n in key_lens]
+        self.max_ext = max(self.seq_lens) if self.seq_lens else 0
+        self.max_keys = max(self.key_lens) if self.key_lens else 0
+        self.key_index = key_index.to(device=device, dtype=torch.int32).contiguous()
+        self.ext = ext.to(device)
+        self.start = start.to(device)
+        self.klen = torch.tensor(self.key_lens, dtype=torch.int32).to(device)
+        self.req = torch.arange(self.n_seq, dtype=torch.int32, device=device)
+
+
+def varlen_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, seq_lens: Optional[Sequence[int]],
                      sm_scale: float, causal: bool = False,
                      key_index: Optional[torch.Tensor] = None,
-                     key_lens: Optional[Sequence[int]] = None) -> torch.Tensor:
+                     key_lens: Optional[Sequence[int]] = None,
+                     plan: Optional[VarlenPlan] = None) -> torch.Tensor:
     """q: [sum(seq_lens), H, D]; k, v: [tokens, Hkv, D] (16-bit, D in KERNEL_HEAD_DIMS).
 
     Sequence b's queries are rows [cu[b], cu[b+1]) of q.  By default its keys are the same rows
     of k/v (self-attention, what context_attention_fwd computes for VisionTritonAttention).
     ``key_index`` [n_seq, max_keys] int32 + ``key_lens`` select other key rows per sequence
-    (used for the padded-patch rows of the Mllama tile mask)."""
-    n_seq = len(seq_lens)
-    total = int(sum(seq_lens))
-    if q.shape[0] != total:
-        raise RuntimeError(f"varlen_attention: q has {q.shape[0]} rows, seq_lens sum to {total}")
+    (used for the padded-patch rows of the Mllama tile mask).  ``plan`` = a prebuilt VarlenPlan."""
+    if plan is None:
+        plan = VarlenPlan(seq_lens, q.device, k.shape[0], key_index, key_lens)
+    if q.shape[0] != plan.total:
+        raise RuntimeError(f"varlen_attention: q has {q.shape[0]} rows, seq_lens sum to {plan.total}")
     if q.dtype not in (torch.float16, torch.bfloat16) or q.shape[-1] not in KERNEL_HEAD_DIMS:
         raise RuntimeError("varlen_attention: 16-bit q/k/v with head dim 64 or 128 expected "
                            "(pad the projection weights, see VisionAttention)")
-    dev = q.device
     out = torch.empty_like(q)
-    if total == 0:
+    if plan.total == 0:
         return out
-    ext = torch.tensor(list(seq_lens), dtype=torch.int32)
-    start = torch.zeros(n_seq, dtype=torch.int32)
-    start[1:] = torch.cumsum(ext, 0)[:-1]
-    if key_index is None:
-        max_keys = int(max(seq_lens))
-        rows = torch.arange(max_keys, dtype=torch.int32).unsqueeze(0) + start.unsqueeze(1)
-        key_index = rows.clamp_(max=k.shape[0] - 1).to(dev, non_blocking=True)
-        key_lens = seq_lens
-    klen = torch.tensor(list(key_lens), dtype=torch.int32)
-    ws = _Workspace.get(_native.extend_workspace_bytes(total, n_seq, q.shape[1], q.shape[2], q.dtype), dev)
-    _native.extend_attention(
-        out, q, k, v, key_index, torch.arange(n_seq, dtype=torch.int32, device=dev),
-        klen.to(dev, non_blocking=True), ext.to(dev, non_blocking=True), start.to(dev, non_blocking=True),
-        sm_scale, 0.0, causal, int(max(seq_lens)), int(max(key_lens)), ws)
+    ws = _Workspace.get(_native.extend_workspace_bytes(plan.total, plan.n_seq, q.shape[1], q.shape[2], q.dtype),
+                        q.device)
+    _native.extend_attention(out, q, k, v, plan.key_index, plan.req, plan.klen, plan.ext, plan.start,
+                             sm_scale, 0.0, causal, plan.max_ext, plan.max_keys, ws)
     return out
+
+
+class VisionAttnPlan:
+    """Per-forward plan of VisionAttention: the main problem and, when padding positions exist, the
+    small second problem that recomputes them over the real keys only."""
+
+    def __init__(self, bsz: int, s: int, device, cu_seqlens: Optional[List[int]] = None,
+                 pad_rows: Optional[torch.Tensor] = None):
+        if cu_seqlens is not None:       # VisionTritonAttention: ragged sequences inside the rows
+            seq_lens = [cu_seqlens[i + 1] - cu_seqlens[i] for i in range(len(cu_seqlens) - 1)]
+        else:
+            seq_lens = [s] * bsz
+        self.main = VarlenPlan(seq_lens, device, bsz * s)
+        self.redo = self.redo_rows = None
+        if pad_rows is None:
+            return
+        pad_rows = pad_rows.cpu()
+        if not bool(pad_rows.any()):
+            return
+        q_rows, q_lens, key_rows, key_lens = [], [], [], []
+        for b in range(bsz):
+            pad = torch.nonzero(pad_rows[b]).flatten() + b * s
+            real = torch.nonzero(~pad_rows[b]).flatten() + b * s
+            if pad.numel() == 0:
+                continue
+            if real.numel() == 0:
+                raise RuntimeError("VisionAttention: a sequence made of padding only")
+            q_rows.append(pad)
+            q_lens.append(int(pad.numel()))
+            key_rows.append(real)
+            key_lens.append(int(real.numel()))
+        table = torch.zeros(len(key_rows), max(key_lens), dtype=torch.int32)
+        for i, rows in enumerate(key_rows):
+            table[i, :rows.numel()] = rows.to(torch.int32)
+        self.redo = VarlenPlan(q_lens, device, bsz * s, table, key_lens)
+        self.redo_rows = torch.cat(q_rows).to(device)
 
 
 class ColumnParallelLinear(nn.Module):
@@ -178,40 +233,18 @@ class VisionAttention(nn.Module):
 
     # ---- forward ------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, cu_seqlens: Optional[List[int]] = None,
-                pad_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+                pad_rows: Optional[torch.Tensor] = None, plan: Optional[VisionAttnPlan] = None) -> torch.Tensor:
+        """``plan``: a VisionAttnPlan built once by the caller for all layers (else built here from
+        ``cu_seqlens`` / ``pad_rows``)."""
         bsz, s, _ = x.shape
         Hl, Dp = self.num_heads, self.kernel_head_size
+        if plan is None:
+            plan = VisionAttnPlan(bsz, s, x.device, cu_seqlens, pad_rows)
         qkv, _ = self.qkv_proj(x)
         q, k, v = (t.reshape(bsz * s, Hl, Dp) for t in qkv.chunk(3, dim=-1))
-        if cu_seqlens is not None:       # VisionTritonAttention: ragged sequences inside the rows
-            seq_lens = [cu_seqlens[i + 1] - cu_seqlens[i] for i in range(len(cu_seqlens) - 1)]
-        else:
-            seq_lens = [s] * bsz
-        out = varlen_attention(q, k, v, seq_lens, self.scaling)
-        if pad_rows is not None and bool(pad_rows.any()):
-            self._redo_padding_rows(out, q, k, v, pad_rows)
+        out = varlen_attention(q, k, v, None, self.scaling, plan=plan.main)
+        if plan.redo is not None:
+            redo = varlen_attention(q.index_select(0, plan.redo_rows), k, v, None, self.scaling, plan=plan.redo)
+            out.index_copy_(0, plan.redo_rows, redo)
         out, _ = self.proj(out.reshape(bsz, s, Hl * Dp))
         return out
-
-    def _redo_padding_rows(self, out, q, k, v, pad_rows: torch.Tensor):
-        bsz, s = pad_rows.shape
-        pad_rows = pad_rows.cpu()
-        q_rows, q_lens, key_rows, key_lens = [], [], [], []
-        for b in range(bsz):
-            pad = torch.nonzero(pad_rows[b]).flatten() + b * s
-            real = torch.nonzero(~pad_rows[b]).flatten() + b * s
-            if pad.numel() == 0:
-                continue
-            if real.numel() == 0:
-                raise RuntimeError("VisionAttention: a sequence made of padding only")
-            q_rows.append(pad)
-            q_lens.append(int(pad.numel()))
-            key_rows.append(real)
-            key_lens.append(int(real.numel()))
-        table = torch.zeros(len(key_rows), max(key_lens), dtype=torch.int32)
-        for i, rows in enumerate(key_rows):
-            table[i, :rows.numel()] = rows.to(torch.int32)
-        sel = torch.cat(q_rows).to(q.device)
-        redo = varlen_attention(q.index_select(0, sel), k, v, q_lens, self.scaling,
-                                key_index=table.to(q.device), key_lens=key_lens)
-        out.index_copy_(0, sel, redo)

@@ -11,16 +11,19 @@ from tests import golden
 pytestmark = pytest.mark.gpu
 
 
-def build(dtype):
+def build(dtype, graph_bs=None):
     from scratchpad_amd.model_runner import ModelConfig, ModelRunner, ServerArgs
     g = golden.load("tiny_mllama")
     hidden, inter, nl, Hq, Hkv, vocab = (int(x) for x in g["cfg"])
     cfg = ModelConfig(hidden, inter, nl, Hq, Hkv, vocab, context_len=60, rms_norm_eps=1e-5, rope_theta=500000.0,
                       max_position_embeddings=128, cross_attention_layers=[int(x) for x in g["cross_layers"]])
-    mr = ModelRunner(cfg, ServerArgs(max_total_tokens=96, max_running_requests=3, disable_cuda_graph=True),
+    mr = ModelRunner(cfg, ServerArgs(max_total_tokens=96, max_running_requests=3,
+                                     disable_cuda_graph=graph_bs is None, cuda_graph_bs=graph_bs),
                      dtype=dtype, init_weights=False)
     w = {k[3:]: torch.from_numpy(v).to(mr.device) for k, v in g.items() if k.startswith("w::")}
     mr.model.load_full_state_dict(w)
+    if graph_bs is not None:
+        mr.init_cuda_graphs()
     return g, mr
 
 
@@ -36,12 +39,15 @@ def test_per_head_rmsnorm_matches_reference():
     assert torch.allclose(n(k_view), n(k_view.contiguous()))
 
 
-def test_tiny_mllama_matches_reference_logits():
+@pytest.mark.parametrize("graph_bs", [None, [4]], ids=["eager", "graph-padded-to-4"])
+def test_tiny_mllama_matches_reference_logits(graph_bs):
+    """graph variant: the decode step replays a HIP graph captured for bs 4 (one padded row with
+    encoder_len 0 and seq_len 1) with encoder_lens as a static graph input (cuda_graph_runner.py:201-208)"""
     from scratchpad_amd.forward_info import ForwardMode
     from scratchpad_amd.mllama import get_full_text_row_masked_out_mask
     from scratchpad_amd.model_runner import TpModelWorker
     from scratchpad_amd.schedule_batch import Req, ScheduleBatch
-    g, mr = build(torch.float32)
+    g, mr = build(torch.float32, graph_bs)
     worker = TpModelWorker(mr)
     dev = mr.device
     enc, text = g["encoder_lens"].tolist(), g["text_lens"].tolist()
@@ -80,7 +86,11 @@ def test_tiny_mllama_matches_reference_logits():
     sb.prepare_for_decode()
     assert sb.encoder_cached == [True] * 3
     assert np.array_equal(sb.out_cache_loc.cpu().numpy(), g["decode_out_cache_loc"])
-    out2, _ = worker.forward_batch_generation(sb.get_model_worker_batch())
+    dec = sb.get_model_worker_batch()
+    if graph_bs is not None:
+        fb = __import__("scratchpad_amd.forward_info", fromlist=["ForwardBatch"]).ForwardBatch.init_new(dec, mr)
+        assert mr.graph_runner is not None and mr.graph_runner.can_run(fb), "the decode step must replay a graph"
+    out2, _ = worker.forward_batch_generation(dec)
     want2 = torch.from_numpy(g["decode_logits"])
     dev2 = float((out2.next_token_logits.cpu() - want2).abs().max() / want2.abs().max())
     assert dev2 <= 1e-4, f"decode logits deviate {dev2:.2e}"

@@ -27,7 +27,9 @@ def test_header_declares_the_whole_path():
               "sp_kv_store", "sp_write_req_to_token", "sp_compute_position", "sp_clamp_position",
               "sp_decode_attention", "sp_decode_attention_workspace_bytes", "sp_decode_plan",
               "sp_decode_plan_bytes", "sp_extend_attention",
-              "sp_extend_attention_workspace_bytes", "sp_abi_version", "sp_status_string"]:
+              "sp_extend_attention_workspace_bytes", "sp_abi_version", "sp_status_string",
+              "sp_argmax", "sp_softmax_temperature", "sp_top_k_top_p_min_p_sample",
+              "sp_top_k_top_p_min_p_renorm"]:
         assert s in syms
 
 
