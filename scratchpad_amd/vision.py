@@ -33,20 +33,6 @@ def kernel_head_dim(head_size: int) -> int:
     raise NotImplementedError(f"head size {head_size} > {KERNEL_HEAD_DIMS[-1]}")
 
 
-class _Workspace:
-    """Grow-only scratch shared by every cache-less attention call on a device."""
-    _buf = {}
-
-    @classmethod
-    def get(cls, nbytes: int, device) -> torch.Tensor:
-        key = str(device)
-        cur = cls._buf.get(key)
-        if cur is None or cur.numel() < nbytes:
-            cur = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
-            cls._buf[key] = cur
-        return cur
-
-
 class VarlenPlan:
     """Launch arguments of one cache-less attention problem, on the device.  A ViT runs the same
     problem in every layer: build the plan once per forward and hand it to each call (no per-layer
@@ -74,6 +60,7 @@ class VarlenPlan:
         self.start = start.to(device)
         self.klen = torch.tensor(self.key_lens, dtype=torch.int32).to(device)
         self.req = torch.arange(self.n_seq, dtype=torch.int32, device=device)
+        self.workspace: Optional[torch.Tensor] = None
 
 
 def varlen_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, seq_lens: Optional[Sequence[int]],
@@ -97,47 +84,78 @@ def varlen_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, seq_lens
     out = torch.empty_like(q)
     if plan.total == 0:
         return out
-    ws = _Workspace.get(_native.extend_workspace_bytes(plan.total, plan.n_seq, q.shape[1], q.shape[2], q.dtype),
-                        q.device)
+    nbytes = _native.extend_workspace_bytes(plan.total, plan.n_seq, q.shape[1], q.shape[2], q.dtype)
+    if plan.workspace is None or plan.workspace.numel() < nbytes:     # per plan: plans may run concurrently
+        plan.workspace = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=q.device)
+    ws = plan.workspace
     _native.extend_attention(out, q, k, v, plan.key_index, plan.req, plan.klen, plan.ext, plan.start,
                              sm_scale, 0.0, causal, plan.max_ext, plan.max_keys, ws)
     return out
 
 
 class VisionAttnPlan:
-    """Per-forward plan of VisionAttention: the main problem and, when padding positions exist, the
-    small second problem that recomputes them over the real keys only."""
+    """Per-forward plan of VisionAttention.
+
+    ``main``: every query over every key of its sequence.  ``side`` (optional): a few rows that are
+    better served by a second, tiny launch running on a side stream under the main one:
+      * padding positions, which see the real keys only (the tile-mask semantics, see VisionAttention);
+      * (MOVE_SPILL_ROWS, off) up to ROW_BLOCK/2 real rows that would otherwise open a nearly empty
+        last 128-row block: Mllama's 4 x 1032 = 4128 positions are 32 blocks + 32 rows, i.e. 528
+        workgroups for 512 resident slots (2 per CU).  Measured on the 11B tower: moving them made
+        the forward SLOWER (43.6 vs 40.9 ms) - the gather/scatter of q and o around the main launch
+        costs more than the 16 late workgroups, which run alone and fast.  Kept switchable."""
+    ROW_BLOCK = 128          # query rows per workgroup of extend_mfma_kernel at G = 1
+    MOVE_SPILL_ROWS = False
 
     def __init__(self, bsz: int, s: int, device, cu_seqlens: Optional[List[int]] = None,
                  pad_rows: Optional[torch.Tensor] = None):
+        self.side = self.side_rows = self.main_rows = self.side_stream = None
         if cu_seqlens is not None:       # VisionTritonAttention: ragged sequences inside the rows
             seq_lens = [cu_seqlens[i + 1] - cu_seqlens[i] for i in range(len(cu_seqlens) - 1)]
-        else:
-            seq_lens = [s] * bsz
-        self.main = VarlenPlan(seq_lens, device, bsz * s)
-        self.redo = self.redo_rows = None
-        if pad_rows is None:
+            self.main = VarlenPlan(seq_lens, device, bsz * s)
             return
-        pad_rows = pad_rows.cpu()
-        if not bool(pad_rows.any()):
-            return
-        q_rows, q_lens, key_rows, key_lens = [], [], [], []
+        pad_rows = torch.zeros(bsz, s, dtype=torch.bool) if pad_rows is None else pad_rows.cpu()
+        main_rows, main_lens, side_q, side_lens, side_keys, side_key_lens = [], [], [], [], [], []
         for b in range(bsz):
-            pad = torch.nonzero(pad_rows[b]).flatten() + b * s
-            real = torch.nonzero(~pad_rows[b]).flatten() + b * s
-            if pad.numel() == 0:
-                continue
-            if real.numel() == 0:
+            base = b * s
+            pad = torch.nonzero(pad_rows[b]).flatten()
+            real = torch.nonzero(~pad_rows[b]).flatten()
+            if pad.numel() and real.numel() == 0:
                 raise RuntimeError("VisionAttention: a sequence made of padding only")
-            q_rows.append(pad)
-            q_lens.append(int(pad.numel()))
-            key_rows.append(real)
-            key_lens.append(int(real.numel()))
-        table = torch.zeros(len(key_rows), max(key_lens), dtype=torch.int32)
-        for i, rows in enumerate(key_rows):
-            table[i, :rows.numel()] = rows.to(torch.int32)
-        self.redo = VarlenPlan(q_lens, device, bsz * s, table, key_lens)
-        self.redo_rows = torch.cat(q_rows).to(device)
+            keep = s - pad.numel() if (self.MOVE_SPILL_ROWS and pad.numel() <= self.ROW_BLOCK // 2) else s
+            spill = keep % self.ROW_BLOCK
+            move_real = spill if (self.MOVE_SPILL_ROWS and keep >= 8 * self.ROW_BLOCK
+                                  and 0 < spill <= self.ROW_BLOCK // 2 and keep == s - pad.numel()) else 0
+            if keep == s:                # too many padding rows to move: they stay in main and are redone
+                rows = torch.arange(s)
+                if pad.numel():
+                    side_q.append(pad + base); side_lens.append(int(pad.numel()))
+                    side_keys.append(real + base); side_key_lens.append(int(real.numel()))
+            else:
+                moved = real[real.numel() - move_real:] if move_real else real[:0]
+                rows = real[:real.numel() - move_real]
+                if pad.numel():
+                    side_q.append(pad + base); side_lens.append(int(pad.numel()))
+                    side_keys.append(real + base); side_key_lens.append(int(real.numel()))
+                if move_real:
+                    side_q.append(moved + base); side_lens.append(int(moved.numel()))
+                    side_keys.append(torch.arange(s) + base); side_key_lens.append(s)
+            main_rows.append(rows + base)
+            main_lens.append(int(rows.numel()))
+        natural = all(n == s for n in main_lens)
+        all_keys = (torch.arange(s, dtype=torch.int32).unsqueeze(0)
+                    + (torch.arange(bsz, dtype=torch.int32) * s).unsqueeze(1))
+        self.main = VarlenPlan(main_lens, device, bsz * s, None if natural else all_keys,
+                               None if natural else [s] * bsz)
+        if not natural:
+            self.main_rows = torch.cat(main_rows).to(device)
+        if side_q:
+            table = torch.zeros(len(side_keys), max(side_key_lens), dtype=torch.int32)
+            for i, rows in enumerate(side_keys):
+                table[i, :rows.numel()] = rows.to(torch.int32)
+            self.side = VarlenPlan(side_lens, device, bsz * s, table, side_key_lens)
+            self.side_rows = torch.cat(side_q).to(device)
+            self.side_stream = torch.cuda.Stream(device=device)
 
 
 class ColumnParallelLinear(nn.Module):
@@ -242,9 +260,23 @@ class VisionAttention(nn.Module):
             plan = VisionAttnPlan(bsz, s, x.device, cu_seqlens, pad_rows)
         qkv, _ = self.qkv_proj(x)
         q, k, v = (t.reshape(bsz * s, Hl, Dp) for t in qkv.chunk(3, dim=-1))
-        out = varlen_attention(q, k, v, None, self.scaling, plan=plan.main)
-        if plan.redo is not None:
-            redo = varlen_attention(q.index_select(0, plan.redo_rows), k, v, None, self.scaling, plan=plan.redo)
-            out.index_copy_(0, plan.redo_rows, redo)
+        if plan.side is None:
+            out = varlen_attention(q, k, v, None, self.scaling, plan=plan.main)
+        else:
+            cur = torch.cuda.current_stream()
+            plan.side_stream.wait_stream(cur)
+            with torch.cuda.stream(plan.side_stream):
+                o_side = varlen_attention(q.index_select(0, plan.side_rows), k, v, None, self.scaling,
+                                          plan=plan.side)
+            if plan.main_rows is None:
+                out = varlen_attention(q, k, v, None, self.scaling, plan=plan.main)
+            else:
+                o_main = varlen_attention(q.index_select(0, plan.main_rows), k, v, None, self.scaling,
+                                          plan=plan.main)
+                out = o_main.new_empty(bsz * s, Hl, Dp)
+                out.index_copy_(0, plan.main_rows, o_main)
+            cur.wait_stream(plan.side_stream)
+            o_side.record_stream(cur)
+            out.index_copy_(0, plan.side_rows, o_side)
         out, _ = self.proj(out.reshape(bsz, s, Hl * Dp))
         return out

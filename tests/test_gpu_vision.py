@@ -107,7 +107,7 @@ def test_tower_matches_reference_fixture(dtype, tol, tag):
     assert rel(got, ov.forward(sh, w, pixels, ids, mask)) <= tol
 
 
-def test_tower_at_11b_widths_against_oracle():
+def test_tower_at_11b_widths_against_oracle(monkeypatch):
     """Two 560x560 tiles -> 2 x 1608 positions, hidden 1280, 16 heads of 80, 1 local + 1 global layer:
     the real per-layer shape (4 tiles halve to keep the fp32 CPU check in seconds)."""
     from scratchpad_amd.mllama_vision import MllamaVisionModel
@@ -139,6 +139,14 @@ def test_tower_at_11b_widths_against_oracle():
     want = ov.forward(sh, w, pixels, ids, mask)
     assert got.shape == (1, 1, 2, 1601, 3840)      # final + taps before and after layer 0
     assert rel(got, want) <= 2e-2
+    # the switchable row partition (padding + block-spill rows in the side launch) computes the same thing
+    from scratchpad_amd.vision import VisionAttnPlan
+    monkeypatch.setattr(VisionAttnPlan, "MOVE_SPILL_ROWS", True)
+    plan = VisionAttnPlan(1, 2 * 1608, "cuda", pad_rows=__import__("scratchpad_amd.mllama_vision", fromlist=["x"])
+                          .padding_positions(mask.reshape(1, 2), 1601, 1608))
+    assert plan.main_rows is not None and plan.main.seq_lens == [3200] and plan.side.seq_lens == [14, 2]
+    got2 = model(pixels.cuda(), ids.cuda(), mask)
+    assert rel(got2, want) <= 2e-2 and rel(got2, got.float().cpu()) <= 1e-2
 
 
 def test_conditional_generation_computes_cross_attention_states_from_mm_inputs():
