@@ -45,7 +45,11 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true",
                     help="run the forward on the overlap worker's thread/stream (tp_worker_client.py)")
-    ap.add_argument("--mode", default="decode", choices=["decode", "prefill"],
+    ap.add_argument("--requests", type=int, default=512, help="serve mode: number of requests in the trace")
+    ap.add_argument("--max-input", type=int, default=2048, help="serve mode: prompts are U[128, max-input]")
+    ap.add_argument("--max-output", type=int, default=128, help="serve mode: outputs are U[16, max-output]")
+    ap.add_argument("--rate", type=float, default=0.0, help="serve mode: Poisson arrival rate (req/s); 0 = all at t=0")
+    ap.add_argument("--mode", default="decode", choices=["decode", "prefill", "serve"],
                     help="decode = the headline metric; prefill = config 3 (ragged prefill, TTFT)")
     ap.add_argument("--prefix", type=int, default=0, help="prefill mode: shared cached prefix length")
     ap.add_argument("--max-prefill-tokens", type=int, default=16384,
@@ -271,6 +275,165 @@ def prefill_main(args, rank, local_rank, world):
     print(json.dumps(out), flush=True)
 
 
+
+def serve_main(args, rank, local_rank, world):
+    """A synthetic continuous-batching trace through the scheduler-side producers: requests arrive
+    (all at t = 0, or Poisson at --rate), are admitted FCFS into extend batches (<= --max-prefill-tokens
+    new tokens, prefix looked up in the RadixCache), merged into the running batch, decoded by HIP-graph
+    replay until their output length is reached, and handed back to the cache.  The loop is the
+    reference's get_next_batch_to_run order (prefill first, else decode; scheduler.py) without its
+    policy knobs; metrics follow tools/benchmark/common.py:306-420 (TTFT, TPOT = (latency - ttft) /
+    (output_len - 1), ITL, output throughput)."""
+    import random
+    from scratchpad_amd.model_runner import ModelConfig, ModelRunner, ServerArgs, TpModelWorker
+    from scratchpad_amd.radix_cache import RadixCache
+    from scratchpad_amd.schedule_batch import Req, ScheduleBatch
+    rnd = random.Random(rank)
+    n_req = args.requests
+    max_running = min(args.bs, n_req)
+    in_lo, in_hi = 128, args.max_input
+    out_lo, out_hi = 16, args.max_output
+    vocab = 128256
+    shared = [rnd.randrange(vocab) for _ in range(args.prefix)]
+    prompts = [shared + [rnd.randrange(vocab) for _ in range(rnd.randint(in_lo, in_hi))] for _ in range(n_req)]
+    out_lens = [rnd.randint(out_lo, out_hi) for _ in range(n_req)]
+    arrivals = [0.0] * n_req
+    if args.rate > 0:
+        t = 0.0
+        for i in range(n_req):
+            t += rnd.expovariate(args.rate)
+            arrivals[i] = t
+    ctx_len = args.prefix + in_hi + out_hi + 8
+    cfg = ModelConfig.llama3_8b(ctx_len)
+    if args.layers:
+        cfg.num_hidden_layers = args.layers
+    pool = max_running * (args.prefix + in_hi + out_hi) + 4096
+    buckets = sorted(set([1, 2, 4] + list(range(8, max_running + 1, 8)) + [max_running]))
+    sargs = ServerArgs(max_total_tokens=pool, max_running_requests=max_running, disable_cuda_graph=args.no_graph,
+                       cuda_graph_max_bs=max_running, cuda_graph_bs=buckets)
+    mr = ModelRunner(cfg, sargs, dtype=torch.bfloat16, gpu_id=local_rank, seed=rank)
+    mr.init_cuda_graphs()
+    worker = TpModelWorker(mr)
+    alloc, r2t, dev = mr.token_to_kv_pool_allocator, mr.req_to_token_pool, mr.device
+    tree = RadixCache(r2t, alloc)
+
+    def run_trace():
+        tree.reset()
+        r2t.clear()
+        alloc.clear()
+        reqs = [Req(str(i), list(prompts[i])) for i in range(n_req)]
+        waiting = list(range(n_req))
+        running = None
+        first_t, last_t, itl = [None] * n_req, [None] * n_req, []
+        reserved = 0            # output tokens promised to running requests but not yet allocated
+        steps = {"extend": 0, "decode": 0, "hit_tokens": 0}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        now = lambda: time.perf_counter() - t0
+        while waiting or running is not None:
+            n_run = 0 if running is None else len(running.reqs)
+            admit, budget = [], args.max_prefill_tokens
+            while waiting and n_run + len(admit) < max_running and arrivals[waiting[0]] <= now():
+                r = reqs[waiting[0]]
+                r.init_next_round_input(tree)
+                need = r.extend_input_len + out_lens[waiting[0]] - 1
+                if admit and r.extend_input_len > budget:
+                    break
+                if alloc.available_size() + tree.evictable_size() - reserved < need:
+                    break
+                tree.inc_lock_ref(r.last_node)
+                steps["hit_tokens"] += r.prefix_len
+                admit.append(waiting.pop(0))
+                budget -= r.extend_input_len
+                reserved += out_lens[admit[-1]] - 1      # one slot per decode step of this request
+            if admit:
+                nb = ScheduleBatch([reqs[i] for i in admit], r2t, alloc, dev, tree_cache=tree)
+                nb.prepare_for_extend()
+                _, ids = worker.forward_batch_generation(nb.get_model_worker_batch())
+                toks = ids.tolist()                     # first tokens reach the host
+                t = now()
+                for i, tok in zip(admit, toks):
+                    reqs[i].output_ids.append(tok)
+                    first_t[i] = last_t[i] = t
+                nb.output_ids = ids
+                steps["extend"] += 1
+                done = [i for i in admit if len(reqs[i].output_ids) >= out_lens[i]]
+                if done:
+                    for i in done:
+                        reqs[i].finished_reason = "length"
+                        reserved -= out_lens[i] - 1
+                        tree.cache_finished_req(reqs[i])
+                    nb.filter_batch()
+                # the prompts' KV becomes shareable at once (the reference's prefill result handler calls
+                # cache_unfinished_req for every request that keeps running)
+                for r in nb.reqs:
+                    tree.cache_unfinished_req(r)
+                if nb.reqs:
+                    if running is None:
+                        running = nb
+                    else:
+                        running.merge_batch(nb)
+                continue
+            if running is None:                         # idle until the next arrival
+                time.sleep(max(0.0, arrivals[waiting[0]] - now()))
+                continue
+            if not running.check_decode_mem():
+                raise RuntimeError("serve trace: KV pool exhausted despite the admission reserve")
+            running.prepare_for_decode()
+            _, ids = worker.forward_batch_generation(running.get_model_worker_batch())
+            toks = ids.tolist()
+            t = now()
+            running.output_ids = ids
+            steps["decode"] += 1
+            any_done = False
+            for r, tok in zip(running.reqs, toks):
+                i = int(r.rid)
+                r.output_ids.append(tok)
+                itl.append(t - last_t[i])
+                last_t[i] = t
+                reserved -= 1
+                if len(r.output_ids) >= out_lens[i]:
+                    r.finished_reason = "length"
+                    tree.cache_finished_req(r)
+                    any_done = True
+            if any_done:
+                running.filter_batch()
+                if not running.reqs:
+                    running = None
+        dur = now()
+        # conservation: every KV slot is free or owned by the prefix cache, every request row is back
+        assert alloc.available_size() + tree.total_size() == alloc.size, "KV slots leaked"
+        assert r2t.available_size() == r2t.size and tree.protected_size() == 0 and reserved == 0
+        assert all(len(reqs[i].output_ids) == out_lens[i] for i in range(n_req))
+        ttft = sorted(first_t[i] - arrivals[i] for i in range(n_req))
+        tpot = sorted((last_t[i] - first_t[i]) / (out_lens[i] - 1) for i in range(n_req) if out_lens[i] > 1)
+        return dur, ttft, tpot, sorted(itl), steps
+
+    run_trace()                                         # warm-up pass (allocator, caches, clocks)
+    dur, ttft, tpot, itl, steps = run_trace()
+    if rank != 0:
+        return
+    pct = lambda xs, q: xs[min(len(xs) - 1, int(len(xs) * q))] * 1e3
+    total_in, total_out = sum(len(p) for p in prompts), sum(out_lens)
+    out = {"metric": "serve_output_tokens_per_sec", "value": round(total_out / dur, 1), "unit": "tokens/s",
+           "n_gpus": world, "steps": steps["extend"] + steps["decode"], "warmup": 1,
+           "ms_per_step": round(dur * 1e3 / (steps["extend"] + steps["decode"]), 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+           "data": "synthetic (random-init weights, random token ids, greedy sampling)",
+           "config": {"workload": f"llama3-8b TP=1 bf16 continuous batching: {n_req} requests, prompts U[{in_lo},{in_hi}]"
+                                  f" (+{args.prefix} shared prefix), outputs U[{out_lo},{out_hi}], max running {max_running}, "
+                                  f"arrival {'all at t=0' if args.rate <= 0 else f'Poisson {args.rate}/s'}, "
+                                  f"extend batches <= {args.max_prefill_tokens} tokens, RadixCache on",
+                      "input_tokens": total_in, "output_tokens": total_out, "extend_steps": steps["extend"],
+                      "decode_steps": steps["decode"], "prefix_cache_hit_tokens": steps["hit_tokens"]},
+           "duration_s": round(dur, 3), "total_tokens_per_sec": round((total_in + total_out) / dur, 1),
+           "ttft_ms": {"p50": round(pct(ttft, 0.5), 1), "p99": round(pct(ttft, 0.99), 1),
+                       "mean": round(sum(ttft) / len(ttft) * 1e3, 1)},
+           "tpot_ms": {"p50": round(pct(tpot, 0.5), 2), "p99": round(pct(tpot, 0.99), 2),
+                       "mean": round(sum(tpot) / len(tpot) * 1e3, 2)},
+           "itl_ms": {"p50": round(pct(itl, 0.5), 2), "p99": round(pct(itl, 0.99), 2)}}
+    print(json.dumps(out), flush=True)
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -295,6 +458,9 @@ def main():
         if args.steps == 64:
             args.steps, args.warmup = 3, 1
         prefill_main(args, rank, local_rank, world)
+        return
+    if args.mode == "serve":
+        serve_main(args, rank, local_rank, world)
         return
     mr, ctx, gen = build_engine(args, local_rank, seed=rank)
     if not args.no_graph:

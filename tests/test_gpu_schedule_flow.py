@@ -280,3 +280,24 @@ def test_radix_cache_prefix_reuse_chunked_prefill_and_retraction():
     close(out.next_token_logits, _fresh_prefill_logits(shape, w, e.origin_input_ids), "E after eviction")
     # conservation: every slot is either free, cached, or held by the running request
     assert alloc.available_size() + tree.total_size() + e.extend_input_len + len(hog) == 96
+
+
+def test_serve_trace_mode_of_the_bench_runs_and_conserves_slots():
+    """bench.py --mode serve at toy size: admission, RadixCache hits on a shared prefix, merge into the
+    running batch, graph-replayed decode over changing batch sizes, finish + cache hand-back.  The
+    mode asserts slot conservation itself; here the JSON line is checked."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--mode", "serve", "--layers", "2", "--requests", "40",
+           "--bs", "12", "--max-input", "300", "--max-output", "24", "--prefix", "64", "--max-prefill-tokens", "1024"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    cfg = line["config"]
+    assert line["metric"] == "serve_output_tokens_per_sec" and line["value"] > 0
+    assert cfg["prefix_cache_hit_tokens"] >= 64 * 20, "later requests reuse the shared prefix"
+    assert cfg["extend_steps"] >= 4 and cfg["decode_steps"] >= 23
+    assert line["ttft_ms"]["p50"] > 0 and line["tpot_ms"]["p50"] > 0
