@@ -557,6 +557,8 @@ def main():
                     "algorithmic_bytes_per_launch": int(alg)}
 
     if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
         return
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.bs * args.steps / elapsed
@@ -580,7 +582,7 @@ def main():
     }
     if roofline is not None:
         out["roofline"] = roofline
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:     # the CPU leg is timed on rank 0 of the 1-GPU run only
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)
     if world > 1:
