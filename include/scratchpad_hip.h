@@ -184,6 +184,15 @@ SP_API int sp_top_k_top_p_min_p_renorm(const float* probs, int64_t row_stride, c
                                 const float* top_ps, const float* min_ps, int batch_size, int vocab,
                                 float* out, int64_t out_stride, int32_t* keep_count, void* stream);
 
+/* ---- Small-batch projection: out[M,N] = x[M,K] . w[N,K]^T, M <= 16, K % 32 == 0, fp16/bf16,
+ *      fp32 accumulation, one rounding.  Serves F.linear inside QKVParallelLinear /
+ *      MergedColumnParallelLinear / RowParallelLinear.forward (nn/layers/linear.py:423-470, 696-760,
+ *      1033-1155) and the LM-head matmul (nn/layers/logits_processor.py:340-376) when the step has
+ *      at most 16 tokens; a weight-streaming kernel (HBM-bound).  Returns SP_ERR_UNSUPPORTED for
+ *      other shapes: the caller keeps the library GEMM.  Strides in elements.                     */
+SP_API int sp_gemm_skinny(void* out, const void* x, const void* w, int M, int N, int K, int64_t x_stride,
+                   int64_t w_stride, int64_t out_stride, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

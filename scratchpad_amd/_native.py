@@ -48,6 +48,7 @@ SIGNATURES = {
     "sp_softmax_temperature": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp]),
     "sp_top_k_top_p_min_p_sample": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "sp_top_k_top_p_min_p_renorm": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "sp_gemm_skinny": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp]),
 }
 
 
@@ -401,3 +402,37 @@ def top_k_top_p_min_p_renorm(probs: torch.Tensor, top_ks: Optional[torch.Tensor]
                                               bs, vocab, out.data_ptr(), out.stride(0), _ptr(cnt), _stream()),
            "sp_top_k_top_p_min_p_renorm")
     return (out, cnt) if return_keep_count else out
+
+
+# --------------------------------------------------------------------------- small-batch projection
+SKINNY_MAX_ROWS = 16
+_SKINNY_ON = os.environ.get("SP_SKINNY_GEMM", "1") != "0"
+
+
+def skinny_gemm_pays(M: int, N: int, K: int) -> bool:
+    """Where the weight-streaming kernel measured faster than hipBLASLt on MI355X
+    (tools/bench_gemv.py, Llama-3-8B shapes): every lane's x fragment is re-read from L2 per k-step,
+    so the win shrinks as rows fill the 16-wide tile and with long rows (down_proj)."""
+    if M <= 16 and N * K <= 4096 * 4096:
+        return True                       # o_proj-sized: 11 vs 19 us at every M <= 16
+    if M <= 2 and K <= 8192:
+        return True                       # bs 1-2: qkv 13 vs 19, gate_up 44 vs 60, lm_head 166 vs 179 us
+    return M <= 8 and K <= 8192 and N <= 65536
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """x @ weight.T.  Small-batch 16-bit products go to the weight-streaming kernel
+    (sp_gemm_skinny) where it pays; everything else is the library GEMM, exactly F.linear."""
+    if (_SKINNY_ON and x.is_cuda and x.dim() == 2 and 0 < x.shape[0] <= SKINNY_MAX_ROWS
+            and skinny_gemm_pays(x.shape[0], weight.shape[0], x.shape[1])
+            and x.dtype in (torch.float16, torch.bfloat16) and weight.dtype == x.dtype
+            and x.shape[1] % 32 == 0 and x.stride(1) == 1 and weight.stride(1) == 1
+            and x.stride(0) % 8 == 0 and weight.stride(0) % 8 == 0
+            and x.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0):
+        M, K = x.shape
+        N = weight.shape[0]
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+        _check(load().sp_gemm_skinny(out.data_ptr(), x.data_ptr(), weight.data_ptr(), M, N, K, x.stride(0),
+                                     weight.stride(0), out.stride(0), _dt(x), _stream()), "sp_gemm_skinny")
+        return out
+    return torch.nn.functional.linear(x, weight)

@@ -1,0 +1,119 @@
+// out[M, N] = x[M, K] . w[N, K]^T for M <= 16 (decode at small batch): a weight-streaming kernel.
+//
+// Call sites it serves: the four per-layer projections and the LM head at decode time -
+// QKVParallelLinear / RowParallelLinear / MergedColumnParallelLinear.forward (nn/layers/linear.py:
+// 696-760, 423-470, 1033-1155 -> F.linear) and LogitsProcessor._get_logits
+// (nn/layers/logits_processor.py:340-376).  Above 16 rows the library GEMM (hipBLASLt) stays.
+//
+// At M <= 16 the product is a pure stream of the weight matrix (2 flop per weight byte per row):
+// HBM-bound.  hipBLASLt runs these shapes at 2.5-5.0 TB/s of weight bytes (bs 1, Llama-3-8B:
+// o_proj 13.6 us for 33.5 MB, qkv 15.5 us for 50 MB); a kernel shaped for the stream does better:
+//   * one workgroup = 16 output columns (16 rows of W), its 8 waves take the k-steps round-robin,
+//     so at any moment the workgroup reads 512 contiguous bytes of each of its 16 rows;
+//   * per k-step (32 elements) a lane loads 16 B of W and 16 B of x straight into the A / B operand
+//     registers of v_mfma_f32_16x16x32 (rows of W are the A rows, rows of x the B columns) - no LDS
+//     on the way in; x (<= 16 x K, <= 460 KB) is re-read from L2 by every workgroup;
+//   * 8 k-steps of loads are in flight per wave before the first MFMA consumes one;
+//   * the 8 waves' 16x16 partial tiles are summed through LDS in a fixed order (deterministic),
+//     rounded once, and stored.
+#include "sp_common.h"
+
+namespace sp {
+
+typedef float f32x4_g __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_g __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_g __attribute__((ext_vector_type(8)));
+
+template <typename Tag>
+__device__ __forceinline__ f32x4_g mfma_g(const u32x4& a, const u32x4& b, const f32x4_g& c);
+template <>
+__device__ __forceinline__ f32x4_g mfma_g<bf16_tag>(const u32x4& a, const u32x4& b, const f32x4_g& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_g, a), __builtin_bit_cast(bf16x8_g, b),
+                                                 c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4_g mfma_g<f16_tag>(const u32x4& a, const u32x4& b, const f32x4_g& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_g, a), __builtin_bit_cast(f16x8_g, b),
+                                                c, 0, 0, 0);
+}
+
+struct SkinnyArgs {
+  const char* x;
+  const char* w;
+  void* out;
+  int M, N, K;
+  int64_t x_stride, w_stride, out_stride;   // elements
+};
+
+constexpr int kSkWaves = 8;
+constexpr int kSkUnroll = 8;
+
+template <typename Tag>
+__global__ __launch_bounds__(kSkWaves * 64) void gemm_skinny_kernel(SkinnyArgs a) {
+  typedef Elem<Tag> E;
+  __shared__ float red[kSkWaves][16 * 16 + 16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r16 = lane & 15, q = lane >> 4;            // operand row / k-quarter of the lane
+  const int n0 = blockIdx.x * 16;
+  const int n = min(n0 + r16, a.N - 1);                // clamp: columns past N are computed, never stored
+  const bool mrow = r16 < a.M;
+  const char* wp = a.w + ((int64_t)n * a.w_stride + 8 * q) * 2;
+  const char* xp = a.x + ((int64_t)min(r16, a.M - 1) * a.x_stride + 8 * q) * 2;
+  const int ksteps = a.K / 32;
+  f32x4_g acc = {0.f, 0.f, 0.f, 0.f};
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  // this wave's k-steps: wave, wave + 8, ...; processed in groups of kSkUnroll with all loads first
+  int ks = wave;
+  for (; ks + (kSkUnroll - 1) * kSkWaves < ksteps; ks += kSkUnroll * kSkWaves) {
+    u32x4 wf[kSkUnroll], xf[kSkUnroll];
+#pragma unroll
+    for (int u = 0; u < kSkUnroll; ++u) {
+      const int64_t off = (int64_t)(ks + u * kSkWaves) * 64;
+      wf[u] = ld16(wp + off);
+      xf[u] = mrow ? ld16(xp + off) : zero;
+    }
+#pragma unroll
+    for (int u = 0; u < kSkUnroll; ++u) acc = mfma_g<Tag>(wf[u], xf[u], acc);
+  }
+  for (; ks < ksteps; ks += kSkWaves) {
+    const int64_t off = (int64_t)ks * 64;
+    const u32x4 wf = ld16(wp + off);
+    const u32x4 xf = mrow ? ld16(xp + off) : zero;
+    acc = mfma_g<Tag>(wf, xf, acc);
+  }
+  // acc[r] = partial of out[m = r16][n0 + 4q + r]; sum the waves in wave order
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][(4 * q + r) * 17 + r16] = acc[r];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = 4 * q + r;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < kSkWaves; ++w) s += red[w][col * 17 + r16];
+      if (mrow && n0 + col < a.N) E::store(a.out, (int64_t)r16 * a.out_stride + n0 + col, s);
+    }
+  }
+}
+
+}  // namespace sp
+
+extern "C" int sp_gemm_skinny(void* out, const void* x, const void* w, int M, int N, int K, int64_t x_stride,
+                              int64_t w_stride, int64_t out_stride, int dtype, void* stream) {
+  SP_CHECK_ARG(M >= 0 && N >= 0 && K > 0);
+  if (M == 0 || N == 0) return SP_OK;
+  SP_CHECK_ARG(out && x && w);
+  if (M > 16 || K % 32 != 0) return SP_ERR_UNSUPPORTED;
+  if (dtype != SP_BF16 && dtype != SP_F16) return SP_ERR_UNSUPPORTED;
+  SP_CHECK_ARG(x_stride % 8 == 0 && w_stride % 8 == 0 && x_stride >= K && w_stride >= K && out_stride >= N);
+  SP_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0);
+  sp::SkinnyArgs a{(const char*)x, (const char*)w, out, M, N, K, x_stride, w_stride, out_stride};
+  const dim3 grid((N + 15) / 16);
+  if (dtype == SP_BF16)
+    sp::gemm_skinny_kernel<sp::bf16_tag><<<grid, sp::kSkWaves * 64, 0, (hipStream_t)stream>>>(a);
+  else
+    sp::gemm_skinny_kernel<sp::f16_tag><<<grid, sp::kSkWaves * 64, 0, (hipStream_t)stream>>>(a);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}

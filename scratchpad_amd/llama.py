@@ -17,6 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _native
 from .attention import RadixAttention
 from .distributed import (divide, get_tensor_model_parallel_rank,
                           get_tensor_model_parallel_world_size, tensor_model_parallel_all_gather,
@@ -71,7 +72,7 @@ class QKVParallelLinear(_ShardedLinear):
         return torch.cat((qs, ks, vs), 0)
 
     def forward(self, x):
-        return F.linear(x, self.weight), None
+        return _native.linear(x, self.weight), None
 
 
 class MergedColumnParallelLinear(_ShardedLinear):
@@ -92,7 +93,7 @@ class MergedColumnParallelLinear(_ShardedLinear):
         return torch.cat(parts, 0)
 
     def forward(self, x):
-        return F.linear(x, self.weight), None
+        return _native.linear(x, self.weight), None
 
 
 class RowParallelLinear(_ShardedLinear):
@@ -111,7 +112,7 @@ class RowParallelLinear(_ShardedLinear):
         return full[:, rank * n:(rank + 1) * n]
 
     def forward(self, x):
-        out = F.linear(x, self.weight)
+        out = _native.linear(x, self.weight)
         if self.reduce_results and self.tp_size > 1:
             out = tensor_model_parallel_all_reduce(out)
         return out, None
@@ -173,7 +174,7 @@ class LogitsProcessor(nn.Module):
         else:
             last_index = torch.cumsum(forward_batch.extend_seq_lens, dim=0) - 1
             pruned = hidden_states[last_index]
-        logits = torch.matmul(pruned.to(lm_head.weight.dtype), lm_head.weight.T)
+        logits = _native.linear(pruned.to(lm_head.weight.dtype), lm_head.weight)
         if self.do_tensor_parallel_all_gather:
             logits = tensor_model_parallel_all_gather(logits)
         logits = logits[:, : self.config.vocab_size].float()

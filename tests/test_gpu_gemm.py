@@ -1,0 +1,56 @@
+"""sp_gemm_skinny (decode projections at <= 16 rows) against an fp32 matmul of the same 16-bit
+operands: fp32 accumulation and a single rounding, so the result may differ from the exact value
+by one rounding of the output dtype plus fp32 summation noise."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def check(got, x, w, dtype):
+    ref = x.float().cpu() @ w.float().cpu().T
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    err = (got.float().cpu() - ref).abs()
+    assert bool((err <= eps * ref.abs() + 1e-4 * ref.abs().max()).all()), float(err.max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [1, 3, 8, 16])
+@pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 14336), (100, 64), (16, 32), (4104, 2048)])
+def test_skinny_gemm_matches_fp32_reference(dtype, M, N, K):
+    from scratchpad_amd import _native
+    g = torch.Generator().manual_seed(M * 1000 + N + K)
+    x = torch.randn(M, K, generator=g).to(dtype).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dtype).cuda()
+    got = torch.empty(M, N, dtype=dtype, device="cuda")      # the kernel itself, whatever the dispatch rule says
+    _native._check(_native.load().sp_gemm_skinny(got.data_ptr(), x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0),
+                                                 w.stride(0), got.stride(0), _native._dt(x), _native._stream()),
+                   "sp_gemm_skinny")
+    check(got, x, w, dtype)
+    got = _native.linear(x, w)
+    assert got.shape == (M, N) and got.dtype == dtype
+    check(got, x, w, dtype)
+    # the library path on the same operands agrees to the same bound
+    check(torch.nn.functional.linear(x, w), x, w, dtype)
+
+
+def test_skinny_gemm_views_fallbacks_and_determinism():
+    from scratchpad_amd import _native
+    g = torch.Generator().manual_seed(7)
+    big = torch.randn(16, 3 * 4096, generator=g).bfloat16().cuda()
+    w = (torch.randn(512, 4096, generator=g) * 0.05).bfloat16().cuda()
+    x = big[:5, 4096:8192]                                   # row-strided view, 16-byte aligned
+    got = _native.linear(x, w)
+    check(got, x, w, torch.bfloat16)
+    assert torch.equal(got, _native.linear(x, w)), "fixed summation order: bit-identical reruns"
+    x17 = torch.randn(17, 4096, generator=g).bfloat16().cuda()      # > 16 rows: library GEMM
+    assert torch.equal(_native.linear(x17, w), torch.nn.functional.linear(x17, w))
+    xk = torch.randn(4, 48, generator=g).bfloat16().cuda()          # K % 32 != 0: library GEMM
+    wk = torch.randn(8, 48, generator=g).bfloat16().cuda()
+    assert torch.equal(_native.linear(xk, wk), torch.nn.functional.linear(xk, wk))
+    x32 = torch.randn(2, 64, generator=g).cuda()                    # fp32: library GEMM
+    w32 = torch.randn(8, 64, generator=g).cuda()
+    assert torch.equal(_native.linear(x32, w32), torch.nn.functional.linear(x32, w32))
+    lib = __import__("ctypes").CDLL(_native.lib_path())
+    assert lib.sp_gemm_skinny(None, None, None, 4, 8, 64, 64, 64, 8, 2, None) == -1      # null pointers
+    assert lib.sp_gemm_skinny(1, 1, 1, 17, 8, 64, 64, 64, 8, 2, None) == -2              # unsupported rows

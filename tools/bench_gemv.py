@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Weight-streaming rate of the small-batch projections: sp_gemm_skinny vs the library GEMM."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scratchpad_amd import _native  # noqa: E402
+
+
+def timeit(fn, n=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+def main():
+    shapes = {"qkv": (6144, 4096), "o": (4096, 4096), "gate_up": (28672, 4096), "down": (4096, 14336),
+              "lm_head": (128256, 4096)}
+    for M in (1, 8, 16):
+        tot_a = tot_b = 0.0
+        for name, (N, K) in shapes.items():
+            x = torch.randn(M, K, device="cuda").bfloat16()
+            ws = [(torch.randn(N, K, device="cuda") * 0.02).bfloat16() for _ in range(1 if name == "lm_head" else 6)]
+            it = [0]
+
+            def nxt():
+                it[0] += 1
+                return ws[it[0] % len(ws)]
+            a = timeit(lambda: _native.linear(x, nxt()))
+            b = timeit(lambda: torch.nn.functional.linear(x, nxt()))
+            gb = N * K * 2 / 1e9
+            print(f"M={M:2d} {name:8s} N={N:6d} K={K:5d}: skinny {a:7.1f} us ({gb / a * 1e3:5.2f} TB/s)   "
+                  f"library {b:7.1f} us ({gb / b * 1e3:5.2f} TB/s)", flush=True)
+            if name != "lm_head":
+                tot_a += a
+                tot_b += b
+        print(f"M={M:2d} per-layer total: skinny {tot_a:.1f} us, library {tot_b:.1f} us", flush=True)
+
+
+if __name__ == "__main__":
+    main()
