@@ -46,55 +46,77 @@ struct SkinnyArgs {
 };
 
 constexpr int kSkWaves = 8;
-constexpr int kSkUnroll = 8;
 
-template <typename Tag>
+// NB = 16-column blocks per workgroup: one x fragment feeds NB MFMAs (x traffic out of L2 drops to
+// 1/NB of the weight stream).  Measured on MI355X it is SLOWER than NB = 1 wherever N allows it
+// (gate_up 28672x4096 at 1 row: NB 2 53.9 us vs NB 1 44.1 us; LM head 128256x4096: NB 4 206 us vs
+// NB 1 166 us; same sign at 8 rows) - fewer, fatter workgroups lose more than the x reads cost -
+// so launch_skinny always takes NB = 1; the parameter stays for re-measurement.
+template <typename Tag, int NB, int UNROLL>
 __global__ __launch_bounds__(kSkWaves * 64) void gemm_skinny_kernel(SkinnyArgs a) {
   typedef Elem<Tag> E;
-  __shared__ float red[kSkWaves][16 * 16 + 16];
+  __shared__ float red[kSkWaves][NB][16 * 17];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r16 = lane & 15, q = lane >> 4;            // operand row / k-quarter of the lane
-  const int n0 = blockIdx.x * 16;
-  const int n = min(n0 + r16, a.N - 1);                // clamp: columns past N are computed, never stored
+  const int n0 = blockIdx.x * 16 * NB;
   const bool mrow = r16 < a.M;
-  const char* wp = a.w + ((int64_t)n * a.w_stride + 8 * q) * 2;
+  const char* wp[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = min(n0 + 16 * nb + r16, a.N - 1);    // clamp: columns past N are computed, never stored
+    wp[nb] = a.w + ((int64_t)n * a.w_stride + 8 * q) * 2;
+  }
   const char* xp = a.x + ((int64_t)min(r16, a.M - 1) * a.x_stride + 8 * q) * 2;
   const int ksteps = a.K / 32;
-  f32x4_g acc = {0.f, 0.f, 0.f, 0.f};
-  const u32x4 zero = {0u, 0u, 0u, 0u};
-  // this wave's k-steps: wave, wave + 8, ...; processed in groups of kSkUnroll with all loads first
-  int ks = wave;
-  for (; ks + (kSkUnroll - 1) * kSkWaves < ksteps; ks += kSkUnroll * kSkWaves) {
-    u32x4 wf[kSkUnroll], xf[kSkUnroll];
+  f32x4_g acc[NB];
 #pragma unroll
-    for (int u = 0; u < kSkUnroll; ++u) {
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4_g{0.f, 0.f, 0.f, 0.f};
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  // this wave's k-steps: wave, wave + 8, ...; processed in groups of UNROLL with all loads first
+  int ks = wave;
+  for (; ks + (UNROLL - 1) * kSkWaves < ksteps; ks += UNROLL * kSkWaves) {
+    u32x4 wf[UNROLL][NB], xf[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
       const int64_t off = (int64_t)(ks + u * kSkWaves) * 64;
-      wf[u] = ld16(wp + off);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) wf[u][nb] = ld16(wp[nb] + off);
       xf[u] = mrow ? ld16(xp + off) : zero;
     }
 #pragma unroll
-    for (int u = 0; u < kSkUnroll; ++u) acc = mfma_g<Tag>(wf[u], xf[u], acc);
+    for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_g<Tag>(wf[u][nb], xf[u], acc[nb]);
   }
   for (; ks < ksteps; ks += kSkWaves) {
     const int64_t off = (int64_t)ks * 64;
-    const u32x4 wf = ld16(wp + off);
     const u32x4 xf = mrow ? ld16(xp + off) : zero;
-    acc = mfma_g<Tag>(wf, xf, acc);
-  }
-  // acc[r] = partial of out[m = r16][n0 + 4q + r]; sum the waves in wave order
 #pragma unroll
-  for (int r = 0; r < 4; ++r) red[wave][(4 * q + r) * 17 + r16] = acc[r];
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_g<Tag>(ld16(wp[nb] + off), xf, acc[nb]);
+  }
+  // acc[nb][r] = partial of out[m = r16][n0 + 16 nb + 4q + r]; sum the waves in wave order
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][nb][(4 * q + r) * 17 + r16] = acc[nb][r];
   __syncthreads();
-  if (wave == 0) {
+  for (int nb = wave; nb < NB; nb += kSkWaves) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int col = 4 * q + r;
       float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < kSkWaves; ++w) s += red[w][col * 17 + r16];
-      if (mrow && n0 + col < a.N) E::store(a.out, (int64_t)r16 * a.out_stride + n0 + col, s);
+      for (int w = 0; w < kSkWaves; ++w) s += red[w][nb][col * 17 + r16];
+      const int n = n0 + 16 * nb + col;
+      if (mrow && n < a.N) E::store(a.out, (int64_t)r16 * a.out_stride + n, s);
     }
   }
+}
+
+template <typename Tag>
+static void launch_skinny(const SkinnyArgs& a, hipStream_t st) {
+  const dim3 block(kSkWaves * 64);
+  gemm_skinny_kernel<Tag, 1, 8><<<dim3((a.N + 15) / 16), block, 0, st>>>(a);
 }
 
 }  // namespace sp
@@ -109,11 +131,8 @@ extern "C" int sp_gemm_skinny(void* out, const void* x, const void* w, int M, in
   SP_CHECK_ARG(x_stride % 8 == 0 && w_stride % 8 == 0 && x_stride >= K && w_stride >= K && out_stride >= N);
   SP_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0);
   sp::SkinnyArgs a{(const char*)x, (const char*)w, out, M, N, K, x_stride, w_stride, out_stride};
-  const dim3 grid((N + 15) / 16);
-  if (dtype == SP_BF16)
-    sp::gemm_skinny_kernel<sp::bf16_tag><<<grid, sp::kSkWaves * 64, 0, (hipStream_t)stream>>>(a);
-  else
-    sp::gemm_skinny_kernel<sp::f16_tag><<<grid, sp::kSkWaves * 64, 0, (hipStream_t)stream>>>(a);
+  if (dtype == SP_BF16) sp::launch_skinny<sp::bf16_tag>(a, (hipStream_t)stream);
+  else sp::launch_skinny<sp::f16_tag>(a, (hipStream_t)stream);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

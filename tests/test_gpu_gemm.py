@@ -16,7 +16,7 @@ def check(got, x, w, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M", [1, 3, 8, 16])
-@pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 14336), (100, 64), (16, 32), (4104, 2048)])
+@pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 14336), (100, 64), (16, 32), (4104, 2048), (28672, 512), (40000, 256)])
 def test_skinny_gemm_matches_fp32_reference(dtype, M, N, K):
     from scratchpad_amd import _native
     g = torch.Generator().manual_seed(M * 1000 + N + K)
