@@ -403,3 +403,60 @@ def test_backend_sliding_window_layers_decode_and_extend():
                                c["req_pool_indices"], c["seq_lens"], ext_t.cpu(), start.cpu(), D ** -0.5,
                                window_left=W)
     assert_close(oe, ref, dtype, what="windowed extend layer")
+
+
+def test_random_shapes_decode_and_extend_against_oracle(nat):
+    """40 seeded random problems: head layout, head size, dtype, batch, ragged lengths (including
+    empty prefixes, single keys, lengths straddling chunk/tile edges), soft cap, kv_start offsets,
+    causal / cross form, sliding window, chunk size and plan on/off - each against the oracle."""
+    import random
+    rnd = random.Random(2024)
+    layouts = [(32, 8), (8, 8), (8, 1), (16, 2), (4, 4), (8, 2), (16, 16)]
+    for case in range(40):
+        Hq, Hkv = rnd.choice(layouts)
+        D = rnd.choice([64, 128])
+        dt = rnd.choice(["bf16", "f16", "f32"] if case % 5 == 0 else ["bf16", "f16"])
+        dtype = DTYPES[dt]
+        bs = rnd.choice([1, 2, 3, 5, 9, 17])
+        edge = [1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 700]
+        cap = rnd.choice([0.0, 0.0, 30.0])
+        scale = D ** -0.5 * rnd.choice([1.0, 0.5])
+        what = f"case {case}: Hq{Hq} Hkv{Hkv} D{D} {dt} bs{bs} cap{cap}"
+        if rnd.random() < 0.5:      # ---- decode
+            lens = [rnd.choice(edge) for _ in range(bs)]
+            off = [rnd.choice([0, 0, 3, 40]) for _ in range(bs)]
+            p = paged_problem(1000 + case, bs, Hq, Hkv, D, [l + o for l, o in zip(lens, off)], dtype, DEV)
+            p["seq_lens"] = torch.tensor(lens, device=DEV)
+            kv_start = torch.tensor(off, device=DEV) if any(off) else None
+            chunk = rnd.choice([64, 128, 512])
+            o = run_decode(nat, p, scale, cap=cap, chunk=chunk, kv_start=kv_start, use_plan=rnd.random() < 0.7)
+            ref = oracle_decode(p, scale, cap, None if kv_start is None else kv_start.cpu())
+            assert_close(o, ref, dtype, what=what + f" decode chunk{chunk}", vmax=float(p["v_buffer"].abs().max()))
+        else:                       # ---- extend
+            ext = [rnd.choice([1, 2, 31, 32, 33, 64, 127, 130, 200]) for _ in range(bs)]
+            causal = rnd.random() < 0.75
+            pre = [rnd.choice([0, 0, 1, 63, 64, 65, 300]) for _ in range(bs)]
+            window = rnd.choice([-1, -1, 0, 5, 64, 100]) if causal else -1
+            if causal:
+                seq = [a + b for a, b in zip(pre, ext)]
+            else:
+                seq = [rnd.choice([0, 1, 64, 65, 300]) for _ in range(bs)]     # encoder lengths, may be empty
+            p = paged_problem(2000 + case, bs, Hq, Hkv, D, [max(s, 1) for s in seq], dtype, DEV)
+            p["seq_lens"] = torch.tensor(seq, device=DEV)
+            g = torch.Generator().manual_seed(3000 + case)
+            q = torch.randn(sum(ext), Hq, D, generator=g).to(dtype).to(DEV)
+            ext_t = torch.tensor(ext, dtype=torch.int32, device=DEV)
+            start = torch.zeros(bs, dtype=torch.int32, device=DEV)
+            start[1:] = torch.cumsum(ext_t[:-1], 0)
+            T_, = (sum(ext),)
+            ws = torch.empty(nat.extend_workspace_bytes(T_, bs, Hq, D, dtype), dtype=torch.uint8, device=DEV)
+            o = torch.zeros_like(q)            # rows without any visible key stay zero (cross-attention contract)
+            nat.extend_attention(o, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"],
+                                 p["seq_lens"], ext_t, start, scale, cap, causal, max(ext), max(max(seq), 1), ws,
+                                 None, window_left=window)
+            c = cpu(p)
+            ref = ops.extend_attention(q.cpu().float(), c["k_buffer"].float(), c["v_buffer"].float(),
+                                       c["req_to_token"], c["req_pool_indices"], c["seq_lens"], ext_t.cpu(),
+                                       start.cpu(), scale, cap, causal=causal, window_left=window)
+            assert_close(o, ref, dtype, what=what + f" extend causal{causal} window{window}",
+                         vmax=float(p["v_buffer"].abs().max()))

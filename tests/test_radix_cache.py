@@ -159,3 +159,59 @@ def test_chunk_cache_keeps_only_the_requests_own_slots():
     cache.cache_finished_req(req)
     assert alloc.available_size() == 32 and r2t.available_size() == 4
     assert cache.evictable_size() == 0 and cache.entries == {}
+
+
+def test_random_traces_against_a_brute_force_prefix_model():
+    """200 seeded operations per trace, 20 traces: the tree's answer must equal a brute-force model
+    (a list of every inserted (key, slots) pair): the longest common prefix over all stored keys,
+    with the slots of whichever entry owns that prefix first (first writer wins, as insert() only
+    adds the unseen tail).  Size counters and allocator conservation hold throughout."""
+    for seed in range(20):
+        rnd = random.Random(seed)
+        alloc = TokenToKVPoolAllocator(4000, torch.float32, "cpu", None)
+        cache = RadixCache(None, alloc)
+        owner = {}            # prefix tuple -> slot of its last token (first writer)
+        locked = []
+        for step in range(200):
+            op = rnd.random()
+            key = [rnd.randrange(4) for _ in range(rnd.randrange(1, 12))]
+            if op < 0.45:
+                slots = alloc.alloc(len(key))
+                if slots is None:
+                    continue
+                n = cache.insert(key, slots.clone())
+                alloc.free(slots[:n])
+                want_n = 0
+                while want_n < len(key) and tuple(key[:want_n + 1]) in owner:
+                    want_n += 1
+                assert n == want_n, (seed, step)
+                for i in range(n, len(key)):
+                    owner[tuple(key[:i + 1])] = int(slots[i])
+            elif op < 0.85:
+                val, node = cache.match_prefix(key)
+                want = []
+                for i in range(len(key)):
+                    slot = owner.get(tuple(key[:i + 1]))
+                    if slot is None:
+                        break
+                    want.append(slot)
+                assert val.tolist() == want, (seed, step)
+                if want and rnd.random() < 0.3:
+                    cache.inc_lock_ref(node)
+                    locked.append(node)
+            elif op < 0.93 and locked:
+                cache.dec_lock_ref(locked.pop(rnd.randrange(len(locked))))
+            else:
+                before = set(cache.all_values_flatten().tolist())
+                cache.evict(rnd.randrange(1, 30))
+                after = set(cache.all_values_flatten().tolist())
+                gone = before - after
+                owner = {k: v for k, v in owner.items() if v not in gone}
+                # a locked path is never evicted
+                for node in locked:
+                    n = node
+                    while n is not cache.root_node:
+                        assert set(n.value.tolist()) <= after
+                        n = n.parent
+            assert cache.total_size() == len(owner) == cache.evictable_size() + cache.protected_size()
+            assert alloc.available_size() + cache.total_size() == 4000
