@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true",
                     help="run the forward on the overlap worker's thread/stream (tp_worker_client.py)")
+    ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8_e5m2"],
+                    help="decode mode: the reference's --kv-cache-dtype (fp8_e5m2 is NOT the headline config)")
     ap.add_argument("--requests", type=int, default=512, help="serve mode: number of requests in the trace")
     ap.add_argument("--max-input", type=int, default=2048, help="serve mode: prompts are U[128, max-input]")
     ap.add_argument("--max-output", type=int, default=128, help="serve mode: outputs are U[16, max-output]")
@@ -75,12 +77,19 @@ def build_engine(args, device_index, seed):
     pool_tokens = int(ctx.sum()) + args.bs * total_steps + 64
     sargs = ServerArgs(max_total_tokens=pool_tokens, max_running_requests=args.bs,
                        disable_cuda_graph=args.no_graph, cuda_graph_max_bs=args.bs,
-                       cuda_graph_bs=[args.bs])
+                       cuda_graph_bs=[args.bs], kv_cache_dtype=args.kv_cache_dtype)
     mr = ModelRunner(cfg, sargs, dtype=torch.bfloat16, gpu_id=device_index, seed=seed)
     # synthetic cache contents (random, not zeros: zero operands run at a higher clock)
     for arena in (mr.token_to_kv_pool._k_arena, mr.token_to_kv_pool._v_arena):
         for layer in range(arena.shape[0]):
-            arena[layer].normal_(0.0, 0.5)
+            if arena.dtype == torch.uint8:      # e5m2 bytes of the same distribution
+                rows = arena[layer]
+                for lo in range(0, rows.shape[0], 1 << 17):
+                    blk = rows[lo:lo + (1 << 17)]
+                    blk.copy_(torch.empty(blk.shape, dtype=torch.bfloat16, device=blk.device).normal_(0.0, 0.5)
+                              .to(torch.float8_e5m2).view(torch.uint8))
+            else:
+                arena[layer].normal_(0.0, 0.5)
     return mr, ctx, gen
 
 
@@ -121,10 +130,10 @@ def engine_step(worker, batch):
     return out
 
 
-def attention_algorithmic_bytes(cfg, seq_sum, bs, elem=2):
+def attention_algorithmic_bytes(cfg, seq_sum, bs, kv_elem=2):
     """K+V rows of every context token + q,o rows + int32 slot indices, per layer."""
-    kv = seq_sum * 2 * cfg.num_key_value_heads * cfg.head_dim * elem
-    qo = 2 * bs * cfg.num_attention_heads * cfg.head_dim * elem
+    kv = seq_sum * 2 * cfg.num_key_value_heads * cfg.head_dim * kv_elem
+    qo = 2 * bs * cfg.num_attention_heads * cfg.head_dim * 2
     return kv + qo + 4 * seq_sum
 
 
@@ -540,13 +549,14 @@ def main():
             mr.graph_runner = saved
         ms = [a.elapsed_time(b) for a, b in events]
         avg_ms = sum(ms) / len(ms)
-        alg = sum(attention_algorithmic_bytes(cfg, s, args.bs) for s in sums) / len(sums)
+        kv_elem = 1 if args.kv_cache_dtype == "fp8_e5m2" else 2
+        alg = sum(attention_algorithmic_bytes(cfg, s, args.bs, kv_elem) for s in sums) / len(sums)
         achieved = alg / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per
         # the gfx950 correction + WRITE_SIZE, same shapes): measured traffic/algorithmic ratio
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_decode_attn_pmc.json")
-        if os.path.exists(pmc) and args.model == "llama3-8b":
+        if os.path.exists(pmc) and args.model == "llama3-8b" and args.kv_cache_dtype == "auto":
             ratio = json.load(open(pmc))["traffic_over_algorithmic"]
             traffic, traffic_src = int(alg * ratio), "profiles/r01_decode_attn_pmc.txt (PMC ratio x algorithmic)"
         roofline = {"bound": "hbm", "kernel": "decode_mfma_kernel+decode_merge_kernel",
@@ -565,7 +575,8 @@ def main():
     # whole-step HBM roofline: weights once + KV of every context token + new KV
     n_params = sum(p.numel() for p in mr.model.parameters())
     avg_seq = (seq_sum_start + seq_sum_end) / 2 + args.bs / 2
-    step_bytes = n_params * 2 + avg_seq * 2 * cfg.num_key_value_heads * cfg.head_dim * 2 * cfg.num_hidden_layers
+    kv_elem = 1 if args.kv_cache_dtype == "fp8_e5m2" else 2
+    step_bytes = n_params * 2 + avg_seq * 2 * cfg.num_key_value_heads * cfg.head_dim * kv_elem * cfg.num_hidden_layers
     step_roofline_tok_s = args.bs / (step_bytes / (HBM_PEAK_GBPS * 1e9))
     out = {
         "metric": "decode_tokens_per_sec", "value": round(value, 1), "unit": "tokens/s",
@@ -574,7 +585,8 @@ def main():
         "data": "synthetic (random-init weights, random KV, seeded contexts and slot permutation)",
         "config": {"workload": f"{args.model} TP=1 bf16 continuous-batching decode bs={args.bs} seq_len=1, "
                                f"ctx={'U[128,4096] seed 0' if args.ctx == 'uniform' else args.ctx}, page_size=1, "
-                               f"{'HIP-graph replay' if not args.no_graph else 'eager'}{', overlap worker' if args.overlap else ''}",
+                               f"{'HIP-graph replay' if not args.no_graph else 'eager'}{', overlap worker' if args.overlap else ''}"
+                               f"{', KV cache fp8_e5m2' if args.kv_cache_dtype != 'auto' else ''}",
                    "batch_size": args.bs, "mean_context": round(avg_seq / args.bs, 1),
                    "layers": cfg.num_hidden_layers, "replicas": world},
         "step_hbm_roofline_tokens_per_sec": round(step_roofline_tok_s, 1),

@@ -34,7 +34,7 @@ extern "C" {
 #define SP_ABI_VERSION 2
 #define SP_API __attribute__((visibility("default")))
 
-typedef enum { SP_F32 = 0, SP_F16 = 1, SP_BF16 = 2 } sp_dtype;
+typedef enum { SP_F32 = 0, SP_F16 = 1, SP_BF16 = 2, SP_FP8_E5M2 = 3 /* KV pool only */ } sp_dtype;
 
 typedef enum {
   SP_OK = 0,
@@ -83,6 +83,16 @@ SP_API int sp_kv_store(void* k_buffer, void* v_buffer, const int64_t* loc, const
                 int64_t k_stride, int64_t v_stride, int64_t k_buffer_stride,
                 int64_t v_buffer_stride, int dtype, void* stream);
 
+/* ---- KV store into an fp8 (e5m2) pool: the `--kv-cache-dtype fp8_e5m2` branch of set_kv_buffer
+ *      (memory/pool.py:401-412: cache_k.div_(k_scale); cache_k.to(float8_e5m2); stored as uint8).
+ * k,v: [T, Hkv, D] in `src_dtype` (fp16/bf16/fp32); buffers: uint8 [P+1, Hkv, D], strides in
+ * elements (= bytes).  Conversion = round-to-nearest-even to 1-5-2 (overflow -> inf), i.e.
+ * torch's .to(torch.float8_e5m2); k_scale / v_scale divide first (pass 1.0 for none).            */
+SP_API int sp_kv_store_fp8(void* k_buffer, void* v_buffer, const int64_t* loc, const void* k, const void* v,
+                    int64_t num_tokens, int num_kv_heads, int head_dim, int64_t k_stride,
+                    int64_t v_stride, int64_t k_buffer_stride, int64_t v_buffer_stride, float k_scale,
+                    float v_scale, int src_dtype, void* stream);
+
 /* ---- req_to_token scatter: replaces write_req_to_token_pool_triton
  *      (scheduler/schedule_batch.py:1546-1580).  All index arrays int64, table int32.           */
 SP_API int sp_write_req_to_token(int32_t* req_to_token, int64_t row_stride,
@@ -111,6 +121,11 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  * on every seq_lens[b], e.g. the context length under graph capture) fix the launch geometry:
  * num_splits = ceil(max_seq_len / chunk).  workspace: sp_decode_attention_workspace_bytes().
  *
+ * `kv_dtype` = `dtype`, or SP_FP8_E5M2 for a uint8 pool written by sp_kv_store_fp8 (16-bit q
+ * only; kv_buffer_stride then counts bytes): the kernels widen e5m2 to half exactly and compute
+ * in fp16 with fp32 accumulation, as flashinfer does for fp8 KV (convert to the query type); the
+ * in-tree Triton kernels' `p.to(v.dtype)` (probabilities rounded to e5m2) is NOT reproduced.
+ *
  * `plan` (optional, may be NULL): the list of non-empty (request, split) items built by
  * sp_decode_plan() from the same seq_lens / chunk, once per step, shared by all layers - the
  * counterpart of flashinfer's begin_forward()/plan (flashinfer_backend.py:623-670) and of
@@ -128,7 +143,7 @@ SP_API int sp_decode_attention(void* out, const void* q, const void* k_buffer, c
                         int head_dim, int64_t q_stride, int64_t out_stride,
                         int64_t kv_buffer_stride, float sm_scale, float logit_cap,
                         int64_t max_seq_len, int chunk, void* workspace, size_t workspace_bytes,
-                        const int32_t* plan, int dtype, void* stream);
+                        const int32_t* plan, int dtype, int kv_dtype, void* stream);
 
 /* ---- Ragged extend (prefill) attention: replaces extend_attention_fwd (nn/attention/
  *      triton_attn/extend_attention.py:229-327; call site triton_backend.py:137-154) and the
@@ -156,7 +171,7 @@ SP_API int sp_extend_attention(void* out, const void* q, const void* k_buffer, c
                         int64_t out_stride, int64_t kv_buffer_stride, float sm_scale,
                         float logit_cap, int causal, int window_left, int max_extend_len,
                         int64_t max_seq_len, void* workspace, size_t workspace_bytes, int dtype,
-                        void* stream);
+                        int kv_dtype, void* stream);
 
 /* ---- Sampler.  Replaces nn/layers/sampler.py:63-75 (torch.argmax; logits.div_(T) + softmax),
  *      sampler.py:195-232 (top_k_top_p_min_p_sampling_from_probs_torch, top_p_normalize_probs_torch)

@@ -118,8 +118,25 @@ def kv_store(k_buffer: torch.Tensor, v_buffer: torch.Tensor, loc: torch.Tensor,
     """MHATokenToKVPool.set_kv_buffer - memory/pool.py:392-424 (non-fp8 branch): in-place
     ``buffer[loc] = cache``.  Duplicate slots (padded rows all write slot 0): last writer wins
     in the reference's index_put; callers must not rely on slot 0's content."""
+    if k_buffer.dtype == torch.uint8:
+        # --kv-cache-dtype fp8_e5m2 (memory/pool.py:274-280, 401-412): cache.to(float8_e5m2), stored
+        # as uint8 because index_put has no fp8 kernel
+        k_buffer[loc] = cache_k.to(torch.float8_e5m2).view(torch.uint8)
+        v_buffer[loc] = cache_v.to(torch.float8_e5m2).view(torch.uint8)
+        return
     k_buffer[loc] = cache_k.to(k_buffer.dtype)
     v_buffer[loc] = cache_v.to(v_buffer.dtype)
+
+
+def kv_rows(buffer: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """Rows of a KV pool as fp32; a uint8 pool holds fp8 e5m2 bytes (get_key_buffer's
+    ``.view(self.dtype)``, pool.py:366-371), widened exactly - flashinfer's treatment of fp8 KV
+    (convert to the query type, fp32 accumulate); the in-tree Triton kernels' rounding of P to
+    the KV dtype (``p.to(v.dtype)``) is not applied for fp8."""
+    rows = buffer[idx]
+    if rows.dtype == torch.uint8:
+        rows = rows.view(torch.float8_e5m2)
+    return rows.to(torch.float32)
 
 
 def write_req_to_token(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor,
@@ -193,8 +210,8 @@ def decode_attention(q: torch.Tensor, k_buffer: torch.Tensor, v_buffer: torch.Te
             continue
         s0 = 0 if kv_start is None else int(kv_start[b])
         idx = req_to_token[int(req_pool_indices[b]), s0:s0 + L].long()
-        k = k_buffer[idx].to(torch.float32)          # [L, Hkv, D]
-        v = v_buffer[idx].to(torch.float32)
+        k = kv_rows(k_buffer, idx)                   # [L, Hkv, D]
+        v = kv_rows(v_buffer, idx)
         qb = q[b].to(torch.float32).view(Hkv, g, D)
         s = torch.einsum("hgd,lhd->hgl", qb, k) * sm_scale
         s = _softcap(s, logit_cap)
@@ -236,8 +253,8 @@ def extend_attention(q: torch.Tensor, k_buffer: torch.Tensor, v_buffer: torch.Te
         off = 0 if kv_start is None else int(kv_start[b])
         P = L - E if causal else L
         idx = req_to_token[int(req_pool_indices[b]), off:off + L].long()
-        k = k_buffer[idx].to(torch.float32)
-        v = v_buffer[idx].to(torch.float32)
+        k = kv_rows(k_buffer, idx)
+        v = kv_rows(v_buffer, idx)
         if causal and k_extend is not None:
             k = torch.cat((k[:P], k_extend[s0:s0 + E].to(torch.float32)), 0)
             v = torch.cat((v[:P], v_extend[s0:s0 + E].to(torch.float32)), 0)

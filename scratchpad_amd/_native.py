@@ -16,6 +16,18 @@ _lib = None
 
 SP_F32, SP_F16, SP_BF16 = 0, 1, 2
 _DTYPES = {torch.float32: SP_F32, torch.float16: SP_F16, torch.bfloat16: SP_BF16}
+SP_FP8_E5M2 = 3
+_FP8_POOL_DTYPES = (torch.uint8, torch.float8_e5m2)
+
+
+def _kv_dt(buf: torch.Tensor, q: torch.Tensor, what: str) -> int:
+    """dtype code of a KV pool buffer next to 16/32-bit q: the same type, or an e5m2 byte pool."""
+    if buf.dtype == q.dtype:
+        return _DTYPES[q.dtype]
+    if buf.dtype in _FP8_POOL_DTYPES and q.dtype in (torch.float16, torch.bfloat16):
+        return SP_FP8_E5M2
+    raise RuntimeError(f"{what}: KV pool dtype {buf.dtype} does not go with q dtype {q.dtype}")
+
 
 _vp, _i64, _i32, _f32, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
                               ctypes.c_size_t)
@@ -39,11 +51,13 @@ SIGNATURES = {
     "sp_decode_plan": (_i32, [_vp, _sz, _vp, _i32, _i32, _i64, _i32, _vp]),
     "sp_decode_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32,
                                    _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32, _i64, _i32,
-                                   _vp, _sz, _vp, _i32, _vp]),
+                                   _vp, _sz, _vp, _i32, _i32, _vp]),
     "sp_extend_attention_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32]),
     "sp_extend_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp,
                                    _i32, _i64, _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32,
-                                   _i32, _i32, _i32, _i64, _vp, _sz, _i32, _vp]),
+                                   _i32, _i32, _i32, _i64, _vp, _sz, _i32, _i32, _vp]),
+    "sp_kv_store_fp8": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _f32,
+                               _i32, _vp]),
     "sp_argmax": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp]),
     "sp_softmax_temperature": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp]),
     "sp_top_k_top_p_min_p_sample": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
@@ -201,6 +215,30 @@ def kv_store(k_buffer: torch.Tensor, v_buffer: torch.Tensor, loc: torch.Tensor,
            "sp_kv_store")
 
 
+def kv_store_fp8(k_buffer: torch.Tensor, v_buffer: torch.Tensor, loc: torch.Tensor, cache_k: torch.Tensor,
+                 cache_v: torch.Tensor, k_scale: float = 1.0, v_scale: float = 1.0) -> None:
+    """pool[loc] = (cache / scale) rounded to fp8 e5m2; the pool is a uint8 (or float8_e5m2) tensor."""
+    _gpu(k_buffer, v_buffer, loc, cache_k, cache_v)
+    if k_buffer.dtype not in _FP8_POOL_DTYPES or v_buffer.dtype not in _FP8_POOL_DTYPES:
+        raise RuntimeError("kv_store_fp8: the pool must be uint8 / float8_e5m2")
+    if cache_k.dtype != cache_v.dtype or cache_k.dtype not in _DTYPES:
+        raise RuntimeError("kv_store_fp8: k and v must share a 16/32-bit float dtype")
+    T = cache_k.shape[0]
+    k2, v2 = cache_k.reshape(T, -1), cache_v.reshape(T, -1)
+    if k2.stride(-1) != 1:
+        k2 = k2.contiguous()
+    if v2.stride(-1) != 1:
+        v2 = v2.contiguous()
+    loc = loc.to(torch.int64).contiguous()
+    Hkv, D = k_buffer.shape[1], k_buffer.shape[2]
+    if v_buffer.shape[2] != D:
+        raise RuntimeError("kv_store_fp8: v_head_dim must equal head_dim")
+    _check(load().sp_kv_store_fp8(k_buffer.data_ptr(), v_buffer.data_ptr(), loc.data_ptr(), k2.data_ptr(),
+                                  v2.data_ptr(), T, Hkv, D, k2.stride(0), v2.stride(0), k_buffer.stride(0),
+                                  v_buffer.stride(0), k_scale, v_scale, _dt(cache_k), _stream()),
+           "sp_kv_store_fp8")
+
+
 # --------------------------------------------------------------------------- index kernels
 def write_req_to_token(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor,
                        pre_lens: torch.Tensor, seq_lens: torch.Tensor, extend_lens: torch.Tensor,
@@ -282,8 +320,9 @@ def decode_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
     bs, Hq, D = q.shape
     if q.stride(2) != 1 or q.stride(1) != D or out.stride(2) != 1 or out.stride(1) != D:
         raise RuntimeError("decode_attention: q/out must be [bs, Hq, D] with contiguous heads")
-    if k_buffer.dtype != q.dtype or v_buffer.dtype != q.dtype:
-        raise RuntimeError("decode_attention: KV pool dtype must equal q dtype")
+    kv_dt = _kv_dt(k_buffer, q, "decode_attention")
+    if v_buffer.dtype != k_buffer.dtype:
+        raise RuntimeError("decode_attention: K and V pools must share a dtype")
     req, seq, idx64 = _idx_pair(req_pool_indices, seq_lens)
     if kv_start is not None:
         kv_start = kv_start.to(seq.dtype).contiguous()
@@ -292,7 +331,7 @@ def decode_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
         req_to_token.stride(0), req.data_ptr(), seq.data_ptr(), _ptr(kv_start), idx64, bs, Hq,
         k_buffer.shape[1], D, q.stride(0), out.stride(0), k_buffer.stride(0), sm_scale, logit_cap,
         max_seq_len, chunk, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
-        _ptr(plan), _dt(q), _stream()), "sp_decode_attention")
+        _ptr(plan), _dt(q), kv_dt, _stream()), "sp_decode_attention")
 
 
 def extend_workspace_bytes(num_tokens: int, bs: int, Hq: int, D: int, dtype: torch.dtype) -> int:
@@ -313,8 +352,9 @@ def extend_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
     T, Hq, D = q.shape
     if q.stride(2) != 1 or q.stride(1) != D or out.stride(2) != 1 or out.stride(1) != D:
         raise RuntimeError("extend_attention: q/out must be [T, Hq, D] with contiguous heads")
-    if k_buffer.dtype != q.dtype or v_buffer.dtype != q.dtype:
-        raise RuntimeError("extend_attention: KV pool dtype must equal q dtype")
+    kv_dt = _kv_dt(k_buffer, q, "extend_attention")
+    if v_buffer.dtype != k_buffer.dtype:
+        raise RuntimeError("extend_attention: K and V pools must share a dtype")
     if extend_seq_lens.dtype != torch.int32 or extend_start_loc.dtype != torch.int32:
         raise RuntimeError("extend_seq_lens / extend_start_loc must be int32")
     req, seq, idx64 = _idx_pair(req_pool_indices, seq_lens)
@@ -326,7 +366,7 @@ def extend_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
         extend_seq_lens.contiguous().data_ptr(), extend_start_loc.contiguous().data_ptr(),
         seq.shape[0], T, Hq, k_buffer.shape[1], D, q.stride(0), out.stride(0), k_buffer.stride(0),
         sm_scale, logit_cap, int(causal), int(window_left), max_extend_len, max_seq_len, workspace.data_ptr(),
-        workspace.numel() * workspace.element_size(), _dt(q), _stream()), "sp_extend_attention")
+        workspace.numel() * workspace.element_size(), _dt(q), kv_dt, _stream()), "sp_extend_attention")
 
 
 # --------------------------------------------------------------------------- sampler

@@ -200,7 +200,8 @@ class HipAttnBackend(AttentionBackend):
                                                     forward_batch.extend_seq_lens_cpu))
             max_len = max(max_len, enc_max, 1)
             ws = self._ensure_workspace(_native.extend_workspace_bytes(
-                forward_batch.extend_num_tokens, bs, self.num_head, self.head_dim, pool_dtype))
+                forward_batch.extend_num_tokens, bs, self.num_head, self.head_dim,
+                pool_dtype if pool_dtype.itemsize > 1 else torch.bfloat16))
             self.forward_metadata = (max_extend, max_len, ws)
 
     def init_cuda_graph_state(self, max_bs: int):

@@ -21,6 +21,7 @@ struct DecodeArgs {
   int chunk, num_splits, hh_shift, head_groups;
   float* part_o;    // [bs, Hq, num_splits, D]
   float* part_lse;  // [bs, Hq, num_splits]  (log2 domain)
+  int kv8;              // 1: the pool holds fp8 e5m2 bytes (kv_stride in bytes); 16-bit q/out only
   const int32_t* plan;  // optional: [count, chunk, (b, c) x count] from sp_decode_plan
 };
 
@@ -40,6 +41,6 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
                     int idx64, const int32_t* extend_seq_lens, const int32_t* extend_start_loc,
                     int batch_size, int num_q_heads, int num_kv_heads, int head_dim, int64_t q_stride,
                     int64_t out_stride, int64_t kv_buffer_stride, float sm_scale, float logit_cap,
-                    int causal, int window_left, int max_extend_len, int dtype, hipStream_t st);
+                    int causal, int window_left, int max_extend_len, int dtype, int kv8, hipStream_t st);
 
 }  // namespace sp

@@ -464,6 +464,11 @@ static int decode_kernel_choice(int group, int dtype) {
 }
 
 int run_decode(const DecodeArgs& a, int head_dim, int group, int dtype, hipStream_t st) {
+  if (a.kv8) {                       // fp8 pool: matrix-core kernel only
+    if (a.Hq / a.Hkv > 16) return SP_ERR_UNSUPPORTED;
+    const int rc = run_decode_mfma(a, head_dim, dtype, st);
+    return rc == SP_OK ? run_decode_merge(a, head_dim, dtype, st) : rc;
+  }
   if (decode_kernel_choice(a.Hq / a.Hkv, dtype) == 2) {
     const int rc = run_decode_mfma(a, head_dim, dtype, st);
     if (rc == SP_OK) return run_decode_merge(a, head_dim, dtype, st);
@@ -528,7 +533,7 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
                                    int64_t q_stride, int64_t out_stride, int64_t kv_buffer_stride,
                                    float sm_scale, float logit_cap, int64_t max_seq_len, int chunk,
                                    void* workspace, size_t workspace_bytes, const int32_t* plan,
-                                   int dtype, void* stream) {
+                                   int dtype, int kv_dtype, void* stream) {
   SP_CHECK_ARG(out && q && k_buffer && v_buffer && req_to_token && req_pool_indices && seq_lens);
   SP_CHECK_ARG(batch_size >= 0 && num_q_heads > 0 && num_kv_heads > 0 && head_dim > 0);
   SP_CHECK_ARG(num_q_heads % num_kv_heads == 0 && max_seq_len >= 0);
@@ -537,9 +542,13 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
   SP_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)k_buffer & 15) == 0 &&
                ((uintptr_t)v_buffer & 15) == 0);
   if (batch_size == 0) return SP_OK;
+  const bool kv8 = kv_dtype == SP_FP8_E5M2;
+  if (!kv8 && kv_dtype != dtype) return SP_ERR_UNSUPPORTED;
+  if (kv8 && dtype != SP_F16 && dtype != SP_BF16) return SP_ERR_UNSUPPORTED;
   const int eb = dtype == SP_F32 ? 4 : 2;
   const int vec = 16 / eb;
-  SP_CHECK_ARG(q_stride % vec == 0 && kv_buffer_stride % vec == 0);
+  SP_CHECK_ARG(q_stride % vec == 0 && kv_buffer_stride % (kv8 ? 8 : vec) == 0);
+  SP_CHECK_ARG(!kv8 || (((uintptr_t)k_buffer & 7) == 0 && ((uintptr_t)v_buffer & 7) == 0));
   const int G = num_q_heads / num_kv_heads;
   int Gk = G, qblocks = 1;  // groups wider than 8 are processed 8 query heads at a time
   if (G > 8) {
@@ -557,7 +566,7 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
   a.seq_lens = seq_lens; a.kv_start = kv_start; a.idx64 = idx64; a.bs = batch_size;
   a.Hq = num_q_heads; a.Hkv = num_kv_heads; a.q_stride = q_stride; a.o_stride = out_stride;
   a.kv_stride = kv_buffer_stride; a.sm_scale = sm_scale; a.logit_cap = logit_cap;
-  a.chunk = chunk; a.num_splits = (int)S; a.plan = plan;
+  a.chunk = chunk; a.num_splits = (int)S; a.plan = plan; a.kv8 = kv8 ? 1 : 0;
   a.hh_shift = decode_heads_per_load_shift(num_kv_heads, head_dim, dtype, &a.head_groups);
   a.part_o = nullptr; a.part_lse = nullptr;
   if (S > 1) {

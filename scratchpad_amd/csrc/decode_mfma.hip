@@ -21,6 +21,8 @@
 //     factor of O^T is lane-local;
 //   * the 4 waves' (m, l, O) are merged through LDS (the tile area is reused), split partials go to
 //     the same workspace / merge kernel as the VALU path.
+#include <type_traits>
+
 #include "attention_internal.h"
 
 namespace sp {
@@ -111,10 +113,20 @@ struct DmCfg {
 // HPW ("head per wave", Hkv % 4 == 0): the 4 waves take the 4 adjacent KV heads of the SAME keys - the
 // workgroup then reads whole 1 KiB token half-rows, and each wave owns its heads outright: no merge,
 // no barrier anywhere.  Otherwise (few KV heads per rank) the waves split the keys of one head.
-template <typename Tag, int D, bool HPW>
+//
+// KV8: the pool holds fp8 e5m2 bytes (--kv-cache-dtype fp8_e5m2).  A lane gathers 8 bytes instead of
+// 16, expands them to 8 halves on the way into the LDS tile (e5m2 is the top byte of a half: one
+// v_perm_b32 per two elements, exact), and the tile math runs in fp16 whatever the model dtype is
+// (bf16 q is converted once per workgroup; P is rounded to fp16); the output keeps the model dtype.
+// HBM bytes per context token halve; everything after the LDS tile is unchanged.
+template <typename Tag, int D, bool HPW, bool KV8>
 __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
   typedef DmCfg<D> C;
   typedef Elem<Tag> E;
+  typedef typename std::conditional<KV8, f16_tag, Tag>::type CT;      // dtype of the tile math
+  typedef typename std::conditional<KV8, u32x2, u32x4>::type raw_t;   // one lane's gathered chunk
+  constexpr int SRC_ROW_B = KV8 ? D : 2 * D;                          // bytes of one head row in the pool
+  constexpr int SRC_CH_B = KV8 ? 8 : 16;                              // bytes of the 8 elements a lane gathers
   constexpr int TK = C::TK, ROW_B = C::ROW_B, CPR = C::CPR, RPL = C::RPL, NLD = C::NLD;
   constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK, TILE_B = C::TILE_B, WAVES = C::WAVES;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -154,7 +166,10 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
     const char* qp = (const char*)a.q +
                      ((int64_t)b * a.q_stride + (int64_t)(hk * G + hcol) * D + 8 * kq) * 2;
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) qf[s] = ld16(qp + s * 64);
+    for (int s = 0; s < KSTEPS; ++s) {
+      qf[s] = ld16(qp + s * 64);
+      if constexpr (KV8 && std::is_same<Tag, bf16_tag>::value) qf[s] = bf16x8_to_f16x8(qf[s]);
+    }
   }
   const float cap = a.logit_cap;
   const float qk_scale = cap > 0.f ? a.sm_scale : a.sm_scale * kLog2eM;
@@ -166,8 +181,8 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
 
   // gather mapping: lane -> (row within the wave-load, 16-byte chunk)
   const int ld_row = lane / CPR, ld_ch = lane % CPR;
-  const int64_t tok_bytes = a.kv_stride * 2;
-  const int64_t head_off = (int64_t)hk * ROW_B;
+  const int64_t tok_bytes = a.kv_stride * (KV8 ? 1 : 2);
+  const int64_t head_off = (int64_t)hk * SRC_ROW_B;
   // fragment-read addresses (constant per lane)
   const int i16 = lane & 15;
   const int tr_row = 4 * kq + (i16 >> 2);          // V row this lane addresses in a tr read
@@ -184,7 +199,7 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
     nextidx = (ps + 64 + lane < we) ? idx_row[ps + 64 + lane] : 0;
     const int ntile = (n + TK - 1) / TK;
 
-    u32x4 kr[NLD], vr[NLD];
+    raw_t kr[NLD], vr[NLD];
     auto issue = [&](int tile) {
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
@@ -193,9 +208,9 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
         // source chunk is XOR-swizzled by the tile row so that the LDS image is conflict-free
         const int R = i * RPL + ld_row;
         const int64_t off = (key < n ? (int64_t)slot : 0) * tok_bytes + head_off +
-                            ((ld_ch ^ (R & (CPR - 1))) * 16);
-        kr[i] = ld16(a.kbuf + off);
-        vr[i] = ld16(a.vbuf + off);
+                            ((ld_ch ^ (R & (CPR - 1))) * SRC_CH_B);
+        kr[i] = *(const raw_t*)(a.kbuf + off);
+        vr[i] = *(const raw_t*)(a.vbuf + off);
       }
     };
     auto stage = [&]() {
@@ -204,8 +219,13 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
         const int R = i * RPL + ld_row;
-        st16(ldsK + R * ROW_B + ld_ch * 16, kr[i]);
-        st16(ldsV + R * ROW_B + ld_ch * 16, vr[i]);
+        if constexpr (KV8) {
+          st16(ldsK + R * ROW_B + ld_ch * 16, expand_e5m2x8(kr[i]));
+          st16(ldsV + R * ROW_B + ld_ch * 16, expand_e5m2x8(vr[i]));
+        } else {
+          st16(ldsK + R * ROW_B + ld_ch * 16, kr[i]);
+          st16(ldsV + R * ROW_B + ld_ch * 16, vr[i]);
+        }
       }
     };
     auto consume = [&](int tile) {
@@ -217,7 +237,7 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
         for (int ks = 0; ks < KSTEPS; ++ks) {
           const int cg = 4 * ks + kq;                          // logical chunk: dims 32ks + 8kq ..
           const u32x4 kf = ld16(ldsK + R * ROW_B + ((cg ^ (R & (CPR - 1))) * 16));
-          s = mfma_qk<Tag>(kf, qf[ks], s);
+          s = mfma_qk<CT>(kf, qf[ks], s);
         }
       }
       // ---- scale, mask, online softmax for column `col`; this lane holds keys 4kq + j
@@ -244,8 +264,8 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
       psum += xchg32m(psum);
       l_run = l_run * alpha + psum;
       u32x2 pf;  // B operand of O^T += V^T.P^T: P^T[k = 4kq + j][col]
-      pf[0] = pack2m<Tag>(x[0], x[1]);
-      pf[1] = pack2m<Tag>(x[2], x[3]);
+      pf[0] = pack2m<CT>(x[0], x[1]);
+      pf[1] = pack2m<CT>(x[2], x[3]);
       // ---- O^T[16 d x 16 cols] per d block; V^T fragment by one transposed read:
       //      lane i of a 16-lane group addresses row 4kq + (i>>2), elements 4(i&3)..+3 of the block
 #pragma unroll
@@ -257,7 +277,7 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
         const u32x2 vf = __builtin_bit_cast(u32x2, vt);
 #pragma unroll
         for (int r = 0; r < 4; ++r) oacc[db][r] *= alpha;
-        oacc[db] = mfma_pv<Tag>(vf, pf, oacc[db]);
+        oacc[db] = mfma_pv<CT>(vf, pf, oacc[db]);
       }
     };
 
@@ -338,18 +358,23 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
   }
 }
 
-template <typename Tag, int D>
-static int launch_dm(const DecodeArgs& a, hipStream_t st) {
+template <typename Tag, int D, bool KV8>
+static int launch_dm_kv(const DecodeArgs& a, hipStream_t st) {
   typedef DmCfg<D> C;
   if (a.Hkv % 4 == 0 && a.o_stride % 4 == 0) {
     const unsigned grid = (unsigned)a.bs * a.num_splits * (a.Hkv / 4);
-    decode_mfma_kernel<Tag, D, true><<<dim3(grid), 256, C::kLdsBytes, st>>>(a);
+    decode_mfma_kernel<Tag, D, true, KV8><<<dim3(grid), 256, C::kLdsBytes, st>>>(a);
   } else {
     const unsigned grid = (unsigned)a.bs * a.num_splits * a.Hkv;
-    decode_mfma_kernel<Tag, D, false><<<dim3(grid), 256, C::kLdsBytes, st>>>(a);
+    decode_mfma_kernel<Tag, D, false, KV8><<<dim3(grid), 256, C::kLdsBytes, st>>>(a);
   }
   SP_LAUNCH_CHECK();
   return SP_OK;
+}
+
+template <typename Tag, int D>
+static int launch_dm(const DecodeArgs& a, hipStream_t st) {
+  return a.kv8 ? launch_dm_kv<Tag, D, true>(a, st) : launch_dm_kv<Tag, D, false>(a, st);
 }
 
 // 16-bit dtypes, D in {64,128}, G <= 16.  Launches the attention kernel only; the caller runs the

@@ -334,6 +334,40 @@ __global__ __launch_bounds__(kBlock) void kv_store_kernel(char* __restrict__ kbu
   }
 }
 
+// e5m2 pool: one thread converts 8 consecutive elements of a K or V row and stores 8 bytes
+template <typename Tag>
+__global__ __launch_bounds__(kBlock) void kv_store_fp8_kernel(char* __restrict__ kbuf, char* __restrict__ vbuf,
+                                                               const int64_t* __restrict__ loc,
+                                                               const void* __restrict__ k,
+                                                               const void* __restrict__ v, int64_t num_tokens,
+                                                               int row_elems, int64_t k_stride, int64_t v_stride,
+                                                               int64_t kb_stride, int64_t vb_stride,
+                                                               float k_inv, float v_inv) {
+  typedef Elem<Tag> E;
+  const int units = row_elems / 8;                     // per row
+  const int64_t total = num_tokens * units * 2;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t t = i / (2 * units);
+    int u = (int)(i - t * 2 * units);
+    const bool is_v = u >= units;
+    if (is_v) u -= units;
+    const int64_t slot = loc[t];
+    const void* src = is_v ? v : k;
+    const int64_t sbase = t * (is_v ? v_stride : k_stride) + (int64_t)u * 8;
+    const float inv = is_v ? v_inv : k_inv;
+    u32x2 out;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      uint32_t word = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) word |= f32_to_e5m2_bits(E::load(src, sbase + 4 * w + e) * inv) << (8 * e);
+      out[w] = word;
+    }
+    char* dst = (is_v ? vbuf + slot * vb_stride : kbuf + slot * kb_stride) + (int64_t)u * 8;
+    *(u32x2*)dst = out;
+  }
+}
+
 // --------------------------------------------------------------- req_to_token write / positions
 __device__ __forceinline__ int64_t block_prefix_i64(const int64_t* a32or64, const int32_t* a32,
                                                     int n, int64_t* smem) {
@@ -540,6 +574,28 @@ extern "C" int sp_kv_store(void* k_buffer, void* v_buffer, const int64_t* loc, c
   else if (eb == 4) SP_KV_LAUNCH(4);
   else SP_KV_LAUNCH(2);
 #undef SP_KV_LAUNCH
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
+extern "C" int sp_kv_store_fp8(void* k_buffer, void* v_buffer, const int64_t* loc, const void* k,
+                               const void* v, int64_t num_tokens, int num_kv_heads, int head_dim,
+                               int64_t k_stride, int64_t v_stride, int64_t k_buffer_stride,
+                               int64_t v_buffer_stride, float k_scale, float v_scale, int src_dtype,
+                               void* stream) {
+  SP_CHECK_ARG(k_buffer && v_buffer && loc && k && v && num_tokens >= 0);
+  SP_CHECK_ARG(num_kv_heads > 0 && head_dim > 0 && k_scale > 0.f && v_scale > 0.f);
+  if (num_tokens == 0) return SP_OK;
+  const int row = num_kv_heads * head_dim;
+  if (row % 8 || k_buffer_stride % 8 || v_buffer_stride % 8 || ((uintptr_t)k_buffer & 7) ||
+      ((uintptr_t)v_buffer & 7))
+    return SP_ERR_UNSUPPORTED;
+  const int64_t work = num_tokens * (row / 8) * 2;
+  int64_t blocks = (work + kBlock - 1) / kBlock;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  SP_DISPATCH_DTYPE(src_dtype, (kv_store_fp8_kernel<Tag><<<dim3((unsigned)blocks), kBlock, 0, (hipStream_t)stream>>>(
+                                   (char*)k_buffer, (char*)v_buffer, loc, k, v, num_tokens, row, k_stride, v_stride,
+                                   k_buffer_stride, v_buffer_stride, 1.0f / k_scale, 1.0f / v_scale)));
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

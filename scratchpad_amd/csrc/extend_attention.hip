@@ -60,7 +60,7 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
                                    int64_t kv_buffer_stride, float sm_scale, float logit_cap,
                                    int causal, int window_left, int max_extend_len,
                                    int64_t max_seq_len, void* workspace, size_t workspace_bytes,
-                                   int dtype, void* stream) {
+                                   int dtype, int kv_dtype, void* stream) {
   SP_CHECK_ARG(out && q && k_buffer && v_buffer && req_to_token && req_pool_indices && seq_lens);
   SP_CHECK_ARG(extend_seq_lens && extend_start_loc && batch_size >= 0 && num_tokens >= 0);
   SP_CHECK_ARG(num_q_heads > 0 && num_kv_heads > 0 && num_q_heads % num_kv_heads == 0);
@@ -68,6 +68,9 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
   SP_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)k_buffer & 15) == 0 &&
                ((uintptr_t)v_buffer & 15) == 0);
   if (dtype != SP_F32 && dtype != SP_F16 && dtype != SP_BF16) return SP_ERR_UNSUPPORTED;
+  const bool kv8 = kv_dtype == SP_FP8_E5M2;
+  if (!kv8 && kv_dtype != dtype) return SP_ERR_UNSUPPORTED;
+  if (kv8 && dtype == SP_F32) return SP_ERR_UNSUPPORTED;
   if (batch_size == 0 || num_tokens == 0) return SP_OK;
   if (head_dim != 64 && head_dim != 128) return SP_ERR_UNSUPPORTED;
   const int G = num_q_heads / num_kv_heads;
@@ -87,8 +90,8 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
                                    req_pool_indices, seq_lens, kv_start, idx64, extend_seq_lens,
                                    extend_start_loc, batch_size, num_q_heads, num_kv_heads, head_dim,
                                    q_stride, out_stride, kv_buffer_stride, sm_scale, logit_cap, causal,
-                                   window_left, max_extend_len, dtype, st);
-    if (rc != SP_ERR_UNSUPPORTED) return rc;
+                                   window_left, max_extend_len, dtype, kv8 ? 1 : 0, st);
+    if (rc != SP_ERR_UNSUPPORTED || kv8) return rc;   // an fp8 pool has no row-stream path
   }
 
   int32_t* row_req = (int32_t*)workspace;
@@ -111,6 +114,6 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
   if (chunk > 0x7ffffff0LL) return SP_ERR_INVALID_ARG;
   a.chunk = (int)chunk; a.num_splits = 1;
   a.hh_shift = decode_heads_per_load_shift(num_kv_heads, head_dim, dtype, &a.head_groups);
-  a.part_o = nullptr; a.part_lse = nullptr; a.plan = nullptr;
+  a.part_o = nullptr; a.part_lse = nullptr; a.plan = nullptr; a.kv8 = 0;
   return run_decode(a, head_dim, G, dtype, st);
 }

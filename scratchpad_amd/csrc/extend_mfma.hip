@@ -20,6 +20,8 @@
 //   * K/V tiles of 64 keys: gathered rows (full 256-B lines, 16 B per lane) -> registers ->
 //     LDS with padded row strides (K +16 B: conflict-free ds_read_b128; V +64 B: conflict-free
 //     tr reads); the next tile's global loads are issued before the current tile is consumed.
+#include <type_traits>
+
 #include "attention_internal.h"
 
 namespace sp {
@@ -46,6 +48,7 @@ struct ExtendArgs {
   int64_t q_stride, o_stride, kv_stride;  // elements
   float sm_scale, logit_cap;
   int causal;
+  int kv8;      // 1: fp8 e5m2 pool (kv_stride in bytes); tile math in fp16, see decode_mfma.hip
   int window;   // sliding window: a row at kv position p sees keys [p - window, p]; < 0 = unlimited
 };
 
@@ -106,9 +109,11 @@ struct ExtCfg {
   static constexpr int kLdsBytes = 2 * kTileBytes;    // double-buffered: one barrier per tile
 };
 
-template <typename Tag, int D, int GK>
+template <typename Tag, int D, int GK, bool KV8>
 __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   typedef ExtCfg<D> C;
+  typedef typename std::conditional<KV8, f16_tag, Tag>::type CT;      // dtype of the tile math
+  typedef typename std::conditional<KV8, u32x2, u32x4>::type raw_t;   // one thread's gathered chunk
   constexpr int BN = C::BN, SK = C::SK, SV = C::SV, CPR = C::CPR, RPP = C::RPP, PASSES = C::PASSES;
   constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK;
   constexpr int BM = 128 / GK;
@@ -150,7 +155,10 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
     const int qrow = min(my_row, E - 1);
     const char* qp = (const char*)a.q + ((t0 + qrow) * a.q_stride + (int64_t)head * D + 8 * h) * 2;
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = ld16(qp + ks * 32);
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      qf[ks] = ld16(qp + ks * 32);
+      if constexpr (KV8 && std::is_same<Tag, bf16_tag>::value) qf[ks] = bf16x8_to_f16x8(qf[ks]);
+    }
   }
   const float cap = a.logit_cap;
   const float qk_scale = cap > 0.f ? a.sm_scale : a.sm_scale * kLog2eX;
@@ -166,9 +174,9 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
 
   // ---- staging: thread -> (row, 16-byte chunk) of the tile, PASSES rows each for K and V
   const int st_row = tid / CPR, st_ch = tid % CPR;
-  const int64_t tok_bytes = a.kv_stride * 2;
-  const int64_t head_off = (int64_t)hk * D * 2 + st_ch * 16;
-  u32x4 kreg[PASSES], vreg[PASSES];
+  const int64_t tok_bytes = a.kv_stride * (KV8 ? 1 : 2);
+  const int64_t head_off = (int64_t)hk * D * (KV8 ? 1 : 2) + st_ch * (KV8 ? 8 : 16);
+  raw_t kreg[PASSES], vreg[PASSES];
   // slot indices run one tile ahead of the row gathers: the dependent req_to_token -> row chain is
   // then never waited for inside the loop (the wave is in-order: a wait on a fresh index load at
   // the top of an iteration stalled the whole tile's compute behind an L2/HBM round trip)
@@ -184,8 +192,8 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int64_t off = (int64_t)slot_next[p] * tok_bytes + head_off;
-      kreg[p] = ld16(a.kbuf + off);
-      vreg[p] = ld16(a.vbuf + off);
+      kreg[p] = *(const raw_t*)(a.kbuf + off);
+      vreg[p] = *(const raw_t*)(a.vbuf + off);
     }
     fetch_slots(tile + 1);
   };
@@ -195,8 +203,13 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int row = p * RPP + st_row;
-      st16(dK + row * SK + st_ch * 16, kreg[p]);
-      st16(dV + row * SV + st_ch * 16, vreg[p]);
+      if constexpr (KV8) {
+        st16(dK + row * SK + st_ch * 16, expand_e5m2x8(kreg[p]));
+        st16(dV + row * SV + st_ch * 16, expand_e5m2x8(vreg[p]));
+      } else {
+        st16(dK + row * SK + st_ch * 16, kreg[p]);
+        st16(dV + row * SV + st_ch * 16, vreg[p]);
+      }
     }
   };
 
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
         // register quad and waits lgkmcnt(0) before every MFMA)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) s[kb] = mfma32<Tag>(kf[ks], qf[ks], s[kb]);
+        for (int ks = 0; ks < KSTEPS; ++ks) s[kb] = mfma32<CT>(kf[ks], qf[ks], s[kb]);
       }
       // ---- scale, mask, online softmax (query row on the lane; keys in registers + lane^32)
       float mx = kNegBigX;
@@ -316,9 +329,9 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
           u32x4 pf;  // B operand: registers 8s..8s+7 of the S^T block, rounded to the KV dtype
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            pf[j] = pack2<Tag>(s[kb][8 * sidx + 2 * j], s[kb][8 * sidx + 2 * j + 1]);
+            pf[j] = pack2<CT>(s[kb][8 * sidx + 2 * j], s[kb][8 * sidx + 2 * j + 1]);
 #pragma unroll
-          for (int db = 0; db < DBLK; ++db) oacc[db] = mfma32<Tag>(vf[sidx][db], pf, oacc[db]);
+          for (int db = 0; db < DBLK; ++db) oacc[db] = mfma32<CT>(vf[sidx][db], pf, oacc[db]);
         }
       }
     }
@@ -348,7 +361,8 @@ static int launch_extend(const ExtendArgs& a, int max_extend_len, int halves, hi
   typedef ExtCfg<D> C;
   constexpr int BM = 128 / GK;
   const dim3 grid((max_extend_len + BM - 1) / BM, a.Hkv * halves, a.bs);
-  extend_mfma_kernel<Tag, D, GK><<<grid, 256, C::kLdsBytes, st>>>(a);
+  if (a.kv8) extend_mfma_kernel<Tag, D, GK, true><<<grid, 256, C::kLdsBytes, st>>>(a);
+  else extend_mfma_kernel<Tag, D, GK, false><<<grid, 256, C::kLdsBytes, st>>>(a);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
@@ -372,11 +386,12 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
                     int idx64, const int32_t* extend_seq_lens, const int32_t* extend_start_loc,
                     int batch_size, int num_q_heads, int num_kv_heads, int head_dim, int64_t q_stride,
                     int64_t out_stride, int64_t kv_buffer_stride, float sm_scale, float logit_cap,
-                    int causal, int window_left, int max_extend_len, int dtype, hipStream_t st) {
+                    int causal, int window_left, int max_extend_len, int dtype, int kv8, hipStream_t st) {
   if (dtype != SP_F16 && dtype != SP_BF16) return SP_ERR_UNSUPPORTED;
   if (head_dim != 64 && head_dim != 128) return SP_ERR_UNSUPPORTED;
   if (batch_size > 65535 || num_kv_heads * 2 > 65535) return SP_ERR_UNSUPPORTED;
   if (q_stride % 8 || out_stride % 4 || kv_buffer_stride % 8) return SP_ERR_UNSUPPORTED;
+  if (kv8 && (((uintptr_t)k_buffer | (uintptr_t)v_buffer) & 7)) return SP_ERR_UNSUPPORTED;
   ExtendArgs a;
   a.out = out; a.q = q; a.kbuf = (const char*)k_buffer; a.vbuf = (const char*)v_buffer;
   a.r2t = req_to_token; a.r2t_stride = req_to_token_stride; a.req_idx = req_pool_indices;
@@ -385,6 +400,7 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
   a.q_stride = q_stride; a.o_stride = out_stride; a.kv_stride = kv_buffer_stride;
   a.sm_scale = sm_scale; a.logit_cap = logit_cap; a.causal = causal;
   a.window = causal ? window_left : -1;
+  a.kv8 = kv8;
   const int G = num_q_heads / num_kv_heads;
   if (max_extend_len <= 0) return SP_OK;
   if (dtype == SP_BF16) {

@@ -142,6 +142,48 @@ __device__ __forceinline__ u32x4 pack16<f16_tag>(const float* f) {
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *(const u32x4*)p; }
 __device__ __forceinline__ void st16(void* p, const u32x4& v) { *(u32x4*)p = v; }
 
+// ---- fp8 e5m2 (1-5-2 = the top byte of an IEEE half) ---------------------------------------------
+// 8 e5m2 bytes -> 8 halves, exactly: each byte becomes the high byte of a 16-bit lane (v_perm_b32)
+__device__ __forceinline__ u32x4 expand_e5m2x8(const u32x2& w) {
+  u32x4 o;
+  o[0] = __builtin_amdgcn_perm(w[0], w[0], 0x010c000cu);   // [0, b0, 0, b1]
+  o[1] = __builtin_amdgcn_perm(w[0], w[0], 0x030c020cu);   // [0, b2, 0, b3]
+  o[2] = __builtin_amdgcn_perm(w[1], w[1], 0x010c000cu);
+  o[3] = __builtin_amdgcn_perm(w[1], w[1], 0x030c020cu);
+  return o;
+}
+// float -> e5m2 byte: one round-to-nearest-even from fp32 (normal and subnormal results), overflow
+// -> inf, NaN -> NaN - the arithmetic of torch's .to(torch.float8_e5m2)
+__device__ __forceinline__ uint32_t f32_to_e5m2_bits(float f) {
+  uint32_t x = as_u32(f);
+  const uint32_t sign = x & 0x80000000u;
+  x ^= sign;
+  uint32_t r;
+  if (x >= (143u << 23)) {                       // |f| >= 2^16, inf, NaN
+    r = x > (0xffu << 23) ? 0x7fu : 0x7cu;
+  } else if (x < (113u << 23)) {                 // below 2^-14: the result is an e5m2 subnormal
+    const float aligned = as_f32(x) + as_f32(134u << 23);   // ulp of (|f| + 128) is 2^-16
+    r = as_u32(aligned) - (134u << 23);
+  } else {
+    const uint32_t odd = (x >> 21) & 1u;
+    x += ((uint32_t)(15 - 127) << 23) + 0xfffffu + odd;     // rebias, round half to even
+    r = x >> 21;
+  }
+  return (r & 0xffu) | (sign >> 24);
+}
+// 8 bf16 -> 8 halves (exact for |x| in the half's normal range)
+__device__ __forceinline__ u32x4 bf16x8_to_f16x8(const u32x4& v) {
+  u32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f16x2_t h;
+    h[0] = (_Float16)as_f32(v[i] << 16);
+    h[1] = (_Float16)as_f32(v[i] & 0xffff0000u);
+    o[i] = __builtin_bit_cast(uint32_t, h);
+  }
+  return o;
+}
+
 // ---- wave reductions ------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

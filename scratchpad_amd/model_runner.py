@@ -117,7 +117,14 @@ class ModelRunner:
         self.server_args = server_args or ServerArgs()
         self.tp_rank, self.tp_size = tp_rank, tp_size
         self.dtype = dtype
-        self.kv_cache_dtype = dtype
+        # model_runner.py:360-372: "auto" = the model dtype; "fp8_e5m2" = 1-byte KV
+        kvd = self.server_args.kv_cache_dtype
+        if kvd == "auto":
+            self.kv_cache_dtype = dtype
+        elif kvd == "fp8_e5m2":
+            self.kv_cache_dtype = torch.float8_e5m2
+        else:
+            raise ValueError(f"Unsupported kv_cache_dtype: {kvd}.")
         self.gpu_id = gpu_id
         if device == "cuda":
             if not torch.cuda.is_available():

@@ -166,12 +166,13 @@ class MHATokenToKVPool(KVCache):
                  layer_num: int, device: str, enable_memory_saver: bool = False):
         if page_size != 1:
             raise NotImplementedError("page_size > 1 (reference: model_runner.py:431-432)")
-        if dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        if dtype not in (torch.float32, torch.float16, torch.bfloat16, torch.float8_e5m2):
             raise NotImplementedError(f"KV cache dtype {dtype} is not built")
         self.size = size
         self.page_size = page_size
         self.dtype = dtype
-        self.store_dtype = dtype
+        # pool.py:274-280: fp8 pools are stored as uint8 (index_put has no fp8 kernel in torch)
+        self.store_dtype = torch.uint8 if dtype == torch.float8_e5m2 else dtype
         self.device = device
         self.head_num = head_num
         self.head_dim = head_dim
@@ -214,12 +215,14 @@ class MHATokenToKVPool(KVCache):
     def get_key_buffer(self, layer_id: int):
         if self.layer_transfer_counter is not None:
             self.layer_transfer_counter.wait_until(layer_id)
-        return self.k_buffer[layer_id]
+        buf = self.k_buffer[layer_id]
+        return buf.view(self.dtype) if self.store_dtype != self.dtype else buf     # pool.py:366-371
 
     def get_value_buffer(self, layer_id: int):
         if self.layer_transfer_counter is not None:
             self.layer_transfer_counter.wait_until(layer_id)
-        return self.v_buffer[layer_id]
+        buf = self.v_buffer[layer_id]
+        return buf.view(self.dtype) if self.store_dtype != self.dtype else buf
 
     def get_kv_buffer(self, layer_id: int):
         return self.get_key_buffer(layer_id), self.get_value_buffer(layer_id)
@@ -228,6 +231,12 @@ class MHATokenToKVPool(KVCache):
                       k_scale: Optional[float] = None, v_scale: Optional[float] = None):
         """pool.py:392-424: k_buffer[layer][loc] = cache_k (one HIP scatter for K and V)."""
         layer_id = layer.layer_id
+        if self.dtype == torch.float8_e5m2:
+            # divide by the scales and round to e5m2 inside the scatter (pool.py:401-412)
+            _native.kv_store_fp8(self.k_buffer[layer_id], self.v_buffer[layer_id], loc, cache_k, cache_v,
+                                 1.0 if k_scale is None else float(k_scale),
+                                 1.0 if v_scale is None else float(v_scale))
+            return
         if cache_k.dtype != self.dtype:
             if k_scale is not None:
                 cache_k.div_(k_scale)
