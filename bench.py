@@ -319,7 +319,7 @@ def serve_main(args, rank, local_rank, world):
     pool = max_running * (args.prefix + in_hi + out_hi) + 4096
     buckets = sorted(set([1, 2, 4] + list(range(8, max_running + 1, 8)) + [max_running]))
     sargs = ServerArgs(max_total_tokens=pool, max_running_requests=max_running, disable_cuda_graph=args.no_graph,
-                       cuda_graph_max_bs=max_running, cuda_graph_bs=buckets)
+                       cuda_graph_max_bs=max_running, cuda_graph_bs=buckets, kv_cache_dtype=args.kv_cache_dtype)
     mr = ModelRunner(cfg, sargs, dtype=torch.bfloat16, gpu_id=local_rank, seed=rank)
     mr.init_cuda_graphs()
     worker = TpModelWorker(mr)
@@ -432,7 +432,8 @@ def serve_main(args, rank, local_rank, world):
            "config": {"workload": f"llama3-8b TP=1 bf16 continuous batching: {n_req} requests, prompts U[{in_lo},{in_hi}]"
                                   f" (+{args.prefix} shared prefix), outputs U[{out_lo},{out_hi}], max running {max_running}, "
                                   f"arrival {'all at t=0' if args.rate <= 0 else f'Poisson {args.rate}/s'}, "
-                                  f"extend batches <= {args.max_prefill_tokens} tokens, RadixCache on",
+                                  f"extend batches <= {args.max_prefill_tokens} tokens, RadixCache on"
+                                  f"{', KV cache fp8_e5m2' if args.kv_cache_dtype != 'auto' else ''}",
                       "input_tokens": total_in, "output_tokens": total_out, "extend_steps": steps["extend"],
                       "decode_steps": steps["decode"], "prefix_cache_hit_tokens": steps["hit_tokens"]},
            "duration_s": round(dur, 3), "total_tokens_per_sec": round((total_in + total_out) / dur, 1),
