@@ -100,9 +100,11 @@ class HipAttnBackend(AttentionBackend):
     Constructed with a ``model_runner`` like the reference's backends (reads ``model_config``,
     ``tp_size``, ``token_to_kv_pool``, ``req_to_token_pool``, ``device``)."""
 
-    # work items (request x split x head-group) we want per launch, so that 256 CUs x 3-4
-    # resident workgroups see several waves of work and the ragged tail stays short
-    TARGET_ITEMS = 2048
+    # work items (request x split x head-group) we want per launch: one per CU.  Measured sweep
+    # (tools/bench_decode_attn.py, bs 1-128 x ctx 1024/4096): fewer, longer workgroups win as soon
+    # as every CU has one - the per-workgroup prologue (index -> gather -> first tile) is amortised
+    # over more tiles - e.g. bs 32 x 1024: chunk 256 (256 items) 28.5 us vs chunk 64 (1024) 34.1 us
+    TARGET_ITEMS = 256
     MIN_CHUNK, MAX_CHUNK = 64, 512
     # LlamaAttention may hand rotary + KV store to the backend as one kernel (sp_rotary_embedding
     # with pool arguments); set False to keep the reference's two-step order
@@ -129,9 +131,7 @@ class HipAttnBackend(AttentionBackend):
         self.sliding_window_size = sw if sw not in (None, -1) else None
         self._window = None            # (lens, kv_start) of the windowed layers, this step
         self._graph_window = None
-        self._graph_workspace = None
-        self._graph_plans = None
-        self._graph_chunk = None
+        self._graph_state = {}         # bs bucket -> (chunk, workspace, plan buffers) of its captured graph
 
     # ---------------------------------------------------------------- launch planning
     def _head_groups(self, dtype: torch.dtype) -> int:
@@ -208,13 +208,9 @@ class HipAttnBackend(AttentionBackend):
         """Static split geometry + workspace for graph replay (triton_backend.py:70-80 allocates
         static attn_logits the same way)."""
         self.cuda_graph_max_seq_len = self.max_context_len
-        pool_dtype = self.kv_dtype
-        self._graph_chunk = self._plan_chunk(max_bs * self.max_context_len // 2, pool_dtype)
-        nbytes = _native.decode_workspace_bytes(max_bs, self.num_head, self.v_head_dim,
-                                                self.cuda_graph_max_seq_len, self._graph_chunk)
-        self._graph_workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        n = _native.decode_plan_bytes(max_bs, self.cuda_graph_max_seq_len, self._graph_chunk) // 4
-        self._graph_plans = [torch.empty(n, dtype=torch.int32, device=self.device) for _ in range(3)]
+        # split geometry is part of the captured launches, so it is chosen per batch-size bucket at
+        # capture time (a bs-1 graph wants 64-key splits, a bs-256 graph 512-key ones)
+        self._graph_state = {}
         if self.sliding_window_size is not None:
             self._graph_window = tuple(torch.ones(max_bs, dtype=torch.int32, device=self.device)
                                        for _ in range(2))
@@ -223,11 +219,16 @@ class HipAttnBackend(AttentionBackend):
                                                  encoder_lens, forward_mode, spec_info=None):
         assert forward_mode.is_decode(), "only decode is captured"
         assert spec_info is None, "speculative decoding is out of scope"
+        chunk = self._plan_chunk(bs * self.max_context_len // 2, self.kv_dtype)
+        ws = torch.empty(_native.decode_workspace_bytes(bs, self.num_head, self.v_head_dim,
+                                                        self.cuda_graph_max_seq_len, chunk),
+                         dtype=torch.uint8, device=self.device)
+        n = _native.decode_plan_bytes(bs, self.cuda_graph_max_seq_len, chunk) // 4
+        plan_bufs = [torch.empty(n, dtype=torch.int32, device=self.device) for _ in range(3)]
+        self._graph_state[bs] = (chunk, ws, plan_bufs)
         self._window = self._window_of(seq_lens, self._graph_window, bs)
-        plans = self._build_plans(self._graph_plans, bs, seq_lens, encoder_lens,
-                                  self.cuda_graph_max_seq_len, self._graph_chunk)
-        self.forward_metadata = (self._graph_chunk, self.cuda_graph_max_seq_len,
-                                 self._graph_workspace, plans)
+        plans = self._build_plans(plan_bufs, bs, seq_lens, encoder_lens, self.cuda_graph_max_seq_len, chunk)
+        self.forward_metadata = (chunk, self.cuda_graph_max_seq_len, ws, plans)
 
     def init_forward_metadata_replay_cuda_graph(self, bs, req_pool_indices, seq_lens, seq_lens_sum,
                                                 encoder_lens, forward_mode, spec_info=None,
@@ -236,12 +237,12 @@ class HipAttnBackend(AttentionBackend):
         # static input buffers; only the split plan (static buffer, fixed address) is rebuilt for
         # this step's lengths, ahead of the replay - where the reference recomputes start_loc /
         # kv_indices (triton_backend.py:103-113, flashinfer_backend.py:330-373)
+        chunk, ws, plan_bufs = self._graph_state[bs]
         self._window = self._window_of(seq_lens[:bs], self._graph_window, bs)
-        plans = self._build_plans(self._graph_plans, bs, seq_lens[:bs],
+        plans = self._build_plans(plan_bufs, bs, seq_lens[:bs],
                                   None if encoder_lens is None else encoder_lens[:bs],
-                                  self.cuda_graph_max_seq_len, self._graph_chunk)
-        self.forward_metadata = (self._graph_chunk, self.cuda_graph_max_seq_len,
-                                 self._graph_workspace, plans)
+                                  self.cuda_graph_max_seq_len, chunk)
+        self.forward_metadata = (chunk, self.cuda_graph_max_seq_len, ws, plans)
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1  # padded rows attend to the dummy slot 0 only (triton_backend.py:115-116)
