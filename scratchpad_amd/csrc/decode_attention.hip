@@ -294,7 +294,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeArgs a) {
   }
 }
 
-// one wave per (request, q head): combine the split partials by their log2-sum-exp
+// one wave per (request, q head): combine the split partials by their log2-sum-exp.  The partials of
+// up to 16 splits (log-sum-exp and the lane's output elements) are loaded in one go - a single memory
+// round trip instead of a max pass followed by a dependent accumulate pass - and merged online across
+// groups of 16 (the launch is latency-bound at small batch: 9 us for a few KB).
 template <typename Tag, int D>
 __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
   typedef Elem<Tag> E;
@@ -307,17 +310,36 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
   if (nsplit <= 1) return;  // written directly by the attention kernel (or empty row)
   const float* lse = a.part_lse + (int64_t)pair * a.num_splits;
   const float* po = a.part_o + (int64_t)pair * a.num_splits * D;
-  float M = kNegBig;
-  for (int c = 0; c < nsplit; ++c) M = fmaxf(M, lse[c]);
   constexpr int PER = D / 64;
-  float o[PER], W = 0.f;
+  constexpr int GRP = 16;
+  float o[PER], W = 0.f, M = kNegBig;
 #pragma unroll
   for (int e = 0; e < PER; ++e) o[e] = 0.f;
-  for (int c = 0; c < nsplit; ++c) {
-    const float w = fast_exp2(lse[c] - M);
-    W += w;
+  for (int c0 = 0; c0 < nsplit; c0 += GRP) {
+    float ls[GRP], pv[GRP][PER];
 #pragma unroll
-    for (int e = 0; e < PER; ++e) o[e] += w * po[(int64_t)c * D + e * 64 + lane];
+    for (int c = 0; c < GRP; ++c) {
+      const bool live = c0 + c < nsplit;
+      const int cc = live ? c0 + c : c0;               // clamped: the load stays in bounds
+      ls[c] = live ? lse[cc] : kNegBig;
+#pragma unroll
+      for (int e = 0; e < PER; ++e) pv[c][e] = po[(int64_t)cc * D + e * 64 + lane];
+    }
+    float Mg = M;
+#pragma unroll
+    for (int c = 0; c < GRP; ++c) Mg = fmaxf(Mg, ls[c]);
+    const float rescale = fast_exp2(M - Mg);           // 0 on the first group (M = -1e30)
+    W *= rescale;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) o[e] *= rescale;
+#pragma unroll
+    for (int c = 0; c < GRP; ++c) {
+      const float w = c0 + c < nsplit ? fast_exp2(ls[c] - Mg) : 0.f;
+      W += w;
+#pragma unroll
+      for (int e = 0; e < PER; ++e) o[e] += w * pv[c][e];
+    }
+    M = Mg;
   }
 #pragma unroll
   for (int e = 0; e < PER; ++e)
