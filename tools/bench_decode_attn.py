@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--kv", default="same", choices=["same", "fp8"], help="fp8 = e5m2 byte pool")
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--no-plan", action="store_true")
     ap.add_argument("--gemm", action="store_true", help="interleave a bf16 GEMM between launches (as in a model)")
@@ -37,6 +38,9 @@ def main():
     P = total + 1024
     kb = torch.empty(P + 1, a.Hkv, a.D, dtype=dt, device=dev).normal_(0, 0.5)
     vb = torch.empty(P + 1, a.Hkv, a.D, dtype=dt, device=dev).normal_(0, 0.5)
+    if a.kv == "fp8":
+        kb = kb.to(torch.float8_e5m2).view(torch.uint8)
+        vb = vb.to(torch.float8_e5m2).view(torch.uint8)
     perm = (torch.randperm(P, generator=g) + 1).to(torch.int32)
     r2t = torch.zeros(a.bs, int(ctx.max()) + 8, dtype=torch.int32)
     off = 0
@@ -50,7 +54,8 @@ def main():
     q = torch.randn(a.bs, a.Hq, a.D, device=dev).to(dt)
     o = torch.empty_like(q)
     eb = q.element_size()
-    alg = total * 2 * a.Hkv * a.D * eb + 2 * a.bs * a.Hq * a.D * eb + 4 * total
+    kv_eb = 1 if a.kv == "fp8" else eb
+    alg = total * 2 * a.Hkv * a.D * kv_eb + 2 * a.bs * a.Hq * a.D * eb + 4 * total
     max_len = int(ctx.max())
     ref = None
     for chunk in [int(c) for c in a.chunks.split(",")]:
