@@ -41,6 +41,8 @@ class ModelConfig:
     # Mllama text model: indices of the cross-attention decoder layers (None = plain Llama)
     cross_attention_layers: Optional[List[int]] = None
     pad_token_id: Optional[int] = None
+    # Mllama: the vision tower's config (MllamaVisionConfig fields); None = text side only
+    vision_config: Optional[object] = None
 
     @property
     def is_encoder_decoder(self) -> bool:

@@ -38,6 +38,8 @@ class Req:
     # encoder-decoder models: the first num_image_tokens ids of origin_input_ids are the image pad
     # ids (mllama.py pad_input_ids 803-816; MultimodalInputs.num_image_tokens)
     num_image_tokens: Optional[int] = None
+    # MultimodalInputs of the request (mm_items with pixel_values / aspect_ratio_id / aspect_ratio_mask)
+    multimodal_inputs: object = None
 
     @property
     def fill_ids(self) -> List[int]:
@@ -328,4 +330,5 @@ class ScheduleBatch:
             extend_prefix_lens=extend_prefix_lens, capture_hidden_mode=CaptureHiddenMode.NULL,
             encoder_cached=self.encoder_cached, encoder_lens=self.encoder_lens,
             encoder_lens_cpu=self.encoder_lens_cpu, encoder_out_cache_loc=self.encoder_out_cache_loc,
+            multimodal_inputs=[r.multimodal_inputs for r in self.reqs],
             sampling_info=self.sampling_info)
