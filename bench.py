@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--requests", type=int, default=512, help="serve mode: number of requests in the trace")
     ap.add_argument("--max-input", type=int, default=2048, help="serve mode: prompts are U[128, max-input]")
     ap.add_argument("--max-output", type=int, default=128, help="serve mode: outputs are U[16, max-output]")
+    ap.add_argument("--sample", action="store_true",
+                    help="serve mode: temperature 0.8 / top-p 0.9 / top-k 50 sampling instead of greedy")
     ap.add_argument("--rate", type=float, default=0.0, help="serve mode: Poisson arrival rate (req/s); 0 = all at t=0")
     ap.add_argument("--mode", default="decode", choices=["decode", "prefill", "serve"],
                     help="decode = the headline metric; prefill = config 3 (ragged prefill, TTFT)")
@@ -296,6 +298,7 @@ def serve_main(args, rank, local_rank, world):
     import random
     from scratchpad_amd.model_runner import ModelConfig, ModelRunner, ServerArgs, TpModelWorker
     from scratchpad_amd.radix_cache import RadixCache
+    from scratchpad_amd.sampler import SamplingBatchInfo, SamplingParams
     from scratchpad_amd.schedule_batch import Req, ScheduleBatch
     rnd = random.Random(rank)
     n_req = args.requests
@@ -325,12 +328,14 @@ def serve_main(args, rank, local_rank, world):
     worker = TpModelWorker(mr)
     alloc, r2t, dev = mr.token_to_kv_pool_allocator, mr.req_to_token_pool, mr.device
     tree = RadixCache(r2t, alloc)
+    sampling = SamplingParams(temperature=0.8, top_p=0.9, top_k=50) if args.sample else None
+    mr.sampler.generator = torch.Generator(device=dev).manual_seed(rank)
 
     def run_trace():
         tree.reset()
         r2t.clear()
         alloc.clear()
-        reqs = [Req(str(i), list(prompts[i])) for i in range(n_req)]
+        reqs = [Req(str(i), list(prompts[i]), sampling_params=sampling) for i in range(n_req)]
         waiting = list(range(n_req))
         running = None
         first_t, last_t, itl = [None] * n_req, [None] * n_req, []
@@ -358,6 +363,8 @@ def serve_main(args, rank, local_rank, world):
             if admit:
                 nb = ScheduleBatch([reqs[i] for i in admit], r2t, alloc, dev, tree_cache=tree)
                 nb.prepare_for_extend()
+                if args.sample:
+                    nb.sampling_info = SamplingBatchInfo.from_schedule_batch(nb, cfg.vocab_size)
                 _, ids = worker.forward_batch_generation(nb.get_model_worker_batch())
                 toks = ids.tolist()                     # first tokens reach the host
                 t = now()
@@ -428,7 +435,8 @@ def serve_main(args, rank, local_rank, world):
            "n_gpus": world, "steps": steps["extend"] + steps["decode"], "warmup": 1,
            "ms_per_step": round(dur * 1e3 / (steps["extend"] + steps["decode"]), 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-           "data": "synthetic (random-init weights, random token ids, greedy sampling)",
+           "data": "synthetic (random-init weights, random token ids, "
+                   + ("temperature 0.8 / top-p 0.9 / top-k 50 sampling)" if args.sample else "greedy sampling)"),
            "config": {"workload": f"llama3-8b TP=1 bf16 continuous batching: {n_req} requests, prompts U[{in_lo},{in_hi}]"
                                   f" (+{args.prefix} shared prefix), outputs U[{out_lo},{out_hi}], max running {max_running}, "
                                   f"arrival {'all at t=0' if args.rate <= 0 else f'Poisson {args.rate}/s'}, "
