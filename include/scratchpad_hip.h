@@ -114,6 +114,7 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  * For request b and q head h:  o = softmax(q.K[idx]^T * sm_scale [soft-capped]) . V[idx],
  *   idx = req_to_token[req_pool_indices[b], kv_start[b] : kv_start[b] + seq_lens[b]]
  * q,o: [bs, Hq, D]; buffers [P+1, Hkv, D] with token stride kv_buffer_stride; page_size = 1.
+ * Hq / Hkv (query heads per KV head): any value 1..16 for fp16/bf16, 1/2/4/8 for fp32; D 64 or 128.
  * A row with seq_lens[b] == 0 (no visible key) is left untouched: pre-fill `out` where that can
  * happen (cross-attention of text-only requests).
  * kv_start may be NULL (= 0); it is the encoder offset of encoder-decoder models

@@ -491,7 +491,7 @@ int run_decode(const DecodeArgs& a, int head_dim, int group, int dtype, hipStrea
     const int rc = run_decode_mfma(a, head_dim, dtype, st);
     return rc == SP_OK ? run_decode_merge(a, head_dim, dtype, st) : rc;
   }
-  if (decode_kernel_choice(a.Hq / a.Hkv, dtype) == 2) {
+  if (group > 8 || decode_kernel_choice(a.Hq / a.Hkv, dtype) == 2) {   // groups 9..16: matrix-core kernel only
     const int rc = run_decode_mfma(a, head_dim, dtype, st);
     if (rc == SP_OK) return run_decode_merge(a, head_dim, dtype, st);
     if (rc != SP_ERR_UNSUPPORTED) return rc;
@@ -572,13 +572,10 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
   SP_CHECK_ARG(q_stride % vec == 0 && kv_buffer_stride % (kv8 ? 8 : vec) == 0);
   SP_CHECK_ARG(!kv8 || (((uintptr_t)k_buffer & 7) == 0 && ((uintptr_t)v_buffer & 7) == 0));
   const int G = num_q_heads / num_kv_heads;
-  int Gk = G, qblocks = 1;  // groups wider than 8 are processed 8 query heads at a time
-  if (G > 8) {
-    if (G % 8) return SP_ERR_UNSUPPORTED;
-    Gk = 8;
-    qblocks = G / 8;
-  }
-  if (qblocks != 1) return SP_ERR_UNSUPPORTED;  // TODO(next): loop q-head blocks over one KV read
+  // query heads per KV head: the matrix-core kernel tiles up to 16 of them as MFMA columns (16-bit
+  // dtypes); the VALU kernel (fp32) holds up to 8 in registers
+  if (G > 16 || (G > 8 && dtype == SP_F32)) return SP_ERR_UNSUPPORTED;
+  const int Gk = G;
   if (head_dim != 64 && head_dim != 128) return SP_ERR_UNSUPPORTED;
 
   const int64_t S = num_splits_for(max_seq_len, chunk);

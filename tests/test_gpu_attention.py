@@ -460,3 +460,24 @@ def test_random_shapes_decode_and_extend_against_oracle(nat):
                                        start.cpu(), scale, cap, causal=causal, window_left=window)
             assert_close(o, ref, dtype, what=what + f" extend causal{causal} window{window}",
                          vmax=float(p["v_buffer"].abs().max()))
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("Hq,Hkv,D", [(16, 1, 128), (32, 2, 128), (12, 2, 64), (24, 8, 128), (10, 2, 128)])
+def test_decode_wide_and_odd_groups_on_the_matrix_core_kernel(nat, dt, Hq, Hkv, D, monkeypatch):
+    """Query-head groups that are not 1/2/4/8 (up to 16 heads per KV head, e.g. Llama-3.1-405B's 128/8):
+    the MFMA decode kernel carries the group as tile columns, so any width <= 16 works."""
+    monkeypatch.delenv("SP_DECODE_KERNEL", raising=False)
+    dtype = DTYPES[dt]
+    lens = [1, 17, 64, 65, 300, 513, 1000, 129]
+    p = paged_problem(81, len(lens), Hq, Hkv, D, lens, dtype, DEV)
+    scale = D ** -0.5
+    ref = oracle_decode(p, scale)
+    vmax = float(p["v_buffer"].float().abs().max())
+    for chunk, use_plan in ((64, True), (256, False)):
+        assert_close(run_decode(nat, p, scale, chunk=chunk, use_plan=use_plan), ref, dtype,
+                     what=f"G={Hq // Hkv} chunk {chunk}", vmax=vmax)
+    if Hq // Hkv > 8:
+        with pytest.raises(RuntimeError, match="unsupported"):      # fp32 keeps the 8-head limit
+            p32 = paged_problem(82, 2, Hq, Hkv, D, [5, 9], torch.float32, DEV)
+            run_decode(nat, p32, scale)
