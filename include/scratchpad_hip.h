@@ -157,7 +157,7 @@ SP_API int sp_decode_attention(void* out, const void* q, const void* k_buffer, c
  * flashinfer_backend.py:413: the row at kv position p sees keys [p - window_left, p]; -1 = no
  * window.  (Decode needs no such argument: the caller passes kv_start = seq_len - min(seq_len,
  * window + 1) and that length, flashinfer_backend.py:559-577.)
- * q,o: [T, Hq, D]; extend_* are int32 [bs].
+ * q,o: [T, Hq, D]; extend_* are int32 [bs].  Hq / Hkv: any width for fp16/bf16, 1/2/4/8 for fp32.
  * num_tokens = sum(extend_seq_lens) (host-known: ForwardBatch.extend_num_tokens) and
  * max_extend_len >= max(extend_seq_lens), max_seq_len >= max(seq_lens) fix the launch geometry.
  * workspace: sp_extend_attention_workspace_bytes().                                              */

@@ -74,7 +74,8 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
   if (batch_size == 0 || num_tokens == 0) return SP_OK;
   if (head_dim != 64 && head_dim != 128) return SP_ERR_UNSUPPORTED;
   const int G = num_q_heads / num_kv_heads;
-  if (G != 1 && G != 2 && G != 4 && G != 8) return SP_ERR_UNSUPPORTED;
+  // fp32 (row streams on the VALU decode kernel): 1/2/4/8 query heads per KV head; 16-bit: any width
+  if (dtype == SP_F32 && G != 1 && G != 2 && G != 4 && G != 8) return SP_ERR_UNSUPPORTED;
   const int vec = dtype == SP_F32 ? 4 : 8;
   SP_CHECK_ARG(q_stride % vec == 0 && kv_buffer_stride % vec == 0);
   if (num_tokens > 0x7fffffffLL / 64) return SP_ERR_INVALID_ARG;

@@ -369,17 +369,16 @@ static int launch_extend(const ExtendArgs& a, int max_extend_len, int halves, hi
 
 template <typename Tag, int D>
 static int dispatch_extend_group(const ExtendArgs& a, int G, int max_extend_len, hipStream_t st) {
-  switch (G) {
-    case 1: return launch_extend<Tag, D, 1>(a, max_extend_len, 1, st);
-    case 2: return launch_extend<Tag, D, 2>(a, max_extend_len, 1, st);
-    case 4: return launch_extend<Tag, D, 4>(a, max_extend_len, 1, st);
-    case 8: return launch_extend<Tag, D, 4>(a, max_extend_len, 2, st);
-    default: return SP_ERR_UNSUPPORTED;
-  }
+  // a workgroup's 4 waves take Gk = 4, 2 or 1 query heads of the KV head (the largest that divides G)
+  // and the remaining G / Gk head blocks become extra workgroups: any group width works
+  if (G < 1 || G > 64) return SP_ERR_UNSUPPORTED;
+  if (G % 4 == 0) return launch_extend<Tag, D, 4>(a, max_extend_len, G / 4, st);
+  if (G % 2 == 0) return launch_extend<Tag, D, 2>(a, max_extend_len, G / 2, st);
+  return launch_extend<Tag, D, 1>(a, max_extend_len, G, st);
 }
 
-// 16-bit dtypes, D in {64,128}, G in {1,2,4,8}; anything else returns SP_ERR_UNSUPPORTED and the
-// caller takes the row-stream path.
+// 16-bit dtypes, D in {64,128}; anything else returns SP_ERR_UNSUPPORTED and the caller takes the
+// row-stream path.
 int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* v_buffer,
                     const int32_t* req_to_token, int64_t req_to_token_stride,
                     const void* req_pool_indices, const void* seq_lens, const void* kv_start,
@@ -389,7 +388,7 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
                     int causal, int window_left, int max_extend_len, int dtype, int kv8, hipStream_t st) {
   if (dtype != SP_F16 && dtype != SP_BF16) return SP_ERR_UNSUPPORTED;
   if (head_dim != 64 && head_dim != 128) return SP_ERR_UNSUPPORTED;
-  if (batch_size > 65535 || num_kv_heads * 2 > 65535) return SP_ERR_UNSUPPORTED;
+  if (batch_size > 65535 || num_q_heads > 65535) return SP_ERR_UNSUPPORTED;   // grid.z, grid.y
   if (q_stride % 8 || out_stride % 4 || kv_buffer_stride % 8) return SP_ERR_UNSUPPORTED;
   if (kv8 && (((uintptr_t)k_buffer | (uintptr_t)v_buffer) & 7)) return SP_ERR_UNSUPPORTED;
   ExtendArgs a;

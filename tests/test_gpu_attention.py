@@ -481,3 +481,22 @@ def test_decode_wide_and_odd_groups_on_the_matrix_core_kernel(nat, dt, Hq, Hkv, 
         with pytest.raises(RuntimeError, match="unsupported"):      # fp32 keeps the 8-head limit
             p32 = paged_problem(82, 2, Hq, Hkv, D, [5, 9], torch.float32, DEV)
             run_decode(nat, p32, scale)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("Hq,Hkv,D", [(16, 1, 128), (12, 2, 64), (24, 8, 128), (10, 2, 128), (32, 2, 128)])
+def test_extend_wide_and_odd_groups(nat, dt, Hq, Hkv, D):
+    """Group widths other than 1/2/4/8: the tile kernel takes 4, 2 or 1 heads per workgroup and spreads
+    the remaining head blocks over the grid."""
+    dtype = DTYPES[dt]
+    pre = [0, 64, 300, 5]
+    ext = [130, 1, 70, 257]
+    p, q, ext_t, start = extend_problem(91, Hq, Hkv, D, pre, ext, dtype)
+    scale = D ** -0.5
+    o = run_extend(nat, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"],
+                   p["seq_lens"], ext_t, start, scale)
+    c = cpu(p)
+    ref = ops.extend_attention(q.cpu().float(), c["k_buffer"].float(), c["v_buffer"].float(),
+                               c["req_to_token"], c["req_pool_indices"], c["seq_lens"], ext_t.cpu(),
+                               start.cpu(), scale)
+    assert_close(o, ref, dtype, what=f"extend G={Hq // Hkv}", vmax=float(c["v_buffer"].float().abs().max()))
