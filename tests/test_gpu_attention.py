@@ -500,3 +500,31 @@ def test_extend_wide_and_odd_groups(nat, dt, Hq, Hkv, D):
                                c["req_to_token"], c["req_pool_indices"], c["seq_lens"], ext_t.cpu(),
                                start.cpu(), scale)
     assert_close(o, ref, dtype, what=f"extend G={Hq // Hkv}", vmax=float(c["v_buffer"].float().abs().max()))
+
+
+def test_long_context_decode_and_extend(nat):
+    """Contexts far beyond the headline range (40 k keys): many splits per request in decode, hundreds
+    of key tiles per row block in extend, slot ids past 2^16."""
+    dtype = torch.bfloat16
+    Hq, Hkv, D = 32, 8, 128
+    lens = [40000, 33001, 7]
+    p = paged_problem(97, 3, Hq, Hkv, D, lens, dtype, DEV, scale=0.5)
+    scale = D ** -0.5
+    ref = oracle_decode(p, scale)
+    vmax = float(p["v_buffer"].float().abs().max())
+    for chunk in (512, 64):
+        assert_close(run_decode(nat, p, scale, chunk=chunk), ref, dtype, what=f"long decode chunk {chunk}", vmax=vmax)
+    # extend: 300 new tokens behind a 39,700-token cached prefix, and a short companion request
+    ext = [300, 5, 7]
+    pre = [lens[0] - 300, lens[1] - 5, 0]
+    g = torch.Generator().manual_seed(98)
+    q = (torch.randn(sum(ext), Hq, D, generator=g) * 0.5).to(dtype).to(DEV)
+    ext_t = torch.tensor(ext, dtype=torch.int32, device=DEV)
+    start = torch.tensor([0, 300, 305], dtype=torch.int32, device=DEV)
+    o = run_extend(nat, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"], p["seq_lens"],
+                   ext_t, start, scale)
+    c = cpu(p)
+    ref = ops.extend_attention(q.cpu().float(), c["k_buffer"].float(), c["v_buffer"].float(), c["req_to_token"],
+                               c["req_pool_indices"], c["seq_lens"], ext_t.cpu(), start.cpu(), scale)
+    assert_close(o, ref, dtype, what="long-prefix extend", vmax=vmax)
+    assert pre[0] == 39700
