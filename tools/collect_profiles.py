@@ -38,7 +38,7 @@ def main(tag):
             open(os.path.join(P, f"{tag}_{dst}"), "w").write(text)
     lines = {}
     for f in ("bench_decode", "bench_prefill", "bench_serve", "bench_serve_prefix", "bench_bs1", "bench_bs8",
-              "bench_bs32", "bench_ctx1024", "bench_fp8kv", "bench_70b_rank"):
+              "bench_bs32", "bench_ctx128", "bench_ctx1024", "bench_ctx4096", "bench_fp8kv", "bench_70b_rank"):
         p = os.path.join(R, f + ".json")
         if os.path.exists(p):
             d = last_json(p)

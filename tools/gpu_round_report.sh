@@ -18,7 +18,7 @@ timeout -k 10 400 python bench.py --mode serve > $R/bench_serve.json 2> $R/bench
 tail -1 $R/bench_serve.json | cut -c1-300
 timeout -k 10 400 python bench.py --mode serve --prefix 512 > $R/bench_serve_prefix.json 2> $R/bench_serve_prefix.err || { tail -20 $R/bench_serve_prefix.err; exit 1; }
 for b in 1 8 32; do timeout -k 10 200 python bench.py --bs $b --ctx 1024 --no-cpu-baseline 2>/dev/null | tail -1 > $R/bench_bs$b.json || exit 1; cut -c1-140 $R/bench_bs$b.json; done
-timeout -k 10 200 python bench.py --ctx 1024 --no-cpu-baseline 2>/dev/null | tail -1 > $R/bench_ctx1024.json || exit 1
+for c in 128 1024 4096; do timeout -k 10 300 python bench.py --ctx $c --no-cpu-baseline 2>/dev/null | tail -1 > $R/bench_ctx$c.json || exit 1; done
 timeout -k 10 300 python bench.py --kv-cache-dtype fp8_e5m2 --no-cpu-baseline 2>/dev/null | tail -1 > $R/bench_fp8kv.json || exit 1
 cut -c1-140 $R/bench_fp8kv.json
 timeout -k 10 300 python bench.py --model llama3-70b-tp8-rank --bs 128 --no-cpu-baseline 2>/dev/null | tail -1 > $R/bench_70b_rank.json || exit 1
