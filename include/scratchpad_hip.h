@@ -209,6 +209,23 @@ SP_API int sp_top_k_top_p_min_p_renorm(const float* probs, int64_t row_stride, c
 SP_API int sp_gemm_skinny(void* out, const void* x, const void* w, int M, int N, int K, int64_t x_stride,
                    int64_t w_stride, int64_t out_stride, int dtype, void* stream);
 
+/* ---- Direct all-reduce through IPC-mapped peer regions: fills GroupCoordinator.ca_comm
+ *      (distributed/parallel_state.py:266-267, 326-347; the reference never constructs one and always
+ *      calls NCCL, linear.py:1148-1149).  Each rank sp_ar_alloc()s one fine-grained region of
+ *      sp_ar_flag_bytes() + 2 * data_bytes, exports it (64-byte IPC handle), and imports every peer's.
+ *      sp_custom_all_reduce sums `num_elems` elements over the `world` ranks (one-shot up to 256 KiB,
+ *      reduce-scatter + all-gather above); `regions[r]` = rank r's region as mapped in this process;
+ *      `epoch` advances by 3 per call on every rank alike.  Opt-in (see allreduce.hip: not yet run across
+ *      xGMI).  These are the only entries that allocate; the region is owned by the caller's object. */
+SP_API size_t sp_ar_flag_bytes(void);
+SP_API int sp_ar_alloc(void** ptr, size_t bytes);
+SP_API int sp_ar_free(void* ptr);
+SP_API int sp_ar_ipc_export(void* ptr, void* handle64);
+SP_API int sp_ar_ipc_import(const void* handle64, void** ptr);
+SP_API int sp_ar_ipc_close(void* ptr);
+SP_API int sp_custom_all_reduce(void* out, const void* in, int64_t num_elems, int dtype, void* const* regions,
+                         int rank, int world, uint32_t epoch, size_t data_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

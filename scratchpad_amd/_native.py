@@ -62,6 +62,13 @@ SIGNATURES = {
     "sp_softmax_temperature": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp]),
     "sp_top_k_top_p_min_p_sample": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "sp_top_k_top_p_min_p_renorm": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "sp_ar_flag_bytes": (_sz, []),
+    "sp_ar_alloc": (_i32, [_vp, _sz]),
+    "sp_ar_free": (_i32, [_vp]),
+    "sp_ar_ipc_export": (_i32, [_vp, _vp]),
+    "sp_ar_ipc_import": (_i32, [_vp, _vp]),
+    "sp_ar_ipc_close": (_i32, [_vp]),
+    "sp_custom_all_reduce": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, ctypes.c_uint32, _sz, _vp]),
     "sp_gemm_skinny": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp]),
 }
 

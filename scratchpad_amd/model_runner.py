@@ -138,6 +138,9 @@ class ModelRunner:
         if not dist_.model_parallel_is_initialized():
             dist_.initialize_model_parallel(tp_size, local_rank=gpu_id)
         assert dist_.get_tensor_model_parallel_world_size() == tp_size
+        if tp_size > 1 and getattr(dist_.get_tp_group(), "ca_comm", None) is None:
+            from .custom_all_reduce import maybe_attach
+            maybe_attach(dist_.get_tp_group())      # opt-in (SP_CUSTOM_ALLREDUCE=1): direct IPC all-reduce
         self.sliding_window_size = None
         self.load_model(seed, init_weights)
         self.init_memory_pool()
@@ -276,11 +279,16 @@ class HipGraphRunner:
         model = self.model_runner.model
         if self.is_encoder_decoder:
             model.capture_mode = True      # cross-attention is always part of the captured step
+        import contextlib
+        ca = getattr(dist_.get_tp_group(), "ca_comm", None)
         try:
-            for bs in reversed(self.capture_bs):
-                graph, out = self.capture_one_batch_size(bs)
-                self.graphs[bs] = graph
-                self.output_buffers[bs] = out
+            # captured steps keep the library all-reduce (parallel_state.py:293-302 toggles its
+            # communicators the same way under graph_capture)
+            with (ca.capture() if ca is not None else contextlib.nullcontext()):
+                for bs in reversed(self.capture_bs):
+                    graph, out = self.capture_one_batch_size(bs)
+                    self.graphs[bs] = graph
+                    self.output_buffers[bs] = out
         finally:
             if self.is_encoder_decoder:
                 model.capture_mode = False

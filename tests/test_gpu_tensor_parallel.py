@@ -22,10 +22,11 @@ def _free_port():
     return port
 
 
-def _rank_main(rank, world, port, case, q):
+def _rank_main(rank, world, port, case, q, custom_ar=False):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
+        os.environ["SP_CUSTOM_ALLREDUCE"] = "1" if custom_ar else "0"
         from oracle import llama as ollama, ops
         from scratchpad_amd import distributed as d
         from scratchpad_amd.forward_info import ForwardMode, ModelWorkerBatch
@@ -45,6 +46,7 @@ def _rank_main(rank, world, port, case, q):
         mr = ModelRunner(cfg, ServerArgs(max_total_tokens=96, max_running_requests=3, disable_cuda_graph=True),
                          tp_rank=rank, tp_size=world, dtype=torch.float32, gpu_id=0, init_weights=False)
         assert mr.token_to_kv_pool.head_num == max(1, shape.Hkv // world), "each rank pools only its KV heads"
+        assert (d.get_tp_group().ca_comm is not None) == custom_ar
         mr.model.load_full_state_dict({k: v.to(mr.device) for k, v in w.items()})
         worker = TpModelWorker(mr)
         dev = mr.device
@@ -89,16 +91,72 @@ def _rank_main(rank, world, port, case, q):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,case", [(2, "a"), (2, "b"), (4, "a")],
-                         ids=["tp2-kv-replicated", "tp2-kv-sharded", "tp4-kv-replicated"])
-def test_sharded_forward_matches_unsharded_oracle(world, case):
+@pytest.mark.parametrize("world,case,custom_ar", [(2, "a", False), (2, "b", False), (4, "a", False), (2, "b", True)],
+                         ids=["tp2-kv-replicated", "tp2-kv-sharded", "tp4-kv-replicated", "tp2-direct-all-reduce"])
+def test_sharded_forward_matches_unsharded_oracle(world, case, custom_ar):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, case, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, case, q, custom_ar)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err in results:
+        assert err is None, f"rank {rank}:\n{err}"
+
+
+def _ar_main(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        from scratchpad_amd import distributed as d
+        from scratchpad_amd.custom_all_reduce import CustomAllReduce
+        d.init_distributed_environment(world, rank, f"tcp://127.0.0.1:{port}", 0, backend="gloo")
+        d.initialize_model_parallel(world, backend="gloo", local_rank=0)
+        torch.cuda.set_device(0)
+        tp = d.get_tp_group()
+        ca = CustomAllReduce(tp, max_bytes=4 << 20)
+        tp.ca_comm = ca
+        gen = torch.Generator().manual_seed(100)        # the same stream on every rank: rank r's input is slice r
+        for dtype, shape in ((torch.bfloat16, (128, 8192)), (torch.float16, (3, 4096)), (torch.float32, (7, 1024)),
+                             (torch.bfloat16, (1, 8)), (torch.bfloat16, (256, 4096))):
+            for rep in range(3):
+                allx = torch.randn(world, *shape, generator=gen).to(dtype)
+                x = allx[rank].cuda()
+                want = allx.float().sum(0)
+                assert ca.should_custom_ar(x)
+                y = d.tensor_model_parallel_all_reduce(x)       # goes through ca_comm
+                torch.cuda.synchronize()
+                eps = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11, torch.float32: 1e-6}[dtype]
+                err = (y.float().cpu() - want).abs()
+                assert bool((err <= eps * want.abs() + 1e-5).all()), (rank, dtype, shape, float(err.max()))
+                gathered = [None] * world
+                torch.distributed.all_gather_object(gathered, y.cpu(), group=tp.cpu_group)
+                assert all(torch.equal(gathered[0], t) for t in gathered), "every rank holds the same bits"
+        big = torch.zeros(4 << 20, dtype=torch.float32, device="cuda")      # 16 MiB > max_bytes -> library path
+        assert not ca.should_custom_ar(big) and ca.custom_all_reduce(big) is None
+        with ca.capture():
+            assert not ca.should_custom_ar(torch.zeros(64, device="cuda"))
+        torch.distributed.barrier()
+        ca.close()
+        q.put((rank, None))
+    except Exception:
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_direct_all_reduce_through_ipc_regions(world):
+    """csrc/allreduce.hip in the ca_comm seam: one-shot (small) and two-shot (large) sums across ranks
+    that share this GPU (IPC handles within one device).  NOT a test of xGMI transport."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ar_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     for rank, err in results:
