@@ -144,3 +144,57 @@ def test_qkv_shard_math_single_rank():
     assert MergedColumnParallelLinear(64, [96, 96]).weight.shape == (192, 64)
     assert RowParallelLinear(96, 64).weight.shape == (64, 96)
     dist_.destroy_model_parallel()
+
+
+# ---------------------------------------------------------------- host logic added with the §8f rows
+def test_sampling_params_and_batch_info_host_side():
+    import torch
+    from scratchpad_amd.sampler import TOP_K_ALL, SamplingBatchInfo, SamplingParams
+    greedy = SamplingParams(temperature=0.0)
+    assert greedy.top_k == 1 and greedy.temperature == 1.0          # sampling_params.py:66-69
+    assert SamplingParams(top_k=-1).top_k == TOP_K_ALL               # whole vocabulary
+    for bad in (dict(top_p=0.0), dict(top_p=1.5), dict(min_p=-0.1), dict(temperature=-1.0), dict(top_k=0)):
+        with pytest.raises(ValueError):
+            SamplingParams(**bad).verify()
+    a = SamplingBatchInfo.from_params([greedy, SamplingParams(temperature=0.7, top_k=40, min_p=0.05)], 100, "cpu")
+    b = SamplingBatchInfo.from_params([greedy], 100, "cpu")
+    assert not a.is_all_greedy and a.need_min_p_sampling and b.is_all_greedy and not b.need_min_p_sampling
+    assert a.temperatures.shape == (2, 1) and a.top_ks.dtype == torch.int32 and len(a) == 2
+    a.merge_batch(b)
+    assert len(a) == 3 and a.top_ks.tolist() == [1, 40, 1] and not a.is_all_greedy
+    a.filter_batch([0, 2], torch.tensor([0, 2]))
+    assert len(a) == 2 and a.top_ks.tolist() == [1, 1] and a.min_ps.tolist() == [0.0, 0.0]
+
+
+def test_skinny_gemm_dispatch_rule_and_cpu_passthrough():
+    import torch
+    from scratchpad_amd import _native
+    pays = _native.skinny_gemm_pays
+    assert pays(1, 6144, 4096) and pays(1, 28672, 4096) and pays(1, 128256, 4096)       # bs 1: all but down_proj
+    assert pays(16, 4096, 4096) and pays(8, 6144, 4096) and pays(8, 28672, 4096)
+    assert not pays(1, 4096, 14336) and not pays(8, 4096, 14336)                          # long rows: library
+    assert not pays(16, 28672, 4096) and not pays(8, 128256, 4096)
+    x, w = torch.randn(3, 64), torch.randn(5, 64)
+    assert torch.equal(_native.linear(x, w), torch.nn.functional.linear(x, w))           # host tensors: plain F.linear
+
+
+def test_vision_attention_plan_partition(monkeypatch):
+    import torch
+    from scratchpad_amd import vision
+    from scratchpad_amd.mllama_vision import padding_positions
+    monkeypatch.setattr(torch.cuda, "Stream", lambda device=None: object())
+    P, Pp = 1025, 1032
+    pad = padding_positions(torch.tensor([[1, 1, 1, 1], [1, 0, 0, 0]]), P, Pp)
+    assert pad.shape == (2, 4 * Pp) and int(pad[0].sum()) == 4 * 7 and int(pad[1].sum()) == 3 * Pp + 7
+    plan = vision.VisionAttnPlan(2, 4 * Pp, "cpu", pad_rows=pad)
+    assert plan.main.seq_lens == [4 * Pp] * 2 and plan.main_rows is None                  # natural order
+    assert plan.side.seq_lens == [28, 3 * Pp + 7] and plan.side.key_lens == [4 * P, P]
+    assert plan.side.key_index.shape == (2, 4 * P) and plan.side.key_index[1, P - 1] == 4 * Pp + P - 1
+    assert torch.equal(plan.side_rows[:7], torch.arange(P, Pp))
+    rag = vision.VisionAttnPlan(1, 10, "cpu", cu_seqlens=[0, 3, 3, 10])
+    assert rag.main.seq_lens == [3, 0, 7] and rag.side is None and rag.main.start.tolist() == [0, 3, 3]
+    monkeypatch.setattr(vision.VisionAttnPlan, "MOVE_SPILL_ROWS", True)
+    moved = vision.VisionAttnPlan(1, 4 * Pp, "cpu", pad_rows=pad[:1])
+    assert moved.main.seq_lens == [4096] and moved.side.seq_lens == [28, 4] and moved.side.key_lens == [4 * P, 4 * Pp]
+    both = torch.cat([moved.main_rows, moved.side_rows]).sort().values
+    assert torch.equal(both, torch.arange(4 * Pp)), "every position is computed exactly once"
