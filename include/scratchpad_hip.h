@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 2
+#define SP_ABI_VERSION 3
 #define SP_API __attribute__((visibility("default")))
 
 typedef enum { SP_F32 = 0, SP_F16 = 1, SP_BF16 = 2, SP_FP8_E5M2 = 3 /* KV pool only */ } sp_dtype;
@@ -46,6 +46,12 @@ typedef enum {
 
 SP_API int sp_abi_version(void);
 SP_API const char* sp_status_string(int status);
+/* Test / tuning hook (no reference counterpart): process-wide kernel-selection switches for A/B
+ * measurements and parity tests of the non-default kernels.  Keys: "decode_kernel" (0 = default,
+ * 1 = VALU kernel, 2 = matrix-core kernel), "extend_waves" (0 = default, 4 or 8 waves per
+ * workgroup).  Nothing on the call path reads the environment.  Returns SP_ERR_INVALID_ARG for
+ * an unknown key.                                                                                */
+SP_API int sp_debug_set(const char* key, int value);
 
 /* ---- RMSNorm: replaces flashinfer.norm.rmsnorm / fused_add_rmsnorm
  *      (nn/layers/layernorm.py:22-32; semantics of forward_native 34-51).
@@ -127,6 +133,12 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  * in fp16 with fp32 accumulation, as flashinfer does for fp8 KV (convert to the query type); the
  * in-tree Triton kernels' `p.to(v.dtype)` (probabilities rounded to e5m2) is NOT reproduced.
  *
+ * `k_scale`, `v_scale` (> 0; 1.0 = none): the layer's KV scales, the same values the store divided
+ * by (flashinfer_backend.py:470-482 passes layer.k_scale / layer.v_scale to both): the pool holds
+ * k / k_scale and v / v_scale, so logits are multiplied by k_scale and the output by v_scale.
+ * A device-side seq_lens[b] above num_splits * chunk is clamped to it (the bound the plan and
+ * the workspace were sized for), never followed past them.
+ *
  * `plan` (optional, may be NULL): the list of non-empty (request, split) items built by
  * sp_decode_plan() from the same seq_lens / chunk, once per step, shared by all layers - the
  * counterpart of flashinfer's begin_forward()/plan (flashinfer_backend.py:623-670) and of
@@ -142,9 +154,10 @@ SP_API int sp_decode_attention(void* out, const void* q, const void* k_buffer, c
                         const void* req_pool_indices, const void* seq_lens, const void* kv_start,
                         int idx64, int batch_size, int num_q_heads, int num_kv_heads,
                         int head_dim, int64_t q_stride, int64_t out_stride,
-                        int64_t kv_buffer_stride, float sm_scale, float logit_cap,
-                        int64_t max_seq_len, int chunk, void* workspace, size_t workspace_bytes,
-                        const int32_t* plan, int dtype, int kv_dtype, void* stream);
+                        int64_t kv_buffer_stride, float sm_scale, float logit_cap, float k_scale,
+                        float v_scale, int64_t max_seq_len, int chunk, void* workspace,
+                        size_t workspace_bytes, const int32_t* plan, int dtype, int kv_dtype,
+                        void* stream);
 
 /* ---- Ragged extend (prefill) attention: replaces extend_attention_fwd (nn/attention/
  *      triton_attn/extend_attention.py:229-327; call site triton_backend.py:137-154) and the
@@ -170,7 +183,8 @@ SP_API int sp_extend_attention(void* out, const void* q, const void* k_buffer, c
                         const int32_t* extend_start_loc, int batch_size, int64_t num_tokens,
                         int num_q_heads, int num_kv_heads, int head_dim, int64_t q_stride,
                         int64_t out_stride, int64_t kv_buffer_stride, float sm_scale,
-                        float logit_cap, int causal, int window_left, int max_extend_len,
+                        float logit_cap, float k_scale, float v_scale, int causal,
+                        int window_left, int max_extend_len,
                         int64_t max_seq_len, void* workspace, size_t workspace_bytes, int dtype,
                         int kv_dtype, void* stream);
 

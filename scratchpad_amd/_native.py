@@ -36,6 +36,7 @@ _vp, _i64, _i32, _f32, _sz = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, cty
 SIGNATURES = {
     "sp_abi_version": (_i32, []),
     "sp_status_string": (ctypes.c_char_p, [_i32]),
+    "sp_debug_set": (_i32, [ctypes.c_char_p, _i32]),
     "sp_rmsnorm": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp]),
     "sp_fused_add_rmsnorm": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp]),
     "sp_silu_and_mul": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _i32, _vp]),
@@ -50,11 +51,11 @@ SIGNATURES = {
     "sp_decode_plan_bytes": (_sz, [_i32, _i64, _i32]),
     "sp_decode_plan": (_i32, [_vp, _sz, _vp, _i32, _i32, _i64, _i32, _vp]),
     "sp_decode_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32,
-                                   _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32, _i64, _i32,
+                                   _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _i64, _i32,
                                    _vp, _sz, _vp, _i32, _i32, _vp]),
     "sp_extend_attention_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32]),
     "sp_extend_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp,
-                                   _i32, _i64, _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32,
+                                   _i32, _i64, _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32, _f32, _f32,
                                    _i32, _i32, _i32, _i64, _vp, _sz, _i32, _i32, _vp]),
     "sp_kv_store_fp8": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _f32,
                                _i32, _vp]),
@@ -91,7 +92,7 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.sp_abi_version() != 2:
+    if lib.sp_abi_version() != 3:
         raise RuntimeError("libscratchpad_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -101,6 +102,11 @@ def _check(status: int, what: str):
     if status != 0:
         msg = load().sp_status_string(status).decode()
         raise RuntimeError(f"{what} failed: {msg} ({status})")
+
+
+def debug_set(key: str, value: int) -> None:
+    """Test / tuning switch of the library (sp_debug_set): "decode_kernel", "extend_waves"."""
+    _check(load().sp_debug_set(key.encode(), int(value)), f"sp_debug_set({key})")
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -321,8 +327,10 @@ def decode_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
                      req_pool_indices: torch.Tensor, seq_lens: torch.Tensor, sm_scale: float,
                      logit_cap: float, max_seq_len: int, chunk: int, workspace: torch.Tensor,
                      kv_start: Optional[torch.Tensor] = None,
-                     plan: Optional[torch.Tensor] = None) -> None:
-    """q, out: [bs, Hq, D] (row stride free); buffers [P+1, Hkv, D]."""
+                     plan: Optional[torch.Tensor] = None, k_scale: Optional[float] = None,
+                     v_scale: Optional[float] = None) -> None:
+    """q, out: [bs, Hq, D] (row stride free); buffers [P+1, Hkv, D].  k_scale / v_scale: the
+    scales the store divided by (None = 1)."""
     _gpu(out, q, k_buffer, v_buffer, req_to_token, req_pool_indices, seq_lens, workspace, kv_start, plan)
     bs, Hq, D = q.shape
     if q.stride(2) != 1 or q.stride(1) != D or out.stride(2) != 1 or out.stride(1) != D:
@@ -337,6 +345,7 @@ def decode_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
         out.data_ptr(), q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), req_to_token.data_ptr(),
         req_to_token.stride(0), req.data_ptr(), seq.data_ptr(), _ptr(kv_start), idx64, bs, Hq,
         k_buffer.shape[1], D, q.stride(0), out.stride(0), k_buffer.stride(0), sm_scale, logit_cap,
+        1.0 if k_scale is None else float(k_scale), 1.0 if v_scale is None else float(v_scale),
         max_seq_len, chunk, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
         _ptr(plan), _dt(q), kv_dt, _stream()), "sp_decode_attention")
 
@@ -351,7 +360,8 @@ def extend_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
                      extend_seq_lens: torch.Tensor, extend_start_loc: torch.Tensor,
                      sm_scale: float, logit_cap: float, causal: bool, max_extend_len: int,
                      max_seq_len: int, workspace: torch.Tensor,
-                     kv_start: Optional[torch.Tensor] = None, window_left: int = -1) -> None:
+                     kv_start: Optional[torch.Tensor] = None, window_left: int = -1,
+                     k_scale: Optional[float] = None, v_scale: Optional[float] = None) -> None:
     """q, out: [T, Hq, D]; the new tokens' K/V must already be in the pool.  window_left >= 0:
     causal rows see only the window_left keys before their own position (and themselves)."""
     _gpu(out, q, k_buffer, v_buffer, req_to_token, req_pool_indices, seq_lens, extend_seq_lens,
@@ -372,7 +382,8 @@ def extend_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
         req_to_token.stride(0), req.data_ptr(), seq.data_ptr(), _ptr(kv_start), idx64,
         extend_seq_lens.contiguous().data_ptr(), extend_start_loc.contiguous().data_ptr(),
         seq.shape[0], T, Hq, k_buffer.shape[1], D, q.stride(0), out.stride(0), k_buffer.stride(0),
-        sm_scale, logit_cap, int(causal), int(window_left), max_extend_len, max_seq_len, workspace.data_ptr(),
+        sm_scale, logit_cap, 1.0 if k_scale is None else float(k_scale),
+        1.0 if v_scale is None else float(v_scale), int(causal), int(window_left), max_extend_len, max_seq_len, workspace.data_ptr(),
         workspace.numel() * workspace.element_size(), _dt(q), kv_dt, _stream()), "sp_extend_attention")
 
 

@@ -80,6 +80,10 @@ class RadixAttention(nn.Module):
         self.is_cross_attention = is_cross_attention
         self.k_scale = None
         self.v_scale = None
+        # per-layer KV scales as floats: flashinfer_backend.py:400-401, 457-458 read these two names
+        # (set by the checkpoint's kv-scale loader upstream; the reference's class never defines them)
+        self.k_scale_float = None
+        self.v_scale_float = None
         self.use_irope = use_irope
 
     def forward(self, q, k, v, forward_batch: "ForwardBatch", save_kv_cache: bool = True):
@@ -294,6 +298,13 @@ class HipAttnBackend(AttentionBackend):
         _native.rotary_embedding(positions, q, k, rope.head_size, rope.cos_sin_cache, rope.is_neox_style,
                                  value=v, k_buffer=kb, v_buffer=vb, out_cache_loc=forward_batch.out_cache_loc)
 
+    def _kv_scales(self, layer: RadixAttention):
+        """flashinfer_backend.py:400-401, 457-458: the layer's float scales, only for a non-"auto"
+        (fp8) KV cache; they go to the store (which divides) and to the kernels (which multiply)."""
+        if self.kv_dtype != torch.float8_e5m2:
+            return None, None
+        return layer.k_scale_float, layer.v_scale_float
+
     @staticmethod
     def _alloc_out(q: torch.Tensor, layer: RadixAttention) -> torch.Tensor:
         # The kernels leave a row with no visible key untouched (sp_decode_attention: seq_len 0).
@@ -307,7 +318,9 @@ class HipAttnBackend(AttentionBackend):
         assert v is not None
         cache_loc = (forward_batch.encoder_out_cache_loc if layer.is_cross_attention
                      else forward_batch.out_cache_loc)
-        forward_batch.token_to_kv_pool.set_kv_buffer(layer, cache_loc, k, v)
+        # flashinfer_backend.py:470-473: the layer's scales go to the store AND to the kernels
+        k_scale, v_scale = self._kv_scales(layer)
+        forward_batch.token_to_kv_pool.set_kv_buffer(layer, cache_loc, k, v, k_scale, v_scale)
 
     def forward_extend(self, q, k, v, layer: RadixAttention, forward_batch: "ForwardBatch",
                        save_kv_cache: bool = True):
@@ -319,6 +332,7 @@ class HipAttnBackend(AttentionBackend):
         # (triton_backend.py:131-134)
         self._store(layer, forward_batch, k, v, save_kv_cache)
         max_extend, max_len, ws = self.forward_metadata
+        k_scale, v_scale = self._kv_scales(layer)
         seq_lens, kv_start = self._kv_window(layer, forward_batch)
         kb, vb = forward_batch.token_to_kv_pool.get_kv_buffer(layer.layer_id)
         _native.extend_attention(
@@ -327,7 +341,8 @@ class HipAttnBackend(AttentionBackend):
             forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices, seq_lens,
             forward_batch.extend_seq_lens, forward_batch.extend_start_loc, layer.scaling,
             layer.logit_cap, not layer.is_cross_attention, max_extend, max_len, ws, kv_start,
-            window_left=layer.sliding_window_size if self._is_windowed(layer) else -1)
+            window_left=layer.sliding_window_size if self._is_windowed(layer) else -1,
+            k_scale=k_scale, v_scale=v_scale)
         return o
 
     def forward_decode(self, q, k, v, layer: RadixAttention, forward_batch: "ForwardBatch",
@@ -338,6 +353,7 @@ class HipAttnBackend(AttentionBackend):
         o = self._alloc_out(q, layer)
         self._store(layer, forward_batch, k, v, save_kv_cache)
         chunk, max_len, ws, plans = self.forward_metadata
+        k_scale, v_scale = self._kv_scales(layer)
         seq_lens, kv_start = self._kv_window(layer, forward_batch)
         plan = plans[2] if self._is_windowed(layer) else (plans[1] if layer.is_cross_attention else plans[0])
         kb, vb = forward_batch.token_to_kv_pool.get_kv_buffer(layer.layer_id)
@@ -345,5 +361,6 @@ class HipAttnBackend(AttentionBackend):
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), kb, vb,
             forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices, seq_lens,
-            layer.scaling, layer.logit_cap, max_len, chunk, ws, kv_start, plan)
+            layer.scaling, layer.logit_cap, max_len, chunk, ws, kv_start, plan,
+            k_scale=k_scale, v_scale=v_scale)
         return o

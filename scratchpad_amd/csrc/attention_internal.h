@@ -18,6 +18,8 @@ struct DecodeArgs {
   int bs, Hq, Hkv;
   int64_t q_stride, o_stride, kv_stride;  // elements
   float sm_scale, logit_cap;
+  float out_scale;  // multiplies the normalised output (the pool's v_scale; 1 = none)
+  int max_len;      // num_splits * chunk: device-side seq_lens are clamped to it
   int chunk, num_splits, hh_shift, head_groups;
   float* part_o;    // [bs, Hq, num_splits, D]
   float* part_lse;  // [bs, Hq, num_splits]  (log2 domain)
@@ -41,6 +43,10 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
                     int idx64, const int32_t* extend_seq_lens, const int32_t* extend_start_loc,
                     int batch_size, int num_q_heads, int num_kv_heads, int head_dim, int64_t q_stride,
                     int64_t out_stride, int64_t kv_buffer_stride, float sm_scale, float logit_cap,
-                    int causal, int window_left, int max_extend_len, int dtype, int kv8, hipStream_t st);
+                    float out_scale, int causal, int window_left, int max_extend_len, int dtype, int kv8, hipStream_t st);
+
+// test / tuning hooks behind sp_debug_set
+void set_decode_kernel(int which);
+void set_extend_waves(int nw);
 
 }  // namespace sp

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeArgs a) {
     b = item / a.num_splits;
   }
 
-  const int seq = (int)load_idx(a.seq_lens, b, a.idx64);
+  const int seq = min((int)load_idx(a.seq_lens, b, a.idx64), a.max_len);
   const int cs = c * a.chunk;
   if (cs >= seq) return;  // (also covers seq == 0) uniform for the whole workgroup
   const int ce = min(cs + a.chunk, seq);
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeArgs a) {
     const int h = (hg * HH + hl) * G + g;
     const float o = O / L;
     if (nsplit == 1) {
-      E::store(a.out, (int64_t)b * a.o_stride + (int64_t)h * D + d, o);
+      E::store(a.out, (int64_t)b * a.o_stride + (int64_t)h * D + d, o * a.out_scale);
     } else {
       const int64_t pi = ((int64_t)b * a.Hq + h) * a.num_splits + c;
       a.part_o[pi * D + d] = o;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
   if (pair >= a.bs * a.Hq) return;
   const int lane = threadIdx.x & 63;
   const int b = pair / a.Hq, h = pair - b * a.Hq;
-  const int seq = (int)load_idx(a.seq_lens, b, a.idx64);
+  const int seq = min((int)load_idx(a.seq_lens, b, a.idx64), a.max_len);
   const int nsplit = (seq + a.chunk - 1) / a.chunk;
   if (nsplit <= 1) return;  // written directly by the attention kernel (or empty row)
   const float* lse = a.part_lse + (int64_t)pair * a.num_splits;
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
   }
 #pragma unroll
   for (int e = 0; e < PER; ++e)
-    E::store(a.out, (int64_t)b * a.o_stride + (int64_t)h * D + e * 64 + lane, o[e] / W);
+    E::store(a.out, (int64_t)b * a.o_stride + (int64_t)h * D + e * 64 + lane, o[e] / W * a.out_scale);
 }
 
 // Build the list of non-empty (request, split) items: plan[0] = count, plan[2+2i], plan[3+2i] =
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
 // quarter first), so the launch ends on its shortest items.
 __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ plan,
                                                            const void* __restrict__ seq_lens,
-                                                           int idx64, int bs, int chunk) {
+                                                           int idx64, int bs, int chunk, int max_len) {
   __shared__ int s_scan[256];
   __shared__ int s_base;
   if (threadIdx.x == 0) s_base = 0;
@@ -362,7 +362,8 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ 
       const int b = t0 + threadIdx.x;
       int nfull = 0, tail = 0;
       if (b < bs) {
-        const int seq = (int)load_idx(seq_lens, b, idx64);
+        // a length beyond the host-supplied bound would index past the plan and the partials
+        const int seq = min((int)load_idx(seq_lens, b, idx64), max_len);
         nfull = seq > 0 ? seq / chunk : 0;
         const int rem = seq > 0 ? seq % chunk : 0;
         // tail class 3 = longest quarter of the chunk ... 0 = shortest; pass 1 takes class 3
@@ -476,12 +477,13 @@ int run_decode_merge(const DecodeArgs& a, int head_dim, int dtype, hipStream_t s
 // Kernel choice.  16-bit dtypes go to the matrix-core kernel (decode_mfma.hip; measured equal or
 // faster than the VALU kernel on every shape tried, 2.3x at G = 8 where the VALU kernel needs 256
 // VGPRs); fp32 and groups wider than 16 stay on the VALU kernel below.
-// SP_DECODE_KERNEL=valu|mfma overrides the choice (A/B measurements and tests only).
+// sp_debug_set("decode_kernel", 1 = valu | 2 = mfma | 0 = default) overrides the choice (A/B
+// measurements and tests only; a process-wide variable, never the environment on the call path).
+static int g_decode_kernel_forced = 0;
+void set_decode_kernel(int which) { g_decode_kernel_forced = which; }
 static int decode_kernel_choice(int group, int dtype) {
-  const char* e = getenv("SP_DECODE_KERNEL");  // read per call: tests flip it within one process
-  const int forced = !e ? 0 : (e[0] == 'm' ? 2 : (e[0] == 'v' ? 1 : 0));
   if (dtype == SP_F32 || group > 16) return 1;
-  if (forced) return forced;
+  if (g_decode_kernel_forced == 1 || g_decode_kernel_forced == 2) return g_decode_kernel_forced;
   return 2;
 }
 
@@ -541,8 +543,10 @@ extern "C" int sp_decode_plan(int32_t* plan, size_t plan_bytes, const void* seq_
                               int batch_size, int64_t max_seq_len, int chunk, void* stream) {
   SP_CHECK_ARG(plan && seq_lens && batch_size >= 0 && chunk >= 4 && chunk % 4 == 0);
   if (plan_bytes < sp_decode_plan_bytes(batch_size, max_seq_len, chunk)) return SP_ERR_WORKSPACE;
+  const int64_t max_len = num_splits_for(max_seq_len, chunk) * chunk;
+  if (max_len > 0x7fffffffLL) return SP_ERR_INVALID_ARG;
   decode_plan_kernel<<<dim3(1), 256, 0, (hipStream_t)stream>>>(plan, seq_lens, idx64, batch_size,
-                                                               chunk);
+                                                               chunk, (int)max_len);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
@@ -553,12 +557,14 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
                                    const void* seq_lens, const void* kv_start, int idx64,
                                    int batch_size, int num_q_heads, int num_kv_heads, int head_dim,
                                    int64_t q_stride, int64_t out_stride, int64_t kv_buffer_stride,
-                                   float sm_scale, float logit_cap, int64_t max_seq_len, int chunk,
-                                   void* workspace, size_t workspace_bytes, const int32_t* plan,
-                                   int dtype, int kv_dtype, void* stream) {
+                                   float sm_scale, float logit_cap, float k_scale, float v_scale,
+                                   int64_t max_seq_len, int chunk, void* workspace,
+                                   size_t workspace_bytes, const int32_t* plan, int dtype,
+                                   int kv_dtype, void* stream) {
   SP_CHECK_ARG(out && q && k_buffer && v_buffer && req_to_token && req_pool_indices && seq_lens);
   SP_CHECK_ARG(batch_size >= 0 && num_q_heads > 0 && num_kv_heads > 0 && head_dim > 0);
   SP_CHECK_ARG(num_q_heads % num_kv_heads == 0 && max_seq_len >= 0);
+  SP_CHECK_ARG(k_scale > 0.f && v_scale > 0.f);
   // each wave takes chunk/4 tokens in pieces of 64: keep the split a multiple of 4
   SP_CHECK_ARG(chunk >= 4 && chunk % 4 == 0);
   SP_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)k_buffer & 15) == 0 &&
@@ -584,7 +590,12 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
   a.r2t = req_to_token; a.r2t_stride = req_to_token_stride; a.req_idx = req_pool_indices;
   a.seq_lens = seq_lens; a.kv_start = kv_start; a.idx64 = idx64; a.bs = batch_size;
   a.Hq = num_q_heads; a.Hkv = num_kv_heads; a.q_stride = q_stride; a.o_stride = out_stride;
-  a.kv_stride = kv_buffer_stride; a.sm_scale = sm_scale; a.logit_cap = logit_cap;
+  // the pool holds k / k_scale and v / v_scale (set_kv_buffer, memory/pool.py:401-412): q.k scales
+  // with k_scale, which joins the softmax scale; the output scales with v_scale
+  a.kv_stride = kv_buffer_stride; a.sm_scale = sm_scale * k_scale; a.logit_cap = logit_cap;
+  a.out_scale = v_scale;
+  if (S * chunk > 0x7fffffffLL) return SP_ERR_INVALID_ARG;
+  a.max_len = (int)(S * chunk);
   a.chunk = chunk; a.num_splits = (int)S; a.plan = plan; a.kv8 = kv8 ? 1 : 0;
   a.hh_shift = decode_heads_per_load_shift(num_kv_heads, head_dim, dtype, &a.head_groups);
   a.part_o = nullptr; a.part_lse = nullptr;

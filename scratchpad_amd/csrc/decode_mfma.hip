@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
     c = item % a.num_splits;
     b = item / a.num_splits;
   }
-  const int seq = (int)load_idx(a.seq_lens, b, a.idx64);
+  const int seq = min((int)load_idx(a.seq_lens, b, a.idx64), a.max_len);
   const int cs = c * a.chunk;
   if (cs >= seq) return;
   const int ce = min(cs + a.chunk, seq);
@@ -297,8 +297,9 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
     //      (lane (col, kq) holds d = 16db + 4kq .. +3 of head col)
     if (col < G) {
       const int h = hk * G + col;
-      const float inv = 1.0f / l_run;
+      float inv = 1.0f / l_run;
       if (nsplit == 1) {
+        inv *= a.out_scale;
         char* op = (char*)a.out + ((int64_t)b * a.o_stride + (int64_t)h * D + 4 * kq) * 2;
 #pragma unroll
         for (int db = 0; db < DBLK; ++db) {
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
     const int h = hk * G + g;
     const float o = O / L;
     if (nsplit == 1) {
-      E::store(a.out, (int64_t)b * a.o_stride + (int64_t)h * D + d, o);
+      E::store(a.out, (int64_t)b * a.o_stride + (int64_t)h * D + d, o * a.out_scale);
     } else {
       const int64_t pi = ((int64_t)b * a.Hq + h) * a.num_splits + c;
       a.part_o[pi * D + d] = o;

@@ -10,6 +10,8 @@
 // and the decode kernel (decode_attention.hip: coalesced full-row gathers, G query heads per
 // KV read) does the rest.  KV traffic is O(sum L^2) instead of O(sum L^2 / BLOCK_M); the MFMA
 // tile kernel for long 16-bit prompts replaces it where that matters.
+#include <cstring>
+
 #include "attention_internal.h"
 
 namespace sp {
@@ -42,6 +44,13 @@ __global__ __launch_bounds__(256) void expand_rows_kernel(
 
 using namespace sp;
 
+extern "C" int sp_debug_set(const char* key, int value) {
+  SP_CHECK_ARG(key);
+  if (!strcmp(key, "decode_kernel")) { set_decode_kernel(value); return SP_OK; }
+  if (!strcmp(key, "extend_waves")) { set_extend_waves(value); return SP_OK; }
+  return SP_ERR_INVALID_ARG;
+}
+
 extern "C" size_t sp_extend_attention_workspace_bytes(int64_t num_tokens, int batch_size,
                                                       int num_q_heads, int head_dim, int dtype) {
   (void)batch_size; (void)num_q_heads; (void)head_dim; (void)dtype;
@@ -58,13 +67,15 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
                                    int64_t num_tokens, int num_q_heads, int num_kv_heads,
                                    int head_dim, int64_t q_stride, int64_t out_stride,
                                    int64_t kv_buffer_stride, float sm_scale, float logit_cap,
-                                   int causal, int window_left, int max_extend_len,
+                                   float k_scale, float v_scale, int causal, int window_left,
+                                   int max_extend_len,
                                    int64_t max_seq_len, void* workspace, size_t workspace_bytes,
                                    int dtype, int kv_dtype, void* stream) {
   SP_CHECK_ARG(out && q && k_buffer && v_buffer && req_to_token && req_pool_indices && seq_lens);
   SP_CHECK_ARG(extend_seq_lens && extend_start_loc && batch_size >= 0 && num_tokens >= 0);
   SP_CHECK_ARG(num_q_heads > 0 && num_kv_heads > 0 && num_q_heads % num_kv_heads == 0);
-  SP_CHECK_ARG(max_extend_len >= 0 && max_seq_len >= 0);
+  SP_CHECK_ARG(max_extend_len >= 0 && max_seq_len >= 0 && k_scale > 0.f && v_scale > 0.f);
+  sm_scale *= k_scale;   // scaled pools (set_kv_buffer, memory/pool.py:401-412): see sp_decode_attention
   SP_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)k_buffer & 15) == 0 &&
                ((uintptr_t)v_buffer & 15) == 0);
   if (dtype != SP_F32 && dtype != SP_F16 && dtype != SP_BF16) return SP_ERR_UNSUPPORTED;
@@ -90,8 +101,8 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
     const int rc = run_extend_mfma(out, q, k_buffer, v_buffer, req_to_token, req_to_token_stride,
                                    req_pool_indices, seq_lens, kv_start, idx64, extend_seq_lens,
                                    extend_start_loc, batch_size, num_q_heads, num_kv_heads, head_dim,
-                                   q_stride, out_stride, kv_buffer_stride, sm_scale, logit_cap, causal,
-                                   window_left, max_extend_len, dtype, kv8 ? 1 : 0, st);
+                                   q_stride, out_stride, kv_buffer_stride, sm_scale, logit_cap, v_scale,
+                                   causal, window_left, max_extend_len, dtype, kv8 ? 1 : 0, st);
     if (rc != SP_ERR_UNSUPPORTED || kv8) return rc;   // an fp8 pool has no row-stream path
   }
 
@@ -109,11 +120,11 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
   a.req_idx = row_req; a.seq_lens = row_len; a.kv_start = row_kv0; a.idx64 = 0;
   a.bs = (int)num_tokens; a.Hq = num_q_heads; a.Hkv = num_kv_heads;
   a.q_stride = q_stride; a.o_stride = out_stride; a.kv_stride = kv_buffer_stride;
-  a.sm_scale = sm_scale; a.logit_cap = logit_cap;
+  a.sm_scale = sm_scale; a.logit_cap = logit_cap; a.out_scale = v_scale;
   // one split per row: every row-stream is reduced inside one workgroup, no partials
   int64_t chunk = ((max_seq_len > 0 ? max_seq_len : 1) + 3) / 4 * 4;
   if (chunk > 0x7ffffff0LL) return SP_ERR_INVALID_ARG;
-  a.chunk = (int)chunk; a.num_splits = 1;
+  a.chunk = (int)chunk; a.num_splits = 1; a.max_len = (int)chunk;
   a.hh_shift = decode_heads_per_load_shift(num_kv_heads, head_dim, dtype, &a.head_groups);
   a.part_o = nullptr; a.part_lse = nullptr; a.plan = nullptr; a.kv8 = 0;
   return run_decode(a, head_dim, G, dtype, st);

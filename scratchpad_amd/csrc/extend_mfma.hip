@@ -6,20 +6,27 @@
 // gathered from the paged pool through req_to_token.
 //
 // Tiling (cdna_hip_programming.md section 3 and Appendix B 'Fused attention prefill'):
-//   * workgroup = 4 waves = (request, kv head, block of BM new tokens); a wave owns 32 query rows of
-//     ONE query head; the 4 waves cover Gk = min(G,4) heads x 4/Gk row blocks, so a K/V tile staged
-//     once in LDS is shared by the whole GQA group;
+//   * workgroup = NW waves = (request, kv head, block of BM new tokens); a wave owns 32 query rows of
+//     ONE query head; the waves cover Gk query heads x NW/Gk row blocks, so a K/V tile staged once in
+//     LDS is shared by the whole GQA group (8 waves: 256 (row, head) pairs per staged tile);
 //   * S^T = K . Q^T with v_mfma_f32_32x32x16 (A = K rows from LDS by ds_read_b128, B = Q fragments held
 //     in registers for the whole kernel): the accumulator then has the query row on the LANE and
-//     the 16 keys of the lane half in registers, so the softmax row max / sum are in-lane plus one
-//     exchange with lane^32, and the rescale factor of O^T is lane-local;
+//     the 16 keys of the lane half in registers, so the softmax row max is in-lane plus one exchange
+//     with lane^32, the row sum stays a per-lane partial until the epilogue, and the rescale factor
+//     of O^T is lane-local;
 //   * O^T = V^T . P^T: P^T is taken straight from the S^T accumulator registers as the B operand
 //     ("an accumulator tile as the next MFMA's operand": registers 8s..8s+7 -> k-step s, key order
 //     16s + 8(j>>2) + 4h + (j&3)); the matching V^T fragments come from the row-major V tile by
 //     ds_read_b64_tr_b16 (hardware transpose), two reads per k-step;
 //   * K/V tiles of 64 keys: gathered rows (full 256-B lines, 16 B per lane) -> registers ->
 //     LDS with padded row strides (K +16 B: conflict-free ds_read_b128; V +64 B: conflict-free
-//     tr reads); the next tile's global loads are issued before the current tile is consumed.
+//     tr reads); the next tile's global loads are issued before the current tile is consumed;
+//   * online softmax in the exp2 domain with the scale folded into the exponent's fma; the running
+//     maximum is only advanced when some row's maximum grew by more than kDeferLog2 (the O^T rescale
+//     is then a rare, wave-uniform branch; P stays <= 2^kDeferLog2);
+//   * grid: x = kv head (fastest: the hardware deals consecutive workgroups round-robin to the 8
+//     XCDs, so with 8 kv heads every row block of one (request, kv head) runs on ONE XCD and its
+//     K/V re-reads hit that XCD's L2), y = row blocks, heaviest (last rows of the prompt) first.
 #include <type_traits>
 
 #include "attention_internal.h"
@@ -46,7 +53,7 @@ struct ExtendArgs {
   const int32_t* ext_start;
   int bs, Hq, Hkv;
   int64_t q_stride, o_stride, kv_stride;  // elements
-  float sm_scale, logit_cap;
+  float sm_scale, logit_cap, out_scale;   // out_scale = the pool's v_scale (1 for unscaled pools)
   int causal;
   int kv8;      // 1: fp8 e5m2 pool (kv_stride in bytes); tile math in fp16, see decode_mfma.hip
   int window;   // sliding window: a row at kv position p sees keys [p - window, p]; < 0 = unlimited
@@ -54,6 +61,8 @@ struct ExtendArgs {
 
 static constexpr float kLog2eX = 1.4426950408889634f;
 static constexpr float kNegBigX = -1.0e30f;
+// the running row maximum trails the true one by at most this much (log2 units): P <= 2^6
+static constexpr float kDeferLog2 = 6.0f;
 
 template <typename Tag>
 __device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, const f32x16& c);
@@ -94,40 +103,43 @@ __device__ __forceinline__ float xchg32(float x) {
   return as_f32((threadIdx.x & 32) ? upper_gets : lower_gets);
 }
 
-template <int D>
+template <int D, int NT>
 struct ExtCfg {
   static constexpr int BN = 64;                    // keys per tile
   static constexpr int ROW_B = D * 2;              // bytes per K/V row
   static constexpr int SK = ROW_B + 16;            // K row stride in LDS
   static constexpr int SV = ROW_B + 64;            // V row stride in LDS
   static constexpr int CPR = ROW_B / 16;           // 16-byte chunks per row
-  static constexpr int RPP = 256 / CPR;            // rows staged per pass of the 256 threads
+  static constexpr int RPP = NT / CPR;             // rows staged per pass of the NT threads
   static constexpr int PASSES = BN / RPP;
   static constexpr int KSTEPS = D / 16;            // MFMA k-steps of Q.K^T
   static constexpr int DBLK = D / 32;              // 32-wide d blocks of O^T
   static constexpr int kTileBytes = BN * (SK + SV);   // one K tile + one V tile
   static constexpr int kLdsBytes = 2 * kTileBytes;    // double-buffered: one barrier per tile
+  static_assert(RPP <= BN && BN % RPP == 0, "staging geometry");
 };
 
-template <typename Tag, int D, int GK, bool KV8>
-__global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
-  typedef ExtCfg<D> C;
+// PLAIN: no logit cap and no sliding window (both compiled out of the tile loop)
+template <typename Tag, int D, int GK, int NW, bool KV8, bool PLAIN>
+__global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
+  constexpr int NT = NW * 64;
+  typedef ExtCfg<D, NT> C;
   typedef typename std::conditional<KV8, f16_tag, Tag>::type CT;      // dtype of the tile math
   typedef typename std::conditional<KV8, u32x2, u32x4>::type raw_t;   // one thread's gathered chunk
   constexpr int BN = C::BN, SK = C::SK, SV = C::SV, CPR = C::CPR, RPP = C::RPP, PASSES = C::PASSES;
   constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK;
-  constexpr int BM = 128 / GK;
+  constexpr int BM = 32 * (NW / GK);
   extern __shared__ __attribute__((aligned(16))) char lds[];
   // two (K,V) tile buffers: tile t lives in buffer t & 1
 
   const int b = blockIdx.z;
   const int E = a.ext_lens[b];
-  const int row0 = blockIdx.x * BM;
+  const int row0 = ((int)gridDim.y - 1 - (int)blockIdx.y) * BM;    // heaviest row blocks first
   if (row0 >= E) return;
   const int G = a.Hq / a.Hkv;
-  const int halves = G / GK;                       // query-head blocks per kv head (2 when G = 8)
-  const int hk = blockIdx.y / halves;
-  const int hh = blockIdx.y - hk * halves;
+  const int halves = G / GK;                       // query-head blocks per kv head
+  const int hk = blockIdx.x / halves;
+  const int hh = blockIdx.x - hk * halves;
   const int L = (int)load_idx(a.seq_lens, b, a.idx64);
   const int P = a.causal ? L - E : 0;              // cached prefix length
   const int64_t req = load_idx(a.req_idx, b, a.idx64);
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   const int kv_len = a.causal ? min(L, P + min(row0 + BM, E)) : L;
   const int ntiles = (kv_len + BN - 1) / BN;
   // sliding window (causal only): the first row of the block reaches furthest back
-  const bool windowed = a.causal && a.window >= 0;
+  const bool windowed = !PLAIN && a.causal && a.window >= 0;
   const int tbeg = windowed ? max(0, P + row0 - a.window) / BN : 0;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -160,8 +172,10 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
       if constexpr (KV8 && std::is_same<Tag, bf16_tag>::value) qf[ks] = bf16x8_to_f16x8(qf[ks]);
     }
   }
-  const float cap = a.logit_cap;
-  const float qk_scale = cap > 0.f ? a.sm_scale : a.sm_scale * kLog2eX;
+  const float cap = PLAIN ? 0.f : a.logit_cap;
+  // scores enter the exponent as exp2(s * sc - m): sc carries the softmax scale (the capped form
+  // rewrites s into the log2 domain first, so its sc is 1)
+  const float sc = cap > 0.f ? 1.0f : a.sm_scale * kLog2eX;
   const int row_limit = a.causal ? P + my_row : 0x7fffffff;   // last visible key index
   const int row_first = windowed ? P + my_row - a.window : 0;  // first visible key index (may be < 0)
 
@@ -170,7 +184,8 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   for (int db = 0; db < DBLK; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
-  float m_run = kNegBigX, l_run = 0.f;
+  float m_run = kNegBigX;   // running row maximum (log2 domain), identical in both lane halves
+  float l_part = 0.f;       // this lane's part of the row sum (its 32 keys of every tile)
 
   // ---- staging: thread -> (row, 16-byte chunk) of the tile, PASSES rows each for K and V
   const int st_row = tid / CPR, st_ch = tid % CPR;
@@ -251,8 +266,16 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) s[kb] = mfma32<CT>(kf[ks], qf[ks], s[kb]);
       }
-      // ---- scale, mask, online softmax (query row on the lane; keys in registers + lane^32)
-      float mx = kNegBigX;
+      // ---- mask (edge tiles only), online softmax (query row on the lane; keys in registers + lane^32)
+      if constexpr (!PLAIN) {
+        if (cap > 0.f) {   // wave-uniform: rewrite the scores as cap * tanh(s * scale / cap) in log2 units
+          const float pre = a.sm_scale / cap, post = cap * kLog2eX;
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = post * tanhf(s[kb][r] * pre);
+        }
+      }
       // interior tiles (entirely below every row's diagonal and inside the key range) need no mask
       const bool need_mask = key0 + BN > kv_len || (a.causal && key0 + BN - 1 > P + r0) ||
                              (windowed && key0 < P + min(r0 + 31, E - 1) - a.window);
@@ -262,52 +285,42 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            float x = s[kb][r] * qk_scale;
-            if (cap > 0.f) x = cap * tanhf(x / cap) * kLog2eX;
-            x = (key < kv_len && key <= row_limit && key >= row_first) ? x : -INFINITY;
-            s[kb][r] = x;
-            mx = fmaxf(mx, x);
-          }
-      } else {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float x = s[kb][r] * qk_scale;
-            if (cap > 0.f) x = cap * tanhf(x / cap) * kLog2eX;
-            s[kb][r] = x;
-            mx = fmaxf(mx, x);
+            const bool vis = key < kv_len && key <= row_limit && (PLAIN || key >= row_first);
+            s[kb][r] = vis ? s[kb][r] : -INFINITY;
           }
       }
+      float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
       mx = fmaxf(mx, xchg32(mx));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      float psum = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
-          s[kb][r] = p;
-          psum += p;
-        }
-      psum += xchg32(psum);
-      l_run = l_run * alpha + psum;
-      if (!__all(alpha == 1.0f)) {  // the row maxima settle after the first tiles: usually skipped
+      const float m_cand = mx * sc;               // sc > 0: the maximum commutes with the scale
+      if (__any(m_cand > m_run + kDeferLog2)) {   // rare once the row maxima have settled
+        const float m_new = fmaxf(m_run, m_cand);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        l_part *= alpha;
 #pragma unroll
         for (int db = 0; db < DBLK; ++db)
 #pragma unroll
           for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
       }
+      float psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], sc, -m_run));
+          s[kb][r] = p;
+          psum += p;
+        }
+      l_part += psum;
       // ---- O^T += V^T . P^T
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        // V^T fragments of the whole 32-key block first (2 k-steps x DBLK d-blocks, two transposed
-        // reads each), then the MFMAs
-        u32x4 vf[2][DBLK];
 #pragma unroll
         for (int sidx = 0; sidx < 2; ++sidx) {
+          // V^T fragments of one 16-key k-step (DBLK d-blocks, two transposed reads each)
+          u32x4 vf[DBLK];
           const int keyA = kb * 32 + 16 * sidx + 4 * h + tr_rowq;       // rows for elements 0..3
           const char* vp = ldsV + keyA * SV + tr_col;
 #pragma unroll
@@ -317,21 +330,17 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
             const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (__attribute__((address_space(3))) s16x4_t*)(vp + 8 * SV + db * 64));
             const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
-            vf[sidx][db][0] = lo2[0];
-            vf[sidx][db][1] = lo2[1];
-            vf[sidx][db][2] = hi2[0];
-            vf[sidx][db][3] = hi2[1];
+            vf[db][0] = lo2[0];
+            vf[db][1] = lo2[1];
+            vf[db][2] = hi2[0];
+            vf[db][3] = hi2[1];
           }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int sidx = 0; sidx < 2; ++sidx) {
           u32x4 pf;  // B operand: registers 8s..8s+7 of the S^T block, rounded to the KV dtype
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             pf[j] = pack2<CT>(s[kb][8 * sidx + 2 * j], s[kb][8 * sidx + 2 * j + 1]);
 #pragma unroll
-          for (int db = 0; db < DBLK; ++db) oacc[db] = mfma32<CT>(vf[sidx][db], pf, oacc[db]);
+          for (int db = 0; db < DBLK; ++db) oacc[db] = mfma32<CT>(vf[db], pf, oacc[db]);
         }
       }
     }
@@ -340,8 +349,9 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   }
 
   // ---- epilogue: O[row][head][d] = O^T[d][row] / l ; lane holds 4 consecutive d per register quad
+  const float l_run = l_part + xchg32(l_part);
   if (my_row < E && wave_live) {
-    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;  // no visible key (empty encoder): zeros
+    const float inv = l_run > 0.f ? a.out_scale / l_run : 0.f;  // no visible key (empty encoder): zeros
     char* op = (char*)a.out + ((t0 + my_row) * a.o_stride + (int64_t)head * D) * 2;
 #pragma unroll
     for (int db = 0; db < DBLK; ++db)
@@ -356,25 +366,45 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(ExtendArgs a) {
   }
 }
 
-template <typename Tag, int D, int GK>
+// test / tuning hook (set through sp_debug_set, never read from the environment on the hot path):
+// waves per workgroup of the extend kernel, 0 = the shipped choice
+static int g_extend_waves = 0;
+void set_extend_waves(int nw) { g_extend_waves = nw; }
+
+template <typename Tag, int D, int GK, int NW>
 static int launch_extend(const ExtendArgs& a, int max_extend_len, int halves, hipStream_t st) {
-  typedef ExtCfg<D> C;
-  constexpr int BM = 128 / GK;
-  const dim3 grid((max_extend_len + BM - 1) / BM, a.Hkv * halves, a.bs);
-  if (a.kv8) extend_mfma_kernel<Tag, D, GK, true><<<grid, 256, C::kLdsBytes, st>>>(a);
-  else extend_mfma_kernel<Tag, D, GK, false><<<grid, 256, C::kLdsBytes, st>>>(a);
+  typedef ExtCfg<D, NW * 64> C;
+  constexpr int BM = 32 * (NW / GK);
+  const dim3 grid(a.Hkv * halves, (max_extend_len + BM - 1) / BM, a.bs);
+  const bool plain = !(a.logit_cap > 0.f) && a.window < 0;
+#define SP_EXT_LAUNCH(KV8_, PLAIN_) \
+  extend_mfma_kernel<Tag, D, GK, NW, KV8_, PLAIN_><<<grid, NW * 64, C::kLdsBytes, st>>>(a)
+  if (a.kv8) {
+    if (plain) SP_EXT_LAUNCH(true, true); else SP_EXT_LAUNCH(true, false);
+  } else {
+    if (plain) SP_EXT_LAUNCH(false, true); else SP_EXT_LAUNCH(false, false);
+  }
+#undef SP_EXT_LAUNCH
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
 
 template <typename Tag, int D>
 static int dispatch_extend_group(const ExtendArgs& a, int G, int max_extend_len, hipStream_t st) {
-  // a workgroup's 4 waves take Gk = 4, 2 or 1 query heads of the KV head (the largest that divides G)
+  // a workgroup's waves take Gk = 4, 2 or 1 query heads of the KV head (the largest that divides G)
   // and the remaining G / Gk head blocks become extra workgroups: any group width works
   if (G < 1 || G > 64) return SP_ERR_UNSUPPORTED;
-  if (G % 4 == 0) return launch_extend<Tag, D, 4>(a, max_extend_len, G / 4, st);
-  if (G % 2 == 0) return launch_extend<Tag, D, 2>(a, max_extend_len, G / 2, st);
-  return launch_extend<Tag, D, 1>(a, max_extend_len, G, st);
+  const bool w4 = g_extend_waves == 4;
+  if (G % 4 == 0) {
+    return w4 ? launch_extend<Tag, D, 4, 4>(a, max_extend_len, G / 4, st)
+              : launch_extend<Tag, D, 4, 8>(a, max_extend_len, G / 4, st);
+  }
+  if (G % 2 == 0) {
+    return w4 ? launch_extend<Tag, D, 2, 4>(a, max_extend_len, G / 2, st)
+              : launch_extend<Tag, D, 2, 8>(a, max_extend_len, G / 2, st);
+  }
+  return w4 ? launch_extend<Tag, D, 1, 4>(a, max_extend_len, G, st)
+            : launch_extend<Tag, D, 1, 8>(a, max_extend_len, G, st);
 }
 
 // 16-bit dtypes, D in {64,128}; anything else returns SP_ERR_UNSUPPORTED and the caller takes the
@@ -385,10 +415,12 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
                     int idx64, const int32_t* extend_seq_lens, const int32_t* extend_start_loc,
                     int batch_size, int num_q_heads, int num_kv_heads, int head_dim, int64_t q_stride,
                     int64_t out_stride, int64_t kv_buffer_stride, float sm_scale, float logit_cap,
-                    int causal, int window_left, int max_extend_len, int dtype, int kv8, hipStream_t st) {
+                    float out_scale, int causal, int window_left, int max_extend_len, int dtype, int kv8,
+                    hipStream_t st) {
   if (dtype != SP_F16 && dtype != SP_BF16) return SP_ERR_UNSUPPORTED;
   if (head_dim != 64 && head_dim != 128) return SP_ERR_UNSUPPORTED;
   if (batch_size > 65535 || num_q_heads > 65535) return SP_ERR_UNSUPPORTED;   // grid.z, grid.y
+  if (max_extend_len > 65535 * 32) return SP_ERR_UNSUPPORTED;
   if (q_stride % 8 || out_stride % 4 || kv_buffer_stride % 8) return SP_ERR_UNSUPPORTED;
   if (kv8 && (((uintptr_t)k_buffer | (uintptr_t)v_buffer) & 7)) return SP_ERR_UNSUPPORTED;
   ExtendArgs a;
@@ -397,7 +429,7 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
   a.seq_lens = seq_lens; a.kv_start = kv_start; a.idx64 = idx64; a.ext_lens = extend_seq_lens;
   a.ext_start = extend_start_loc; a.bs = batch_size; a.Hq = num_q_heads; a.Hkv = num_kv_heads;
   a.q_stride = q_stride; a.o_stride = out_stride; a.kv_stride = kv_buffer_stride;
-  a.sm_scale = sm_scale; a.logit_cap = logit_cap; a.causal = causal;
+  a.sm_scale = sm_scale; a.logit_cap = logit_cap; a.out_scale = out_scale; a.causal = causal;
   a.window = causal ? window_left : -1;
   a.kv8 = kv8;
   const int G = num_q_heads / num_kv_heads;

@@ -1,8 +1,10 @@
 """KV memory: request->slot table, slot allocator, per-layer K/V pool.
 
-Mirrors memory/pool.py: ReqToTokenPool 13-73, KVCache 150-186, TokenToKVPoolAllocator 189-255,
-MHATokenToKVPool 258-424 (page_size = 1 only, as the reference enforces at
-model_runner.py:431-432).  Slot 0 is the reserved dummy slot for padded rows.
+Same seam as memory/pool.py (ReqToTokenPool 13-73, KVCache 150-186, TokenToKVPoolAllocator 189-255,
+MHATokenToKVPool 258-424; page_size = 1 only, as the reference enforces at model_runner.py:431-432;
+slot 0 is the reserved dummy slot for padded rows) with the bookkeeping re-designed: both free lists
+are rings (host ring for request rows, device ring for KV slots) instead of lists that are rebuilt
+on every alloc/free.
 
 MI355X layout: K and V each live in ONE allocation [layers, P+1, Hkv, D] (token-major, NHD);
 ``get_key_buffer(l)`` is a view of layer l, so addresses and strides are what the reference's
@@ -11,152 +13,250 @@ per-layer tensors would have, while a 288 GB HBM pool is a single contiguous are
 import abc
 from typing import List, Optional, Tuple, Union
 
+import numpy as np
 import torch
 
 from . import _native
 
 
+class _HostFifo:
+    """Fixed-capacity FIFO of small integers on the host (numpy ring: head + count).  Pops come from
+    the head in insertion order, pushes go to the tail - the hand-out order a list sliced at the front
+    and appended at the back would give, without re-building the list on every call."""
+
+    def __init__(self, capacity: int):
+        self.capacity = max(int(capacity), 1)
+        self.ring = np.zeros(self.capacity, dtype=np.int64)
+        self.head = 0
+        self.count = 0
+
+    def load(self, values) -> None:
+        values = np.asarray(values, dtype=np.int64).reshape(-1)
+        if values.size > self.capacity:                     # a caller-supplied list may exceed the table
+            self.capacity = int(values.size)
+            self.ring = np.zeros(self.capacity, dtype=np.int64)
+        self.ring[:values.size] = values
+        self.head, self.count = 0, int(values.size)
+
+    def pop(self, n: int) -> np.ndarray:
+        idx = (self.head + np.arange(n)) % self.capacity
+        self.head = (self.head + n) % self.capacity
+        self.count -= n
+        return self.ring[idx]
+
+    def push(self, values) -> None:
+        values = np.asarray(values, dtype=np.int64).reshape(-1)
+        if self.count + values.size > self.capacity:
+            raise RuntimeError("free list overflow: more rows returned than the pool has")
+        idx = (self.head + self.count + np.arange(values.size)) % self.capacity
+        self.ring[idx] = values
+        self.count += int(values.size)
+
+    def snapshot(self) -> np.ndarray:
+        return self.ring[(self.head + np.arange(self.count)) % self.capacity].copy()
+
+
 class ReqToTokenPool:
-    """memory/pool.py:13-73: req_to_token[size, max_context_len] int32 + host free-list."""
+    """The request -> KV-slot table of memory/pool.py:13-73: ``req_to_token[size, max_context_len]``
+    int32 on the device (row = request, column = position), plus the free request rows.  Public
+    surface kept for the seam: ``req_to_token``, ``size``, ``max_context_len``, ``alloc`` (rows as a
+    Python list, ``None`` when short), ``free`` (one row or a list), ``clear``, ``available_size``,
+    ``write`` and the write journal (``get_write_records`` / ``apply_write_records``, used by the
+    reference's overlap worker to mirror table writes).  Rows are handed out first-freed-first."""
 
     def __init__(self, size: int, max_context_len: int, device: str, use_records: bool = False):
         self.size = size
         self.max_context_len = max_context_len
         self.device = device
-        self.req_to_token = torch.zeros((size, max_context_len), dtype=torch.int32, device=device)
-        self.free_slots = list(range(size))
-        self.write_records = []
         self.use_records = use_records
-        self.write = self.write_with_records if use_records else self.write_without_records
+        self.req_to_token = torch.zeros((size, max_context_len), dtype=torch.int32, device=device)
+        self._rows = _HostFifo(size)
+        self._journal: List[Tuple] = []
+        self.clear()
 
-    def available_size(self):
-        return len(self.free_slots)
+    # the free rows in hand-out order; assignable (tests and benches lay out a specific order)
+    @property
+    def free_slots(self) -> List[int]:
+        return self._rows.snapshot().tolist()
+
+    @free_slots.setter
+    def free_slots(self, rows) -> None:
+        self._rows.load(list(rows))
+
+    def available_size(self) -> int:
+        return self._rows.count
 
     def alloc(self, need_size: int) -> Optional[List[int]]:
-        if need_size > len(self.free_slots):
+        if need_size > self._rows.count:
             return None
-        select_index = self.free_slots[:need_size]
-        self.free_slots = self.free_slots[need_size:]
-        return select_index
+        return self._rows.pop(need_size).tolist()
 
-    def free(self, free_index: Union[int, List[int]]):
-        if isinstance(free_index, int):
-            self.free_slots.append(free_index)
-        else:
-            self.free_slots.extend(free_index)
+    def free(self, free_index: Union[int, List[int]]) -> None:
+        self._rows.push([free_index] if isinstance(free_index, int) else free_index)
 
-    def clear(self):
-        self.free_slots = list(range(self.size))
-        self.write_records = []
+    def clear(self) -> None:
+        self._rows.load(np.arange(self.size))
+        self._journal = []
 
-    def write_without_records(self, indices, values):
+    def write(self, indices, values) -> None:
         self.req_to_token[indices] = values
+        if self.use_records:
+            self._journal.append((indices, values))
 
-    def write_with_records(self, indices, values):
-        self.req_to_token[indices] = values
-        self.write_records.append((indices, values))
+    def get_write_records(self) -> List[Tuple]:
+        out, self._journal = self._journal, []
+        return out
 
-    def get_write_records(self):
-        ret = self.write_records
-        self.write_records = []
-        return ret
-
-    def apply_write_records(self, write_records: List[Tuple]):
+    def apply_write_records(self, write_records: List[Tuple]) -> None:
         for indices, values in write_records:
             self.req_to_token[indices] = values
 
 
 class KVCache(abc.ABC):
-    """memory/pool.py:150-186."""
+    """The cache interface of memory/pool.py:150-186 (what an attention backend may call)."""
 
     @abc.abstractmethod
     def get_key_buffer(self, layer_id: int) -> torch.Tensor:
-        raise NotImplementedError()
+        ...
 
     @abc.abstractmethod
     def get_value_buffer(self, layer_id: int) -> torch.Tensor:
-        raise NotImplementedError()
+        ...
 
     @abc.abstractmethod
     def get_kv_buffer(self, layer_id: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        raise NotImplementedError()
+        ...
 
     @abc.abstractmethod
     def set_kv_buffer(self, layer, loc: torch.Tensor, cache_k: torch.Tensor,
                       cache_v: torch.Tensor) -> None:
-        raise NotImplementedError()
+        ...
 
     @abc.abstractmethod
     def get_flat_data(self, indices):
-        raise NotImplementedError()
+        ...
 
     @abc.abstractmethod
     def transfer(self, indices, flat_data):
-        raise NotImplementedError()
+        ...
 
     @abc.abstractmethod
     def transfer_per_layer(self, indices, flat_data, layer_id):
-        raise NotImplementedError()
+        ...
 
     def register_layer_transfer_counter(self, layer_transfer_counter):
         self.layer_transfer_counter = layer_transfer_counter
 
 
 class TokenToKVPoolAllocator:
-    """memory/pool.py:189-255: free-list of slot ids 1..size (int64, on `device`)."""
+    """KV slot allocator with the interface of memory/pool.py:189-255 (slot ids 1..size as int64 on
+    ``device``, slot 0 reserved for padded rows, page_size 1), built as a **device-resident ring**:
+
+    * ``_ring[capacity]`` holds the free slot ids; the host keeps ``_head`` and ``_count`` - every
+      size it needs (``alloc(n)``, ``free(t)`` with ``t.numel()``) is host-known, so no call ever
+      reads the device;
+    * ``alloc(n)`` copies ``n`` ids out of the ring at the head (one small copy; a wrap makes it two
+      pieces) - the returned tensor is the caller's own, later frees cannot touch it;
+    * ``free(t)`` appends ``t`` at the tail (one small copy).  The reference re-materialises the whole
+      free list with ``torch.cat`` on every free - 4.5 MB per decode step for a 560 k-slot pool;
+      here a step's alloc + free moves ``2 x batch`` ids;
+    * hand-out order is first-freed-first, which is what the reference's slice-the-head /
+      append-at-the-tail list gives, so recorded reference traces replay bit for bit
+      (``tests/test_host_logic.py``, ``tests/test_radix_cache.py``);
+    * ``free_group_begin/end`` batches the frees of one scheduler event into a single append;
+      ``backup_state`` / ``restore_state`` snapshot and reload the list (speculative paths)."""
 
     def __init__(self, size: int, dtype: torch.dtype, device: str, kvcache: KVCache):
         self.size = size
         self.dtype = dtype
         self.device = device
         self.page_size = 1
-        self.free_slots = None
-        self.is_not_in_free_group = True
-        self.free_group = []
-        self.clear()
         self._kvcache = kvcache
+        self._capacity = max(int(size), 1)
+        self._ring = torch.empty(self._capacity, dtype=torch.int64, device=device)
+        self._head = 0
+        self._count = 0
+        self._group: Optional[List[torch.Tensor]] = None     # open free-group, else None
+        self.clear()
 
-    def available_size(self):
-        return len(self.free_slots)
+    # ---- the list view (tests, benches and backup/restore use it; the hot calls never do)
+    @property
+    def free_slots(self) -> torch.Tensor:
+        return self._take(self._head, self._count)
+
+    @free_slots.setter
+    def free_slots(self, slots: torch.Tensor) -> None:
+        slots = slots.to(device=self.device, dtype=torch.int64).reshape(-1)
+        if slots.numel() > self._capacity:
+            self._capacity = int(slots.numel())
+            self._ring = torch.empty(self._capacity, dtype=torch.int64, device=self.device)
+        self._ring[:slots.numel()] = slots
+        self._head, self._count = 0, int(slots.numel())
+
+    def _take(self, start: int, n: int) -> torch.Tensor:
+        """n ring entries from `start` as a fresh tensor (two pieces across the wrap)."""
+        first = min(n, self._capacity - start)
+        if first == n:
+            return self._ring[start:start + n].clone()
+        return torch.cat((self._ring[start:], self._ring[:n - first]))
+
+    def _append(self, ids: torch.Tensor) -> None:
+        n = ids.numel()
+        if self._count + n > self._capacity:
+            raise RuntimeError("KV free list overflow: more slots freed than the pool has")
+        tail = (self._head + self._count) % self._capacity
+        first = min(n, self._capacity - tail)
+        self._ring[tail:tail + first] = ids[:first]
+        if first < n:
+            self._ring[:n - first] = ids[first:]
+        self._count += n
+
+    # ---- the allocator interface
+    def available_size(self) -> int:
+        return self._count
 
     def get_kvcache(self):
         return self._kvcache
 
-    def alloc(self, need_size: int):
-        if need_size > len(self.free_slots):
+    def alloc(self, need_size: int) -> Optional[torch.Tensor]:
+        if need_size > self._count:
             return None
-        select_index = self.free_slots[:need_size]
-        self.free_slots = self.free_slots[need_size:]
-        return select_index
+        out = self._take(self._head, need_size)
+        self._head = (self._head + need_size) % self._capacity
+        self._count -= need_size
+        return out
 
-    def free(self, free_index: torch.Tensor):
+    def free(self, free_index: torch.Tensor) -> None:
         if free_index.numel() == 0:
             return
-        if self.is_not_in_free_group:
-            self.free_slots = torch.cat((self.free_slots, free_index))
+        ids = free_index.reshape(-1).to(device=self.device, dtype=torch.int64)
+        if self._group is not None:
+            self._group.append(ids)
         else:
-            self.free_group.append(free_index)
+            self._append(ids)
 
-    def free_group_begin(self):
-        self.is_not_in_free_group = False
-        self.free_group = []
+    def free_group_begin(self) -> None:
+        self._group = []
 
-    def free_group_end(self):
-        self.is_not_in_free_group = True
-        if self.free_group:
-            self.free(torch.cat(self.free_group))
+    def free_group_end(self) -> None:
+        pending, self._group = self._group, None
+        if pending:
+            self._append(torch.cat(pending) if len(pending) > 1 else pending[0])
 
-    def backup_state(self):
+    @property
+    def is_not_in_free_group(self) -> bool:
+        return self._group is None
+
+    def backup_state(self) -> torch.Tensor:
         return self.free_slots
 
-    def restore_state(self, free_slots):
+    def restore_state(self, free_slots: torch.Tensor) -> None:
         self.free_slots = free_slots
 
-    def clear(self):
-        # slot 0 is reserved for dummy writes of padded tokens
-        self.free_slots = torch.arange(1, self.size + 1, dtype=torch.int64, device=self.device)
-        self.is_not_in_free_group = True
-        self.free_group = []
+    def clear(self) -> None:
+        # slot 0 stays out of the list: padded rows write and read it (the dummy slot)
+        self.free_slots = torch.arange(1, self.size + 1, dtype=torch.int64)
+        self._group = None
 
 
 class MHATokenToKVPool(KVCache):

@@ -24,14 +24,12 @@ def nat():
 
 
 @pytest.fixture(params=["auto", "valu", "mfma"])
-def decode_kernel(request, monkeypatch):
+def decode_kernel(request, nat):
     """run a test under the library's own kernel choice and with each decode kernel forced
-    (SP_DECODE_KERNEL is read per call; fp32 always takes the VALU kernel)"""
-    if request.param == "auto":
-        monkeypatch.delenv("SP_DECODE_KERNEL", raising=False)
-    else:
-        monkeypatch.setenv("SP_DECODE_KERNEL", request.param)
-    return request.param
+    (sp_debug_set("decode_kernel"); fp32 always takes the VALU kernel)"""
+    nat.debug_set("decode_kernel", {"auto": 0, "valu": 1, "mfma": 2}[request.param])
+    yield request.param
+    nat.debug_set("decode_kernel", 0)
 
 
 def run_decode(nat, p, scale, cap=0.0, chunk=64, max_len=None, kv_start=None, idx_dtype=None,
@@ -464,10 +462,10 @@ def test_random_shapes_decode_and_extend_against_oracle(nat):
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("Hq,Hkv,D", [(16, 1, 128), (32, 2, 128), (12, 2, 64), (24, 8, 128), (10, 2, 128)])
-def test_decode_wide_and_odd_groups_on_the_matrix_core_kernel(nat, dt, Hq, Hkv, D, monkeypatch):
+def test_decode_wide_and_odd_groups_on_the_matrix_core_kernel(nat, dt, Hq, Hkv, D):
     """Query-head groups that are not 1/2/4/8 (up to 16 heads per KV head, e.g. Llama-3.1-405B's 128/8):
     the MFMA decode kernel carries the group as tile columns, so any width <= 16 works."""
-    monkeypatch.delenv("SP_DECODE_KERNEL", raising=False)
+    nat.debug_set("decode_kernel", 0)
     dtype = DTYPES[dt]
     lens = [1, 17, 64, 65, 300, 513, 1000, 129]
     p = paged_problem(81, len(lens), Hq, Hkv, D, lens, dtype, DEV)

@@ -198,3 +198,76 @@ def test_vision_attention_plan_partition(monkeypatch):
     assert moved.main.seq_lens == [4096] and moved.side.seq_lens == [28, 4] and moved.side.key_lens == [4 * P, 4 * Pp]
     both = torch.cat([moved.main_rows, moved.side_rows]).sort().values
     assert torch.equal(both, torch.arange(4 * Pp)), "every position is computed exactly once"
+
+
+def test_ring_allocators_match_a_list_model_across_wraps():
+    """Both free lists are rings (pool.py): a long random alloc / free / free-group / backup-restore
+    sequence, which wraps the rings many times, must hand out exactly what the reference's
+    slice-the-head / append-at-the-tail lists would."""
+    import random
+    rnd = random.Random(7)
+    size = 37
+    alloc = TokenToKVPoolAllocator(size, torch.float32, "cpu", None)
+    model = list(range(1, size + 1))
+    held = []
+    for step in range(3000):
+        op = rnd.random()
+        if op < 0.45:
+            n = rnd.randint(0, 9)
+            got = alloc.alloc(n)
+            if n > len(model):
+                assert got is None
+            else:
+                assert got.tolist() == model[:n], step
+                model = model[n:]
+                held.extend(got.tolist())
+        elif op < 0.85 and held:
+            rnd.shuffle(held)
+            k = rnd.randint(1, min(len(held), 11))
+            back, held = held[:k], held[k:]
+            if rnd.random() < 0.3:
+                alloc.free_group_begin()
+                assert not alloc.is_not_in_free_group
+                mid = rnd.randint(0, k)
+                alloc.free(torch.tensor(back[:mid], dtype=torch.int64))
+                alloc.free(torch.tensor(back[mid:], dtype=torch.int64))
+                assert alloc.available_size() == len(model), "a group's frees land at free_group_end"
+                alloc.free_group_end()
+            else:
+                alloc.free(torch.tensor(back, dtype=torch.int64))
+            model = model + back
+        elif op < 0.9:
+            state = alloc.backup_state()
+            n = min(len(model), rnd.randint(0, 5))
+            assert alloc.alloc(n).tolist() == model[:n]
+            alloc.restore_state(state)              # the allocation is undone
+        assert alloc.available_size() == len(model)
+    assert alloc.free_slots.tolist() == model and 0 not in model
+    with pytest.raises(RuntimeError, match="overflow"):
+        alloc.free(torch.arange(1, size + 2))
+
+    rows = ReqToTokenPool(9, 4, "cpu")
+    rmodel = list(range(9))
+    rheld = []
+    for step in range(2000):
+        if rnd.random() < 0.5:
+            n = rnd.randint(0, 4)
+            got = rows.alloc(n)
+            if n > len(rmodel):
+                assert got is None
+            else:
+                assert got == rmodel[:n] and all(isinstance(x, int) for x in got)
+                rmodel = rmodel[n:]
+                rheld.extend(got)
+        elif rheld:
+            rnd.shuffle(rheld)
+            if rnd.random() < 0.5:
+                x = rheld.pop()
+                rows.free(x)
+                rmodel.append(x)
+            else:
+                k = rnd.randint(1, len(rheld))
+                back, rheld = rheld[:k], rheld[k:]
+                rows.free(back)
+                rmodel.extend(back)
+        assert rows.available_size() == len(rmodel) and rows.free_slots == rmodel

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--D", type=int, default=128)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--waves", default="0", help="comma list of sp_debug_set('extend_waves') values to time")
+    ap.add_argument("--rounds", type=int, default=3, help="interleaved timing rounds per variant")
     a = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
     dev = "cuda"
@@ -53,18 +55,28 @@ def main():
     seq_d = seq.to(dev)
     run = lambda: _native.extend_attention(o, q, kb, vb, r2t, req, seq_d, ext_d, start, a.D ** -0.5, 0.0, True,
                                            int(ext.max()), int(seq.max()), ws)
-    run()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(a.iters):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / a.iters
     flops = 4 * a.Hq * a.D * float(((ext.double() ** 2) / 2 + ext.double() * pre.double()).sum())
-    print(f"extend bs={a.bs} tokens={T} prefix={a.prefix} {a.dtype}: {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s "
-          f"(causal flops {flops / 1e12:.2f} T)", flush=True)
+    variants = [int(w) for w in a.waves.split(",")]
+    times = {w: [] for w in variants}
+    for w in variants:
+        _native.debug_set("extend_waves", w)
+        run()
+    torch.cuda.synchronize()
+    for _ in range(a.rounds):          # interleaved rounds in one process (same clocks, same device)
+        for w in variants:
+            _native.debug_set("extend_waves", w)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            times[w].append(e0.elapsed_time(e1) / a.iters)
+    _native.debug_set("extend_waves", 0)
+    for w in variants:
+        ms = sorted(times[w])[len(times[w]) // 2]
+        print(f"extend bs={a.bs} tokens={T} prefix={a.prefix} {a.dtype} waves={w}: {ms:.3f} ms (best {min(times[w]):.3f})  "
+              f"{flops / ms / 1e9:.1f} TFLOP/s (causal flops {flops / 1e12:.2f} T)", flush=True)
 
 
 if __name__ == "__main__":
