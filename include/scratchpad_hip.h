@@ -48,9 +48,9 @@ SP_API int sp_abi_version(void);
 SP_API const char* sp_status_string(int status);
 /* Test / tuning hook (no reference counterpart): process-wide kernel-selection switches for A/B
  * measurements and parity tests of the non-default kernels.  Keys: "decode_kernel" (0 = default,
- * 1 = VALU kernel, 2 = matrix-core kernel), "extend_waves" (0 = default, 4 or 8 waves per
- * workgroup).  Nothing on the call path reads the environment.  Returns SP_ERR_INVALID_ARG for
- * an unknown key.                                                                                */
+ * 1 = VALU kernel, 2 = matrix-core kernel), "extend_defer_x10" (how far the extend kernel's running
+ * row maximum may trail, in tenths of a log2 unit; < 0 = the shipped value).  Nothing on the call
+ * path reads the environment.  Returns SP_ERR_INVALID_ARG for an unknown key.                    */
 SP_API int sp_debug_set(const char* key, int value);
 
 /* ---- RMSNorm: replaces flashinfer.norm.rmsnorm / fused_add_rmsnorm
@@ -176,6 +176,17 @@ SP_API int sp_decode_attention(void* out, const void* q, const void* k_buffer, c
  * workspace: sp_extend_attention_workspace_bytes().                                              */
 SP_API size_t sp_extend_attention_workspace_bytes(int64_t num_tokens, int batch_size, int num_q_heads,
                                            int head_dim, int dtype);
+/* `plan` (optional, may be NULL): the step's (request, row block) work items, heaviest first, built once
+ * per forward by sp_extend_plan() from the same extend_seq_lens / seq_lens / head counts / causal flag
+ * and shared by every layer (the counterpart of flashinfer's begin_forward() for the prefill wrappers,
+ * flashinfer_backend.py:400-444, 672-830).  It only decides which workgroup computes which rows (no
+ * empty workgroups on ragged batches, longest rows first); results do not depend on it.  A plan built
+ * for other head counts is ignored by the kernel's workgroups (nothing is written): build it with the
+ * layer's own num_q_heads / num_kv_heads.  sp_extend_plan_bytes() sizes the int32 buffer.          */
+SP_API size_t sp_extend_plan_bytes(int64_t num_tokens, int batch_size, int num_q_heads, int num_kv_heads);
+SP_API int sp_extend_plan(int32_t* plan, size_t plan_bytes, const int32_t* extend_seq_lens, const void* seq_lens,
+                   int idx64, int batch_size, int64_t num_tokens, int num_q_heads, int num_kv_heads,
+                   int causal, void* stream);
 SP_API int sp_extend_attention(void* out, const void* q, const void* k_buffer, const void* v_buffer,
                         const int32_t* req_to_token, int64_t req_to_token_stride,
                         const void* req_pool_indices, const void* seq_lens, const void* kv_start,
@@ -185,8 +196,8 @@ SP_API int sp_extend_attention(void* out, const void* q, const void* k_buffer, c
                         int64_t out_stride, int64_t kv_buffer_stride, float sm_scale,
                         float logit_cap, float k_scale, float v_scale, int causal,
                         int window_left, int max_extend_len,
-                        int64_t max_seq_len, void* workspace, size_t workspace_bytes, int dtype,
-                        int kv_dtype, void* stream);
+                        int64_t max_seq_len, void* workspace, size_t workspace_bytes,
+                        const int32_t* plan, int dtype, int kv_dtype, void* stream);
 
 /* ---- Sampler.  Replaces nn/layers/sampler.py:63-75 (torch.argmax; logits.div_(T) + softmax),
  *      sampler.py:195-232 (top_k_top_p_min_p_sampling_from_probs_torch, top_p_normalize_probs_torch)
@@ -204,6 +215,16 @@ SP_API int sp_extend_attention(void* out, const void* q, const void* k_buffer, c
  * sp_argmax returns the first maximal index (torch.argmax).                                       */
 SP_API int sp_argmax(const void* logits, int64_t row_stride, int batch_size, int vocab, int64_t* out_ids,
               int dtype, void* stream);
+/* Vocab-parallel greedy (TP): instead of all-gathering [bs, vocab / tp] logits and taking the argmax
+ * of the gathered row (nn/layers/logits_processor.py:362-369 followed by sampler.py:63-65), every
+ * rank reduces its own shard to out_pairs[b] = {fp32 bits of the shard maximum, global index of its
+ * first occurrence = local index + index_offset}; the caller all-gathers the [bs, 2] int32 words
+ * rank-major and sp_argmax_merge returns, per row, the index of the largest value, ties to the
+ * lowest global index - bit-identical to the gathered path.  `cols` = this rank's columns that are
+ * real vocabulary (padding columns excluded; 0 = none: the shard never wins).                   */
+SP_API int sp_argmax_shard(const void* logits, int64_t row_stride, int batch_size, int cols, int index_offset,
+                    int32_t* out_pairs, int dtype, void* stream);
+SP_API int sp_argmax_merge(const int32_t* pairs, int num_shards, int batch_size, int64_t* out_ids, void* stream);
 SP_API int sp_softmax_temperature(float* logits_inout, int64_t row_stride, const float* temperatures,
                            int batch_size, int vocab, void* stream);
 SP_API int sp_top_k_top_p_min_p_sample(const float* probs, int64_t row_stride, const int32_t* top_ks,
@@ -229,16 +250,21 @@ SP_API int sp_gemm_skinny(void* out, const void* x, const void* w, int M, int N,
  *      sp_ar_flag_bytes() + 2 * data_bytes, exports it (64-byte IPC handle), and imports every peer's.
  *      sp_custom_all_reduce sums `num_elems` elements over the `world` ranks (one-shot up to 256 KiB,
  *      reduce-scatter + all-gather above); `regions[r]` = rank r's region as mapped in this process;
- *      `epoch` advances by 3 per call on every rank alike.  Opt-in (see allreduce.hip: not yet run across
- *      xGMI).  These are the only entries that allocate; the region is owned by the caller's object. */
+ *      calls are collective (every rank issues the same sequence; the call counters live in the regions,
+ *      so the launch is graph-capturable - the role of pynccl inside the reference's graphs,
+ *      parallel_state.py:256-302).  sp_ar_status reads the region's status word (1 = a peer barrier timed
+ *      out, results since then are invalid); it synchronises and is meant for check points, not the call
+ *      path.  Opt-in (see allreduce.hip: not yet run across xGMI).  sp_ar_alloc/import are the only
+ *      entries that allocate; the region is owned by the caller's object.                              */
 SP_API size_t sp_ar_flag_bytes(void);
 SP_API int sp_ar_alloc(void** ptr, size_t bytes);
 SP_API int sp_ar_free(void* ptr);
 SP_API int sp_ar_ipc_export(void* ptr, void* handle64);
 SP_API int sp_ar_ipc_import(const void* handle64, void** ptr);
 SP_API int sp_ar_ipc_close(void* ptr);
+SP_API int sp_ar_status(const void* own_region, int* status);
 SP_API int sp_custom_all_reduce(void* out, const void* in, int64_t num_elems, int dtype, void* const* regions,
-                         int rank, int world, uint32_t epoch, size_t data_bytes, void* stream);
+                         int rank, int world, size_t data_bytes, void* stream);
 
 #ifdef __cplusplus
 }

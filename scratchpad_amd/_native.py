@@ -56,10 +56,14 @@ SIGNATURES = {
     "sp_extend_attention_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32]),
     "sp_extend_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp,
                                    _i32, _i64, _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32, _f32, _f32,
-                                   _i32, _i32, _i32, _i64, _vp, _sz, _i32, _i32, _vp]),
+                                   _i32, _i32, _i32, _i64, _vp, _sz, _vp, _i32, _i32, _vp]),
+    "sp_extend_plan_bytes": (_sz, [_i64, _i32, _i32, _i32]),
+    "sp_extend_plan": (_i32, [_vp, _sz, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
     "sp_kv_store_fp8": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _f32,
                                _i32, _vp]),
     "sp_argmax": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp]),
+    "sp_argmax_shard": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "sp_argmax_merge": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "sp_softmax_temperature": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp]),
     "sp_top_k_top_p_min_p_sample": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "sp_top_k_top_p_min_p_renorm": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
@@ -69,7 +73,8 @@ SIGNATURES = {
     "sp_ar_ipc_export": (_i32, [_vp, _vp]),
     "sp_ar_ipc_import": (_i32, [_vp, _vp]),
     "sp_ar_ipc_close": (_i32, [_vp]),
-    "sp_custom_all_reduce": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, ctypes.c_uint32, _sz, _vp]),
+    "sp_ar_status": (_i32, [_vp, _vp]),
+    "sp_custom_all_reduce": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _sz, _vp]),
     "sp_gemm_skinny": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp]),
 }
 
@@ -105,7 +110,7 @@ def _check(status: int, what: str):
 
 
 def debug_set(key: str, value: int) -> None:
-    """Test / tuning switch of the library (sp_debug_set): "decode_kernel", "extend_waves"."""
+    """Test / tuning switch of the library (sp_debug_set): "decode_kernel", "extend_defer_x10"."""
     _check(load().sp_debug_set(key.encode(), int(value)), f"sp_debug_set({key})")
 
 
@@ -361,11 +366,14 @@ def extend_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
                      sm_scale: float, logit_cap: float, causal: bool, max_extend_len: int,
                      max_seq_len: int, workspace: torch.Tensor,
                      kv_start: Optional[torch.Tensor] = None, window_left: int = -1,
-                     k_scale: Optional[float] = None, v_scale: Optional[float] = None) -> None:
+                     k_scale: Optional[float] = None, v_scale: Optional[float] = None,
+                     plan: Optional[torch.Tensor] = None) -> None:
     """q, out: [T, Hq, D]; the new tokens' K/V must already be in the pool.  window_left >= 0:
     causal rows see only the window_left keys before their own position (and themselves)."""
     _gpu(out, q, k_buffer, v_buffer, req_to_token, req_pool_indices, seq_lens, extend_seq_lens,
-         extend_start_loc, workspace, kv_start)
+         extend_start_loc, workspace, kv_start, plan)
+    if plan is not None and plan.dtype != torch.int32:
+        raise RuntimeError("extend_attention: plan must be int32 (extend_plan)")
     T, Hq, D = q.shape
     if q.stride(2) != 1 or q.stride(1) != D or out.stride(2) != 1 or out.stride(1) != D:
         raise RuntimeError("extend_attention: q/out must be [T, Hq, D] with contiguous heads")
@@ -384,7 +392,25 @@ def extend_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
         seq.shape[0], T, Hq, k_buffer.shape[1], D, q.stride(0), out.stride(0), k_buffer.stride(0),
         sm_scale, logit_cap, 1.0 if k_scale is None else float(k_scale),
         1.0 if v_scale is None else float(v_scale), int(causal), int(window_left), max_extend_len, max_seq_len, workspace.data_ptr(),
-        workspace.numel() * workspace.element_size(), _dt(q), kv_dt, _stream()), "sp_extend_attention")
+        workspace.numel() * workspace.element_size(), _ptr(plan), _dt(q), kv_dt, _stream()), "sp_extend_attention")
+
+
+def extend_plan(extend_seq_lens: torch.Tensor, seq_lens: torch.Tensor, num_tokens: int, Hq: int, Hkv: int,
+                causal: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The (request, row block) work items of an extend step, heaviest first (int32; reuse `out` when it
+    is large enough).  Built once per forward, shared by all layers with these head counts."""
+    _gpu(extend_seq_lens, seq_lens, out)
+    if extend_seq_lens.dtype != torch.int32 or seq_lens.dtype not in (torch.int32, torch.int64):
+        raise RuntimeError("extend_plan: extend_seq_lens int32, seq_lens int32/int64")
+    bs = extend_seq_lens.shape[0]
+    need = int(load().sp_extend_plan_bytes(num_tokens, bs, Hq, Hkv)) // 4
+    if out is None or out.numel() < need or out.dtype != torch.int32:
+        out = torch.empty(need, dtype=torch.int32, device=extend_seq_lens.device)
+    seq = seq_lens.contiguous()
+    _check(load().sp_extend_plan(out.data_ptr(), out.numel() * 4, extend_seq_lens.contiguous().data_ptr(),
+                                 seq.data_ptr(), int(seq.dtype == torch.int64), bs, num_tokens, Hq, Hkv,
+                                 int(causal), _stream()), "sp_extend_plan")
+    return out
 
 
 # --------------------------------------------------------------------------- sampler
@@ -410,6 +436,30 @@ def argmax(logits: torch.Tensor) -> torch.Tensor:
     out = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
     _check(load().sp_argmax(logits.data_ptr(), logits.stride(0), logits.shape[0], logits.shape[1],
                             out.data_ptr(), _dt(logits), _stream()), "sp_argmax")
+    return out
+
+
+def argmax_shard(logits: torch.Tensor, cols: int, index_offset: int) -> torch.Tensor:
+    """This rank's vocab shard [bs, >= cols] -> int32 [bs, 2] = (fp32 bits of the row maximum over the
+    first `cols` columns, global index of its first occurrence)."""
+    _gpu(logits)
+    logits = _prob_rows(logits, "argmax_shard")
+    if not 0 <= cols <= logits.shape[1]:
+        raise RuntimeError("argmax_shard: cols out of range")
+    out = torch.empty((logits.shape[0], 2), dtype=torch.int32, device=logits.device)
+    _check(load().sp_argmax_shard(logits.data_ptr(), logits.stride(0), logits.shape[0], int(cols),
+                                  int(index_offset), out.data_ptr(), _dt(logits), _stream()), "sp_argmax_shard")
+    return out
+
+
+def argmax_merge(pairs: torch.Tensor) -> torch.Tensor:
+    """pairs: int32 [shards, bs, 2] (rank-major all-gather of argmax_shard outputs) -> int64 [bs]."""
+    _gpu(pairs)
+    if pairs.dtype != torch.int32 or pairs.dim() != 3 or pairs.shape[2] != 2 or not pairs.is_contiguous():
+        raise RuntimeError("argmax_merge: contiguous int32 [shards, bs, 2] expected")
+    out = torch.empty(pairs.shape[1], dtype=torch.int64, device=pairs.device)
+    _check(load().sp_argmax_merge(pairs.data_ptr(), pairs.shape[0], pairs.shape[1], out.data_ptr(), _stream()),
+           "sp_argmax_merge")
     return out
 
 

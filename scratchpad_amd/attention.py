@@ -136,6 +136,7 @@ class HipAttnBackend(AttentionBackend):
         self._window = None            # (lens, kv_start) of the windowed layers, this step
         self._graph_window = None
         self._graph_state = {}         # bs bucket -> (chunk, workspace, plan buffers) of its captured graph
+        self._extend_plan = None       # int32 work list of the current extend step (sp_extend_plan)
 
     # ---------------------------------------------------------------- launch planning
     def _head_groups(self, dtype: torch.dtype) -> int:
@@ -206,6 +207,11 @@ class HipAttnBackend(AttentionBackend):
             ws = self._ensure_workspace(_native.extend_workspace_bytes(
                 forward_batch.extend_num_tokens, bs, self.num_head, self.head_dim,
                 pool_dtype if pool_dtype.itemsize > 1 else torch.bfloat16))
+            # the step's (request, row block) work list, heaviest first: built once, read by every layer
+            # (where the reference's backends run begin_forward, flashinfer_backend.py:672-830)
+            self._extend_plan = _native.extend_plan(forward_batch.extend_seq_lens, forward_batch.seq_lens,
+                                                    forward_batch.extend_num_tokens, self.num_head,
+                                                    self.num_kv_head, True, self._extend_plan)
             self.forward_metadata = (max_extend, max_len, ws)
 
     def init_cuda_graph_state(self, max_bs: int):
@@ -342,7 +348,9 @@ class HipAttnBackend(AttentionBackend):
             forward_batch.extend_seq_lens, forward_batch.extend_start_loc, layer.scaling,
             layer.logit_cap, not layer.is_cross_attention, max_extend, max_len, ws, kv_start,
             window_left=layer.sliding_window_size if self._is_windowed(layer) else -1,
-            k_scale=k_scale, v_scale=v_scale)
+            k_scale=k_scale, v_scale=v_scale,
+            plan=self._extend_plan if layer.tp_q_head_num == self.num_head
+            and layer.tp_k_head_num == self.num_kv_head else None)
         return o
 
     def forward_decode(self, q, k, v, layer: RadixAttention, forward_batch: "ForwardBatch",

@@ -14,12 +14,19 @@
 // hipIpcOpenMemHandle.  A workgroup synchronises only with the SAME workgroup index on the other ranks:
 // lane p stores this call's epoch into flag slot [block][my rank] of peer p (system-scope release) and
 // spins until slot [block][p] of its own region shows the epoch (system-scope acquire).  Epochs
-// increase monotonically per communicator, so no flag is ever reset.  The kernel is graph-capturable
-// only with a fixed epoch sequence, so captured steps keep RCCL (should_custom_ar returns false during
-// capture).
+// increase monotonically per communicator, so no flag is ever reset.  The epoch is DEVICE state: every
+// workgroup keeps its own counter word in its rank's region (read at entry, advanced by 3 at exit;
+// only that workgroup of that rank ever touches it, and launches of one stream are serialised), so
+// the launch arguments are the same for every call and a captured launch replays correctly - the
+// all-reduces of a HIP-graph decode step need no library call (the reference runs pynccl inside its
+// graphs, distributed/parallel_state.py:256-302, device_communicators/pynccl.py:108-130).
+// A barrier that times out (lost or slow peer) raises the region's status word; the host reads it
+// through sp_ar_status() (CustomAllReduce.check(): in debug mode after every call, always at close()
+// and after a timed run) and then abandons the communicator for RCCL.
 //
-// STATUS: functional tests run with all ranks on ONE GPU (IPC within a device); it has not run across
-// xGMI in this round (no multi-GPU box available to the build), hence opt-in: SP_CUSTOM_ALLREDUCE=1.
+// STATUS: functional tests run with all ranks on ONE GPU (IPC within a device), eager and inside
+// HIP-graph replay; it has not run across xGMI (no multi-GPU box available to the build), hence opt-in:
+// SP_CUSTOM_ALLREDUCE=1.
 #include <cstring>
 
 #include "sp_common.h"
@@ -29,6 +36,10 @@ namespace sp {
 constexpr int kArMaxRanks = 8;
 constexpr int kArBlocks = 32;          // workgroups per launch (each syncs with its twin on the peers)
 constexpr int kArThreads = 512;
+// words of a region's flag area: [kArBlocks][kArMaxRanks] arrival flags, then one epoch counter per
+// workgroup, then the status word
+constexpr int kArEpochWord0 = kArBlocks * kArMaxRanks;
+constexpr int kArStatusWord = kArEpochWord0 + kArBlocks;
 
 struct ArArgs {
   char* region[kArMaxRanks];           // every rank's region as mapped in THIS process
@@ -36,8 +47,7 @@ struct ArArgs {
   void* out;
   int64_t n;                           // elements
   int rank, world;
-  uint32_t epoch;
-  int64_t flag_bytes, data_bytes;      // region layout: [flags][data][reduced]
+  int64_t flag_bytes, data_bytes;      // region layout: [flags | epoch counters | status][data][reduced]
 };
 
 __device__ __forceinline__ void ar_barrier(const ArArgs& a, uint32_t epoch) {
@@ -56,7 +66,7 @@ __device__ __forceinline__ void ar_barrier(const ArArgs& a, uint32_t epoch) {
     while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
       __builtin_amdgcn_s_sleep(8);
       if (++spins > (1l << 24)) {        // ~ seconds
-        ((volatile uint32_t*)a.region[a.rank])[kArBlocks * kArMaxRanks] = 1u;
+        ((volatile uint32_t*)a.region[a.rank])[kArStatusWord] = 1u;
         break;
       }
     }
@@ -79,9 +89,15 @@ __global__ __launch_bounds__(kArThreads) void all_reduce_kernel(ArArgs a) {
   const int64_t nvec = a.n / V;
   const int64_t tid = (int64_t)blockIdx.x * kArThreads + threadIdx.x, nthr = (int64_t)kArBlocks * kArThreads;
   char* my_data = a.region[a.rank] + a.flag_bytes;
+  // this workgroup's call counter (device state, see the header): the call uses epochs e, e+1, e+2
+  __shared__ uint32_t s_epoch;
+  volatile uint32_t* my_counter = (volatile uint32_t*)a.region[a.rank] + kArEpochWord0 + blockIdx.x;
+  if (threadIdx.x == 0) s_epoch = *my_counter + 1u;
+  __syncthreads();
+  const uint32_t epoch = s_epoch;
   // 1. publish my input
   for (int64_t i = tid; i < nvec; i += nthr) st16(my_data + i * 16, ld16((const char*)a.in + i * 16));
-  ar_barrier(a, a.epoch);
+  ar_barrier(a, epoch);
   if (!TWO_SHOT) {
     // 2. every rank sums all inputs (fixed rank order: identical bits on every rank)
     for (int64_t i = tid; i < nvec; i += nthr) {
@@ -91,7 +107,8 @@ __global__ __launch_bounds__(kArThreads) void all_reduce_kernel(ArArgs a) {
       for (int r = 0; r < a.world; ++r) accumulate16<Tag>(ld16(a.region[r] + a.flag_bytes + i * 16), acc);
       st16((char*)a.out + i * 16, pack16<Tag>(acc));
     }
-    ar_barrier(a, a.epoch + 1);        // nobody overwrites its data region while a peer still reads it
+    ar_barrier(a, epoch + 1);          // nobody overwrites its data region while a peer still reads it
+    if (threadIdx.x == 0) *my_counter = epoch + 2u;
     return;
   }
   // 2. reduce-scatter: I own vectors [lo, hi)
@@ -110,7 +127,7 @@ __global__ __launch_bounds__(kArThreads) void all_reduce_kernel(ArArgs a) {
     st16(my_red + i * 16, v);
     st16((char*)a.out + i * 16, v);
   }
-  ar_barrier(a, a.epoch + 1);
+  ar_barrier(a, epoch + 1);
   // 3. all-gather the other ranks' reduced slices
   for (int r = 0; r < a.world; ++r) {
     if (r == a.rank) continue;
@@ -118,15 +135,27 @@ __global__ __launch_bounds__(kArThreads) void all_reduce_kernel(ArArgs a) {
     const char* red = a.region[r] + a.flag_bytes + a.data_bytes;
     for (int64_t i = first_at(rlo); i < rhi; i += nthr) st16((char*)a.out + i * 16, ld16(red + i * 16));
   }
-  ar_barrier(a, a.epoch + 2);
+  ar_barrier(a, epoch + 2);
+  if (threadIdx.x == 0) *my_counter = epoch + 2u;
 }
 
 }  // namespace sp
 
 using namespace sp;
 
-// flags [blocks][ranks] + one 'a barrier timed out' word, padded to 256 bytes
-extern "C" size_t sp_ar_flag_bytes(void) { return (((size_t)kArBlocks * kArMaxRanks + 1) * sizeof(uint32_t) + 255) / 256 * 256; }
+// flags [blocks][ranks] + epoch counters [blocks] + one 'a barrier timed out' word, padded to 256 bytes
+extern "C" size_t sp_ar_flag_bytes(void) { return (((size_t)kArStatusWord + 1) * sizeof(uint32_t) + 255) / 256 * 256; }
+
+// status word of a rank's OWN region: 0 = every barrier so far completed, 1 = one timed out (results
+// since then are garbage).  Synchronises with the device (a small copy): not for the call path.
+extern "C" int sp_ar_status(const void* own_region, int* status) {
+  SP_CHECK_ARG(own_region && status);
+  uint32_t w = 0;
+  if (hipMemcpy(&w, (const uint32_t*)own_region + kArStatusWord, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess)
+    return SP_ERR_LAUNCH;
+  *status = (int)w;
+  return SP_OK;
+}
 
 extern "C" int sp_ar_alloc(void** ptr, size_t bytes) {
   SP_CHECK_ARG(ptr && bytes > 0);
@@ -158,10 +187,11 @@ extern "C" int sp_ar_ipc_import(const void* handle64, void** ptr) {
 extern "C" int sp_ar_ipc_close(void* ptr) { return hipIpcCloseMemHandle(ptr) == hipSuccess ? SP_OK : SP_ERR_LAUNCH; }
 
 // regions: host array of `world` pointers (every rank's region as mapped here; regions[rank] is my own).
-// Consumes epochs [epoch, epoch + 2]; the caller advances its epoch by 3 per call.
+// Calls are collective: every rank issues the same sequence (the device-side epoch counters advance
+// in lock step).  Graph-capturable.
 extern "C" int sp_custom_all_reduce(void* out, const void* in, int64_t num_elems, int dtype,
-                                    void* const* regions, int rank, int world, uint32_t epoch,
-                                    size_t data_bytes, void* stream) {
+                                    void* const* regions, int rank, int world, size_t data_bytes,
+                                    void* stream) {
   SP_CHECK_ARG(out && in && regions && num_elems >= 0 && world >= 2 && world <= kArMaxRanks);
   SP_CHECK_ARG(rank >= 0 && rank < world);
   if (num_elems == 0) return SP_OK;
@@ -171,7 +201,7 @@ extern "C" int sp_custom_all_reduce(void* out, const void* in, int64_t num_elems
   if ((size_t)num_elems * eb > data_bytes) return SP_ERR_WORKSPACE;
   ArArgs a;
   for (int r = 0; r < world; ++r) a.region[r] = (char*)regions[r];
-  a.in = in; a.out = out; a.n = num_elems; a.rank = rank; a.world = world; a.epoch = epoch;
+  a.in = in; a.out = out; a.n = num_elems; a.rank = rank; a.world = world;
   a.flag_bytes = (int64_t)sp_ar_flag_bytes(); a.data_bytes = (int64_t)data_bytes;
   const bool two_shot = (size_t)num_elems * eb > (256u << 10);
   hipStream_t st = (hipStream_t)stream;

@@ -43,10 +43,11 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
                     int idx64, const int32_t* extend_seq_lens, const int32_t* extend_start_loc,
                     int batch_size, int num_q_heads, int num_kv_heads, int head_dim, int64_t q_stride,
                     int64_t out_stride, int64_t kv_buffer_stride, float sm_scale, float logit_cap,
-                    float out_scale, int causal, int window_left, int max_extend_len, int dtype, int kv8, hipStream_t st);
+                    float out_scale, int causal, int window_left, int max_extend_len, const int32_t* plan,
+                    int plan_items, int dtype, int kv8, hipStream_t st);
 
 // test / tuning hooks behind sp_debug_set
 void set_decode_kernel(int which);
-void set_extend_waves(int nw);
+void set_extend_defer_x10(int tenths);
 
 }  // namespace sp

@@ -10,6 +10,7 @@
 // and the decode kernel (decode_attention.hip: coalesced full-row gathers, G query heads per
 // KV read) does the rest.  KV traffic is O(sum L^2) instead of O(sum L^2 / BLOCK_M); the MFMA
 // tile kernel for long 16-bit prompts replaces it where that matters.
+#include <algorithm>
 #include <cstring>
 
 #include "attention_internal.h"
@@ -40,16 +41,105 @@ __global__ __launch_bounds__(256) void expand_rows_kernel(
   }
 }
 
+// Work list of the MFMA extend kernel: the (request, row block) items of a step.  Requests are ordered
+// longest first (the launch ends on its shortest rows), and all row blocks of one request stay
+// together, last rows first: consecutive workgroups of a kv head (= of an XCD, see extend_mfma.hip) then
+// walk the SAME request's keys and share them in that XCD's L2.  (Sorting the items themselves by cost
+// interleaves the requests and measured 10 % slower: every XCD then streams many requests at once.)
+// One workgroup: a histogram of item counts over the requests' cost classes (64-key tiles), a scan
+// from the highest class down, and one ticket per request for its contiguous run of items.
+constexpr int kPlanThreads = 1024;
+constexpr int kPlanBins = 4096;         // requests above 262k keys share the top class
+__global__ __launch_bounds__(kPlanThreads) void extend_plan_kernel(
+    int32_t* __restrict__ plan, int max_items, const int32_t* __restrict__ extend_seq_lens,
+    const void* __restrict__ seq_lens, int idx64, int bs, int block_rows, int causal) {
+  __shared__ int s_bin[kPlanBins];
+  __shared__ int s_total;
+  for (int i = threadIdx.x; i < kPlanBins; i += kPlanThreads) s_bin[i] = 0;
+  __syncthreads();
+  for (int b = threadIdx.x; b < bs; b += kPlanThreads) {
+    const int E = extend_seq_lens[b];
+    const int L = (int)load_idx(seq_lens, b, idx64);
+    const int nblk = E > 0 ? (E + block_rows - 1) / block_rows : 0;
+    if (nblk > 0) atomicAdd(&s_bin[min((max(L, 0) + 63) / 64, kPlanBins - 1)], nblk);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {            // start offsets, longest class first (4096 adds: microseconds)
+    int run = 0;
+    for (int c = kPlanBins - 1; c >= 0; --c) {
+      const int n = s_bin[c];
+      s_bin[c] = run;
+      run += n;
+    }
+    s_total = run;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < bs; b += kPlanThreads) {
+    const int E = extend_seq_lens[b];
+    const int L = (int)load_idx(seq_lens, b, idx64);
+    const int nblk = E > 0 ? (E + block_rows - 1) / block_rows : 0;
+    if (nblk == 0) continue;
+    const int pos = atomicAdd(&s_bin[min((max(L, 0) + 63) / 64, kPlanBins - 1)], nblk);
+    for (int i = 0; i < nblk; ++i) {
+      if (pos + i < max_items) {
+        plan[2 + 2 * (pos + i)] = b;
+        plan[3 + 2 * (pos + i)] = nblk - 1 - i;      // the request's last rows (most keys) first
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    plan[0] = min(s_total, max_items);
+    plan[1] = block_rows;
+  }
+  (void)causal;
+}
+
+int extend_block_rows(int num_q_heads, int num_kv_heads);   // extend_mfma.hip
+
 }  // namespace sp
 
 using namespace sp;
 
+// items of a step: sum over requests of ceil(extend_len / block_rows) <= num_tokens / block_rows + bs
+static inline int64_t extend_plan_items(int64_t num_tokens, int batch_size, int block_rows) {
+  return num_tokens / block_rows + batch_size;
+}
+
+extern "C" size_t sp_extend_plan_bytes(int64_t num_tokens, int batch_size, int num_q_heads, int num_kv_heads) {
+  if (num_tokens <= 0 || batch_size <= 0 || num_q_heads <= 0 || num_kv_heads <= 0) return 16;
+  const int bm = extend_block_rows(num_q_heads, num_kv_heads);
+  return (size_t)(2 + 2 * extend_plan_items(num_tokens, batch_size, bm)) * sizeof(int32_t);
+}
+
+extern "C" int sp_extend_plan(int32_t* plan, size_t plan_bytes, const int32_t* extend_seq_lens,
+                              const void* seq_lens, int idx64, int batch_size, int64_t num_tokens,
+                              int num_q_heads, int num_kv_heads, int causal, void* stream) {
+  SP_CHECK_ARG(plan && extend_seq_lens && seq_lens && batch_size >= 0 && num_tokens >= 0);
+  SP_CHECK_ARG(num_q_heads > 0 && num_kv_heads > 0 && num_q_heads % num_kv_heads == 0);
+  if (plan_bytes < sp_extend_plan_bytes(num_tokens, batch_size, num_q_heads, num_kv_heads)) return SP_ERR_WORKSPACE;
+  const int bm = extend_block_rows(num_q_heads, num_kv_heads);
+  const int64_t items = extend_plan_items(num_tokens, batch_size, bm);
+  if (items > 0x3fffffffLL) return SP_ERR_INVALID_ARG;
+  extend_plan_kernel<<<dim3(1), kPlanThreads, 0, (hipStream_t)stream>>>(plan, (int)items, extend_seq_lens, seq_lens,
+                                                                      idx64, batch_size, bm, causal);
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
 extern "C" int sp_debug_set(const char* key, int value) {
   SP_CHECK_ARG(key);
   if (!strcmp(key, "decode_kernel")) { set_decode_kernel(value); return SP_OK; }
-  if (!strcmp(key, "extend_waves")) { set_extend_waves(value); return SP_OK; }
+  if (!strcmp(key, "extend_defer_x10")) { set_extend_defer_x10(value); return SP_OK; }
   return SP_ERR_INVALID_ARG;
 }
+
+#ifdef SP_EXTEND_STAMPS
+namespace sp { void set_extend_stamp_buffer(void* p); }
+extern "C" SP_API int sp_debug_extend_stamp_buffer(void* device_u64x8) {
+  sp::set_extend_stamp_buffer(device_u64x8);
+  return SP_OK;
+}
+#endif
 
 extern "C" size_t sp_extend_attention_workspace_bytes(int64_t num_tokens, int batch_size,
                                                       int num_q_heads, int head_dim, int dtype) {
@@ -70,7 +160,7 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
                                    float k_scale, float v_scale, int causal, int window_left,
                                    int max_extend_len,
                                    int64_t max_seq_len, void* workspace, size_t workspace_bytes,
-                                   int dtype, int kv_dtype, void* stream) {
+                                   const int32_t* plan, int dtype, int kv_dtype, void* stream) {
   SP_CHECK_ARG(out && q && k_buffer && v_buffer && req_to_token && req_pool_indices && seq_lens);
   SP_CHECK_ARG(extend_seq_lens && extend_start_loc && batch_size >= 0 && num_tokens >= 0);
   SP_CHECK_ARG(num_q_heads > 0 && num_kv_heads > 0 && num_q_heads % num_kv_heads == 0);
@@ -102,7 +192,10 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
                                    req_pool_indices, seq_lens, kv_start, idx64, extend_seq_lens,
                                    extend_start_loc, batch_size, num_q_heads, num_kv_heads, head_dim,
                                    q_stride, out_stride, kv_buffer_stride, sm_scale, logit_cap, v_scale,
-                                   causal, window_left, max_extend_len, dtype, kv8 ? 1 : 0, st);
+                                   causal, window_left, max_extend_len, plan,
+                                   (int)std::min<int64_t>(extend_plan_items(num_tokens, batch_size,
+                                       extend_block_rows(num_q_heads, num_kv_heads)), 0x7fffffff),
+                                   dtype, kv8 ? 1 : 0, st);
     if (rc != SP_ERR_UNSUPPORTED || kv8) return rc;   // an fp8 pool has no row-stream path
   }
 

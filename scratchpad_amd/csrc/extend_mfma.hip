@@ -26,7 +26,9 @@
 //     is then a rare, wave-uniform branch; P stays <= 2^kDeferLog2);
 //   * grid: x = kv head (fastest: the hardware deals consecutive workgroups round-robin to the 8
 //     XCDs, so with 8 kv heads every row block of one (request, kv head) runs on ONE XCD and its
-//     K/V re-reads hit that XCD's L2), y = row blocks, heaviest (last rows of the prompt) first.
+//     K/V re-reads hit that XCD's L2: FETCH_SIZE per launch 5.7 -> 1.8 GB), y = the (request, row
+//     block) items of sp_extend_plan, heaviest first (without a plan: every row block of every request,
+//     last rows of the prompt first).
 #include <type_traits>
 
 #include "attention_internal.h"
@@ -57,6 +59,9 @@ struct ExtendArgs {
   int causal;
   int kv8;      // 1: fp8 e5m2 pool (kv_stride in bytes); tile math in fp16, see decode_mfma.hip
   int window;   // sliding window: a row at kv position p sees keys [p - window, p]; < 0 = unlimited
+  float defer;  // the running maximum may trail the true row maximum by this much (log2 units)
+  const int32_t* plan;  // optional work list from sp_extend_plan: [count, BM, (request, row block) x count]
+  int plan_items;       // grid rows when a plan is given (an upper bound of its count)
 };
 
 static constexpr float kLog2eX = 1.4426950408889634f;
@@ -103,6 +108,24 @@ __device__ __forceinline__ float xchg32(float x) {
   return as_f32((threadIdx.x & 32) ? upper_gets : lower_gets);
 }
 
+// Diagnostic build only (-DSP_EXTEND_STAMPS, tools/build_stamps.sh; never in the shipped library):
+// s_memtime stamps between the segments of a tile iteration, summed per wave and added to a
+// caller-supplied buffer, to see where an iteration spends its cycles (cdna_hip_programming.md
+// section 7 'In-kernel stamps').
+#ifdef SP_EXTEND_STAMPS
+__device__ unsigned long long* g_stamp_buf = nullptr;
+#define SP_STAMP(var)                                                                       \
+  do {                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");             \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+  } while (0)
+#define SP_STAMP_ACC(slot, from, to) stamp_sum[slot] += (to) - (from)
+#else
+#define SP_STAMP(var) do { } while (0)
+#define SP_STAMP_ACC(slot, from, to) do { } while (0)
+#endif
+
 template <int D, int NT>
 struct ExtCfg {
   static constexpr int BN = 64;                    // keys per tile
@@ -115,7 +138,6 @@ struct ExtCfg {
   static constexpr int KSTEPS = D / 16;            // MFMA k-steps of Q.K^T
   static constexpr int DBLK = D / 32;              // 32-wide d blocks of O^T
   static constexpr int kTileBytes = BN * (SK + SV);   // one K tile + one V tile
-  static constexpr int kLdsBytes = 2 * kTileBytes;    // double-buffered: one barrier per tile
   static_assert(RPP <= BN && BN % RPP == 0, "staging geometry");
 };
 
@@ -123,6 +145,7 @@ struct ExtCfg {
 template <typename Tag, int D, int GK, int NW, bool KV8, bool PLAIN>
 __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
   constexpr int NT = NW * 64;
+  constexpr int NB = 2;                // LDS tile buffers: tile t lives in buffer t & 1
   typedef ExtCfg<D, NT> C;
   typedef typename std::conditional<KV8, f16_tag, Tag>::type CT;      // dtype of the tile math
   typedef typename std::conditional<KV8, u32x2, u32x4>::type raw_t;   // one thread's gathered chunk
@@ -130,11 +153,17 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
   constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK;
   constexpr int BM = 32 * (NW / GK);
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  // two (K,V) tile buffers: tile t lives in buffer t & 1
 
-  const int b = blockIdx.z;
+  int b, row0;
+  if (a.plan) {                                    // planned: items are sorted heaviest first
+    if ((int)blockIdx.y >= a.plan[0] || a.plan[1] != BM) return;   // plan[1]: the block size it was built for
+    b = a.plan[2 + 2 * blockIdx.y];
+    row0 = a.plan[3 + 2 * blockIdx.y] * BM;
+  } else {
+    b = blockIdx.z;
+    row0 = ((int)gridDim.y - 1 - (int)blockIdx.y) * BM;    // heaviest row blocks first
+  }
   const int E = a.ext_lens[b];
-  const int row0 = ((int)gridDim.y - 1 - (int)blockIdx.y) * BM;    // heaviest row blocks first
   if (row0 >= E) return;
   const int G = a.Hq / a.Hkv;
   const int halves = G / GK;                       // query-head blocks per kv head
@@ -191,39 +220,50 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
   const int st_row = tid / CPR, st_ch = tid % CPR;
   const int64_t tok_bytes = a.kv_stride * (KV8 ? 1 : 2);
   const int64_t head_off = (int64_t)hk * D * (KV8 ? 1 : 2) + st_ch * (KV8 ? 8 : 16);
-  raw_t kreg[PASSES], vreg[PASSES];
-  // slot indices run one tile ahead of the row gathers: the dependent req_to_token -> row chain is
-  // then never waited for inside the loop (the wave is in-order: a wait on a fresh index load at
-  // the top of an iteration stalled the whole tile's compute behind an L2/HBM round trip)
-  int slot_next[PASSES];
-  auto fetch_slots = [&](int tile) {
+  // Two register sets of gathered rows, two tiles in flight: set X holds tile t+1 while tile t is
+  // consumed from LDS and set Y is being filled with tile t+2 (in-kernel stamps showed a gather that
+  // is issued one tile ahead still waited for ~3,300 cycles per tile: the 32 workgroups of an XCD
+  // walk the same keys in step, so every tile's first touch is an HBM miss for all of them at once).
+  // Slot indices of a set's NEXT tile are fetched right after its gathers are issued, so the
+  // dependent req_to_token -> row chain is never waited for inside the loop.
+  struct RegSet {
+    raw_t k[PASSES], v[PASSES];
+    int slot[PASSES];
+  };
+  RegSet setA, setB;
+  auto fetch_slots = [&](RegSet& r, int tile) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
+      // rows past the end re-read the last valid key (masked in the softmax; real, finite K/V so a
+      // zero probability times its V row is zero).  No conditional load and no select on the loaded
+      // value: a load the wave may skip makes the compiler's count of outstanding loads ambiguous
+      // (every later wait degrades to vmcnt(0), which also waits for the youngest gathers), and a
+      // select on the index is scheduled at the END of the iteration that issued the load.
       const int key = tile * BN + p * RPP + st_row;
-      slot_next[p] = key < kv_len ? idx_row[key] : 0;   // rows past the end read the dummy slot 0
+      r.slot[p] = idx_row[max(min(key, kv_len - 1), 0)];
     }
   };
-  auto prefetch = [&](int tile) {   // gathers of `tile` from slot_next, then the indices of tile+1
+  auto prefetch = [&](RegSet& r, int tile) __attribute__((always_inline)) {   // gathers of `tile` from r.slot, then the indices of tile+2
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
-      const int64_t off = (int64_t)slot_next[p] * tok_bytes + head_off;
-      kreg[p] = *(const raw_t*)(a.kbuf + off);
-      vreg[p] = *(const raw_t*)(a.vbuf + off);
+      const int64_t off = (int64_t)r.slot[p] * tok_bytes + head_off;
+      r.k[p] = *(const raw_t*)(a.kbuf + off);
+      r.v[p] = *(const raw_t*)(a.vbuf + off);
     }
-    fetch_slots(tile + 1);
+    fetch_slots(r, tile + 2);
   };
-  auto stage = [&](int buf) {
+  auto stage = [&](const RegSet& r, int buf) __attribute__((always_inline)) {
     char* dK = lds + buf * C::kTileBytes;
     char* dV = dK + BN * SK;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int row = p * RPP + st_row;
       if constexpr (KV8) {
-        st16(dK + row * SK + st_ch * 16, expand_e5m2x8(kreg[p]));
-        st16(dV + row * SV + st_ch * 16, expand_e5m2x8(vreg[p]));
+        st16(dK + row * SK + st_ch * 16, expand_e5m2x8(r.k[p]));
+        st16(dV + row * SV + st_ch * 16, expand_e5m2x8(r.v[p]));
       } else {
-        st16(dK + row * SK + st_ch * 16, kreg[p]);
-        st16(dV + row * SV + st_ch * 16, vreg[p]);
+        st16(dK + row * SK + st_ch * 16, r.k[p]);
+        st16(dV + row * SV + st_ch * 16, r.v[p]);
       }
     }
   };
@@ -232,121 +272,177 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
   const int i16 = lane & 15, g16 = lane >> 4;
   const int tr_rowq = i16 >> 2, tr_col = ((g16 & 1) * 16 + (i16 & 3) * 4) * 2;  // bytes
 
-  // pipeline: tile t+1's global gathers fly during compute(t); they are written to the OTHER LDS
-  // buffer right after compute(t), and one barrier per tile both publishes tile t+1 and retires
-  // every wave's reads of tile t (whose buffer is overwritten only in iteration t+1)
-  fetch_slots(tbeg);
-  prefetch(tbeg);
-  stage(tbeg & 1);
-  __syncthreads();
-  for (int t = tbeg; t < ntiles; ++t) {
-    if (t + 1 < ntiles) prefetch(t + 1);
-    const char* ldsK = lds + (t & 1) * C::kTileBytes;
-    const char* ldsV = ldsK + BN * SK;
+  // pipeline: the gathers of tiles t+1 and t+2 fly during compute(t); tile t+1 is written to the other
+  // LDS buffer right after compute(t), and one barrier per tile both publishes tile t+1 and retires
+  // every wave's reads of the buffer that tile t+2 will overwrite.
+#ifdef SP_EXTEND_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0;
+#endif
+  // S^T, mask, online softmax of tile t from LDS buffer `buf`; leaves P^T packed in pf (B operands of
+  // the four 16-key k-steps).  Returns false when the wave has no visible key in the tile.
+  auto qk_softmax = [&](int t, int buf, u32x4 (&pf)[4]) __attribute__((always_inline)) -> bool {
+    const char* ldsK = lds + buf * C::kTileBytes;
     const int key0 = t * BN;
     // a wave skips tiles that lie entirely above its rows' diagonal (wave-uniform)
     const bool visible = wave_live && (!a.causal || key0 <= P + min(r0 + 31, E - 1)) &&
                          (!windowed || key0 + BN - 1 >= P + r0 - a.window);
-    if (visible) {
-      // ---- S^T = K . Q^T for the two 32-key blocks of the tile
-      f32x16 s[2];
+    if (!visible) return false;
+    // ---- S^T = K . Q^T for the two 32-key blocks of the tile
+    f32x16 s[2];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-        const char* kp = ldsK + (kb * 32 + c) * SK + h * 16;
-        // all fragment reads of the block are issued before its first MFMA (distinct registers), so
-        // one LDS latency is exposed per block instead of one per MFMA
-        u32x4 kf[KSTEPS];
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+      const char* kp = ldsK + (kb * 32 + c) * SK + h * 16;
+      // all fragment reads of the block are issued before its first MFMA (distinct registers), so
+      // one LDS latency is exposed per block instead of one per MFMA; the sched_barrier keeps the
+      // scheduler from sinking each read next to its MFMA again (it then reuses one register quad
+      // and waits lgkmcnt(0) before every MFMA)
+      u32x4 kf[KSTEPS];
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) kf[ks] = ld16(kp + ks * 32);
-        // keep the scheduler from sinking each read next to its MFMA again (it then reuses one
-        // register quad and waits lgkmcnt(0) before every MFMA)
-        __builtin_amdgcn_sched_barrier(0);
+      for (int ks = 0; ks < KSTEPS; ++ks) kf[ks] = ld16(kp + ks * 32);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) s[kb] = mfma32<CT>(kf[ks], qf[ks], s[kb]);
-      }
-      // ---- mask (edge tiles only), online softmax (query row on the lane; keys in registers + lane^32)
-      if constexpr (!PLAIN) {
-        if (cap > 0.f) {   // wave-uniform: rewrite the scores as cap * tanh(s * scale / cap) in log2 units
-          const float pre = a.sm_scale / cap, post = cap * kLog2eX;
-#pragma unroll
-          for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = post * tanhf(s[kb][r] * pre);
-        }
-      }
-      // interior tiles (entirely below every row's diagonal and inside the key range) need no mask
-      const bool need_mask = key0 + BN > kv_len || (a.causal && key0 + BN - 1 > P + r0) ||
-                             (windowed && key0 < P + min(r0 + 31, E - 1) - a.window);
-      if (need_mask) {
+      for (int ks = 0; ks < KSTEPS; ++ks) s[kb] = mfma32<CT>(kf[ks], qf[ks], s[kb]);
+    }
+    SP_STAMP(ts2);
+    // ---- mask (edge tiles only), online softmax (query row on the lane; keys in registers + lane^32)
+    if constexpr (!PLAIN) {
+      if (cap > 0.f) {   // wave-uniform: rewrite the scores as cap * tanh(s * scale / cap) in log2 units
+        const float pre = a.sm_scale / cap, post = cap * kLog2eX;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const bool vis = key < kv_len && key <= row_limit && (PLAIN || key >= row_first);
-            s[kb][r] = vis ? s[kb][r] : -INFINITY;
-          }
+          for (int r = 0; r < 16; ++r) s[kb][r] = post * tanhf(s[kb][r] * pre);
       }
-      float mx = fmaxf(s[0][0], s[1][0]);
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
-      mx = fmaxf(mx, xchg32(mx));
-      const float m_cand = mx * sc;               // sc > 0: the maximum commutes with the scale
-      if (__any(m_cand > m_run + kDeferLog2)) {   // rare once the row maxima have settled
-        const float m_new = fmaxf(m_run, m_cand);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        l_part *= alpha;
-#pragma unroll
-        for (int db = 0; db < DBLK; ++db)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-      }
-      float psum = 0.f;
+    }
+    // interior tiles (entirely below every row's diagonal and inside the key range) need no mask
+    const bool need_mask = key0 + BN > kv_len || (a.causal && key0 + BN - 1 > P + r0) ||
+                           (windowed && key0 < P + min(r0 + 31, E - 1) - a.window);
+    if (need_mask) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], sc, -m_run));
-          s[kb][r] = p;
-          psum += p;
+          const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const bool vis = key < kv_len && key <= row_limit && (PLAIN || key >= row_first);
+          s[kb][r] = vis ? s[kb][r] : -INFINITY;
         }
-      l_part += psum;
-      // ---- O^T += V^T . P^T
+    }
+    float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
+    mx = fmaxf(mx, xchg32(mx));
+    const float m_cand = mx * sc;               // sc > 0: the maximum commutes with the scale
+    if (__any(m_cand > m_run + a.defer)) {      // rare once the row maxima have settled
+      const float m_new = fmaxf(m_run, m_cand);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_part *= alpha;
 #pragma unroll
-        for (int sidx = 0; sidx < 2; ++sidx) {
-          // V^T fragments of one 16-key k-step (DBLK d-blocks, two transposed reads each)
-          u32x4 vf[DBLK];
-          const int keyA = kb * 32 + 16 * sidx + 4 * h + tr_rowq;       // rows for elements 0..3
-          const char* vp = ldsV + keyA * SV + tr_col;
+      for (int db = 0; db < DBLK; ++db)
 #pragma unroll
-          for (int db = 0; db < DBLK; ++db) {
-            const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4_t*)(vp + db * 64));
-            const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4_t*)(vp + 8 * SV + db * 64));
-            const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
-            vf[db][0] = lo2[0];
-            vf[db][1] = lo2[1];
-            vf[db][2] = hi2[0];
-            vf[db][3] = hi2[1];
-          }
-          u32x4 pf;  // B operand: registers 8s..8s+7 of the S^T block, rounded to the KV dtype
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+    }
+    float psum = 0.f;
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            pf[j] = pack2<CT>(s[kb][8 * sidx + 2 * j], s[kb][8 * sidx + 2 * j + 1]);
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-          for (int db = 0; db < DBLK; ++db) oacc[db] = mfma32<CT>(vf[db], pf, oacc[db]);
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], sc, -m_run));
+        s[kb][r] = p;
+        psum += p;
+      }
+    l_part += psum;
+    // B operands of O^T += V^T . P^T: registers 8s..8s+7 of an S^T block, rounded to the KV dtype
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          pf[kb * 2 + sidx][j] = pack2<CT>(s[kb][8 * sidx + 2 * j], s[kb][8 * sidx + 2 * j + 1]);
+    SP_STAMP(ts3);
+    return true;
+  };
+  // ---- O^T += V^T . P^T with the V tile of LDS buffer `buf`
+  auto pv = [&](int buf, const u32x4 (&pf)[4]) __attribute__((always_inline)) {
+    const char* ldsV = lds + buf * C::kTileBytes + BN * SK;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        // V^T fragments of one 16-key k-step (DBLK d-blocks, two transposed reads each)
+        u32x4 vf[DBLK];
+        const int keyA = kb * 32 + 16 * sidx + 4 * h + tr_rowq;       // rows for elements 0..3
+        const char* vp = ldsV + keyA * SV + tr_col;
+#pragma unroll
+        for (int db = 0; db < DBLK; ++db) {
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(vp + db * 64));
+          const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(vp + 8 * SV + db * 64));
+          const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
+          vf[db][0] = lo2[0];
+          vf[db][1] = lo2[1];
+          vf[db][2] = hi2[0];
+          vf[db][3] = hi2[1];
         }
+#pragma unroll
+        for (int db = 0; db < DBLK; ++db) oacc[db] = mfma32<CT>(vf[db], pf[kb * 2 + sidx], oacc[db]);
       }
     }
-    if (t + 1 < ntiles) stage((t + 1) & 1);
+  };
+
+  fetch_slots(setA, tbeg);
+  fetch_slots(setB, tbeg + 1);
+  prefetch(setA, tbeg);
+  prefetch(setB, tbeg + 1);
+  stage(setA, tbeg & 1);
+  __syncthreads();
+  // one tile: `fill` is the free register set (it receives tile t+2), `next` holds tile t+1
+  auto tile_step = [&](int t, RegSet& fill, const RegSet& next) __attribute__((always_inline)) {
+    SP_STAMP(ts0);
+    // unconditional, also past the last tile (rows of the last valid key, never consumed): see fetch_slots
+    prefetch(fill, t + 2);
+    SP_STAMP(ts1);
+    u32x4 pf[4];
+    const bool visible = qk_softmax(t, t & 1, pf);
+    if (visible) pv(t & 1, pf);
+#ifdef SP_EXTEND_STAMPS
+    if (!visible) ts2 = ts3 = ts1;
+#endif
+    SP_STAMP(ts4);
+    stage(next, (t + 1) & 1);   // past the last tile: dummy rows into the buffer nobody reads again
+    SP_STAMP(ts5);
     __syncthreads();
+    SP_STAMP(ts6);
+    SP_STAMP_ACC(0, ts0, ts1);   // issue of the next tile's gathers (+ wait for its slot indices)
+    SP_STAMP_ACC(1, ts1, ts2);   // K fragment reads + S^T MFMAs (issue)
+    SP_STAMP_ACC(2, ts2, ts3);   // softmax (starts by waiting for the S^T results)
+    SP_STAMP_ACC(3, ts3, ts4);   // V^T reads + O^T MFMAs (issue)
+    SP_STAMP_ACC(4, ts4, ts5);   // wait for the gathers + LDS writes
+    SP_STAMP_ACC(5, ts5, ts6);   // barrier
+#ifdef SP_EXTEND_STAMPS
+    stamp_sum[6] += visible ? 1 : 0;
+    stamp_sum[7] += 1;
+#endif
+  };
+  // whole pairs in the loop, an odd last tile after it: with the second step under a condition the
+  // compiler sees a path from the first step straight to the loop head, where set A's indices would
+  // be the youngest loads, and waits vmcnt(0) at the top of EVERY iteration
+  int t = tbeg;
+  for (; t + 1 < ntiles; t += 2) {
+    tile_step(t, setA, setB);
+    tile_step(t + 1, setB, setA);
   }
+  if (t < ntiles) tile_step(t, setA, setB);
+#ifdef SP_EXTEND_STAMPS
+  if (lane == 0 && g_stamp_buf) {
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_stamp_buf[i], stamp_sum[i]);
+  }
+#endif
 
   // ---- epilogue: O[row][head][d] = O^T[d][row] / l ; lane holds 4 consecutive d per register quad
   const float l_run = l_part + xchg32(l_part);
@@ -366,19 +462,47 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
   }
 }
 
-// test / tuning hook (set through sp_debug_set, never read from the environment on the hot path):
-// waves per workgroup of the extend kernel, 0 = the shipped choice
-static int g_extend_waves = 0;
-void set_extend_waves(int nw) { g_extend_waves = nw; }
+// test hook (set through sp_debug_set, never read from the environment on the call path): how far the
+// running maximum may trail (log2 units); < 0 restores the shipped value.  tests compare 0 (rescale at
+// every growth of a row maximum) with the shipped threshold.
+static float g_extend_defer = kDeferLog2;
+void set_extend_defer_x10(int tenths) { g_extend_defer = tenths < 0 ? kDeferLog2 : 0.1f * tenths; }
+#ifdef SP_EXTEND_STAMPS
+void set_extend_stamp_buffer(void* p) {
+  unsigned long long* q = (unsigned long long*)p;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &q, sizeof(q));
+}
+#endif
 
-template <typename Tag, int D, int GK, int NW>
+constexpr int kExtendWaves = 8;
+
+// row blocks per workgroup tile for a query-head group of width G (any G: Gk = the largest of 4, 2, 1
+// that divides it; the remaining G / Gk head blocks become extra workgroups)
+static int extend_gk(int G) { return G % 4 == 0 ? 4 : (G % 2 == 0 ? 2 : 1); }
+int extend_block_rows(int num_q_heads, int num_kv_heads) {
+  return 32 * (kExtendWaves / extend_gk(num_q_heads / num_kv_heads));
+}
+
+template <typename Tag, int D, int GK>
 static int launch_extend(const ExtendArgs& a, int max_extend_len, int halves, hipStream_t st) {
+  constexpr int NW = kExtendWaves;
   typedef ExtCfg<D, NW * 64> C;
   constexpr int BM = 32 * (NW / GK);
-  const dim3 grid(a.Hkv * halves, (max_extend_len + BM - 1) / BM, a.bs);
+  constexpr int kLds = 2 * C::kTileBytes;
+  // with a plan: one grid row per (request, row block) item, heaviest first; without: every
+  // request x every possible row block (workgroups past a request's end exit at once)
+  const dim3 grid(a.Hkv * halves, a.plan ? a.plan_items : (max_extend_len + BM - 1) / BM, a.plan ? 1 : a.bs);
   const bool plain = !(a.logit_cap > 0.f) && a.window < 0;
-#define SP_EXT_LAUNCH(KV8_, PLAIN_) \
-  extend_mfma_kernel<Tag, D, GK, NW, KV8_, PLAIN_><<<grid, NW * 64, C::kLdsBytes, st>>>(a)
+#define SP_EXT_LAUNCH(KV8_, PLAIN_)                                                            \
+  do {                                                                                         \
+    static bool attr_set = false; /* benign race: idempotent */                                \
+    if (!attr_set && kLds > 64 * 1024) {                                                       \
+      (void)hipFuncSetAttribute((const void*)extend_mfma_kernel<Tag, D, GK, NW, KV8_, PLAIN_>, \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLds);             \
+      attr_set = true;                                                                         \
+    }                                                                                          \
+    extend_mfma_kernel<Tag, D, GK, NW, KV8_, PLAIN_><<<grid, NW * 64, kLds, st>>>(a);          \
+  } while (0)
   if (a.kv8) {
     if (plain) SP_EXT_LAUNCH(true, true); else SP_EXT_LAUNCH(true, false);
   } else {
@@ -391,20 +515,10 @@ static int launch_extend(const ExtendArgs& a, int max_extend_len, int halves, hi
 
 template <typename Tag, int D>
 static int dispatch_extend_group(const ExtendArgs& a, int G, int max_extend_len, hipStream_t st) {
-  // a workgroup's waves take Gk = 4, 2 or 1 query heads of the KV head (the largest that divides G)
-  // and the remaining G / Gk head blocks become extra workgroups: any group width works
   if (G < 1 || G > 64) return SP_ERR_UNSUPPORTED;
-  const bool w4 = g_extend_waves == 4;
-  if (G % 4 == 0) {
-    return w4 ? launch_extend<Tag, D, 4, 4>(a, max_extend_len, G / 4, st)
-              : launch_extend<Tag, D, 4, 8>(a, max_extend_len, G / 4, st);
-  }
-  if (G % 2 == 0) {
-    return w4 ? launch_extend<Tag, D, 2, 4>(a, max_extend_len, G / 2, st)
-              : launch_extend<Tag, D, 2, 8>(a, max_extend_len, G / 2, st);
-  }
-  return w4 ? launch_extend<Tag, D, 1, 4>(a, max_extend_len, G, st)
-            : launch_extend<Tag, D, 1, 8>(a, max_extend_len, G, st);
+  if (G % 4 == 0) return launch_extend<Tag, D, 4>(a, max_extend_len, G / 4, st);
+  if (G % 2 == 0) return launch_extend<Tag, D, 2>(a, max_extend_len, G / 2, st);
+  return launch_extend<Tag, D, 1>(a, max_extend_len, G, st);
 }
 
 // 16-bit dtypes, D in {64,128}; anything else returns SP_ERR_UNSUPPORTED and the caller takes the
@@ -415,8 +529,8 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
                     int idx64, const int32_t* extend_seq_lens, const int32_t* extend_start_loc,
                     int batch_size, int num_q_heads, int num_kv_heads, int head_dim, int64_t q_stride,
                     int64_t out_stride, int64_t kv_buffer_stride, float sm_scale, float logit_cap,
-                    float out_scale, int causal, int window_left, int max_extend_len, int dtype, int kv8,
-                    hipStream_t st) {
+                    float out_scale, int causal, int window_left, int max_extend_len, const int32_t* plan,
+                    int plan_items, int dtype, int kv8, hipStream_t st) {
   if (dtype != SP_F16 && dtype != SP_BF16) return SP_ERR_UNSUPPORTED;
   if (head_dim != 64 && head_dim != 128) return SP_ERR_UNSUPPORTED;
   if (batch_size > 65535 || num_q_heads > 65535) return SP_ERR_UNSUPPORTED;   // grid.z, grid.y
@@ -432,14 +546,23 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
   a.sm_scale = sm_scale; a.logit_cap = logit_cap; a.out_scale = out_scale; a.causal = causal;
   a.window = causal ? window_left : -1;
   a.kv8 = kv8;
+  a.defer = g_extend_defer;
+  a.plan = plan; a.plan_items = plan_items;
+  if (plan && (plan_items <= 0 || plan_items > 65535)) a.plan = nullptr;   // grid.y limit: unplanned launch
   const int G = num_q_heads / num_kv_heads;
   if (max_extend_len <= 0) return SP_OK;
+#ifdef SP_EXTEND_ONLY_HEADLINE   // ISA experiments only: one instantiation family, seconds to compile
+  if (dtype == SP_BF16 && head_dim == 128 && G % 4 == 0)
+    return launch_extend<bf16_tag, 128, 4>(a, max_extend_len, G / 4, st);
+  return SP_ERR_UNSUPPORTED;
+#else
   if (dtype == SP_BF16) {
     return head_dim == 128 ? dispatch_extend_group<bf16_tag, 128>(a, G, max_extend_len, st)
                            : dispatch_extend_group<bf16_tag, 64>(a, G, max_extend_len, st);
   }
   return head_dim == 128 ? dispatch_extend_group<f16_tag, 128>(a, G, max_extend_len, st)
                          : dispatch_extend_group<f16_tag, 64>(a, G, max_extend_len, st);
+#endif
 }
 
 }  // namespace sp

@@ -311,6 +311,58 @@ __global__ __launch_bounds__(kSampThreads) void argmax_kernel(const void* __rest
   }
 }
 
+// ---- vocab-parallel greedy: every rank reduces its own vocab shard to one (value, global index)
+// pair per row, the pairs ([bs, 2] words per rank instead of [bs, vocab / tp] logits) are
+// all-gathered, and the merge picks the maximum with the lowest global index - the token
+// torch.argmax would return on the gathered row (logits_processor.py:362-369 + sampler.py:63-65).
+template <typename Tag>
+__global__ __launch_bounds__(kSampThreads) void argmax_shard_kernel(const void* __restrict__ logits,
+                                                                    int64_t row_stride, int cols,
+                                                                    int index_offset,
+                                                                    int32_t* __restrict__ pairs) {
+  __shared__ float s_val[kSampWaves];
+  __shared__ int s_idx[kSampWaves];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t base = (int64_t)b * row_stride;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int i = tid; i < cols; i += kSampThreads) {
+    const float v = Elem<Tag>::load(logits, base + i);
+    if (v > best || idx == 0x7fffffff) { best = v; idx = i; }
+  }
+  auto better = [](float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); };
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(best, off, 64);
+    const int oi = __shfl_xor(idx, off, 64);
+    if (better(ov, oi, best, idx)) { best = ov; idx = oi; }
+  }
+  if (lane == 0) { s_val[wave] = best; s_idx[wave] = idx; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < kSampWaves; ++w)
+      if (better(s_val[w], s_idx[w], best, idx)) { best = s_val[w]; idx = s_idx[w]; }
+    // an empty shard (cols == 0: every column of this rank is vocabulary padding) never wins
+    pairs[2 * b] = (int32_t)as_u32(idx == 0x7fffffff ? -INFINITY : best);
+    pairs[2 * b + 1] = idx == 0x7fffffff ? 0x7fffffff : idx + index_offset;
+  }
+}
+
+// pairs: [shards][bs][2]; one thread per row
+__global__ __launch_bounds__(256) void argmax_merge_kernel(const int32_t* __restrict__ pairs, int shards,
+                                                           int bs, int64_t* __restrict__ out) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= bs) return;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int r = 0; r < shards; ++r) {
+    const float v = as_f32((uint32_t)pairs[((int64_t)r * bs + b) * 2]);
+    const int i = pairs[((int64_t)r * bs + b) * 2 + 1];
+    if (v > best || (v == best && i < idx) || idx == 0x7fffffff) { best = v; idx = i; }
+  }
+  out[b] = idx == 0x7fffffff ? 0 : idx;
+}
+
 // ---- probs = softmax(logits / T) in place, fp32 (sampler.py:71-73) ---------------------------
 __global__ __launch_bounds__(kSampThreads) void softmax_temperature_kernel(float* __restrict__ x, int64_t row_stride,
                                                                           const float* __restrict__ temps, int vocab) {
@@ -349,6 +401,29 @@ extern "C" int sp_argmax(const void* logits, int64_t row_stride, int batch_size,
   SP_CHECK_ARG(logits && out_ids && row_stride >= vocab);
   SP_DISPATCH_DTYPE(dtype, (sp::argmax_kernel<Tag><<<dim3(batch_size), sp::kSampThreads, 0, (hipStream_t)stream>>>(
                                logits, row_stride, vocab, out_ids)));
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
+extern "C" int sp_argmax_shard(const void* logits, int64_t row_stride, int batch_size, int cols, int index_offset,
+                               int32_t* out_pairs, int dtype, void* stream) {
+  SP_CHECK_ARG(batch_size >= 0 && cols >= 0 && index_offset >= 0);
+  if (batch_size == 0) return SP_OK;
+  SP_CHECK_ARG(logits && out_pairs && row_stride >= cols);
+  SP_DISPATCH_DTYPE(dtype, (sp::argmax_shard_kernel<Tag><<<dim3(batch_size), sp::kSampThreads, 0,
+                                                          (hipStream_t)stream>>>(logits, row_stride, cols,
+                                                                                 index_offset, out_pairs)));
+  SP_LAUNCH_CHECK();
+  return SP_OK;
+}
+
+extern "C" int sp_argmax_merge(const int32_t* pairs, int num_shards, int batch_size, int64_t* out_ids,
+                               void* stream) {
+  SP_CHECK_ARG(batch_size >= 0 && num_shards > 0);
+  if (batch_size == 0) return SP_OK;
+  SP_CHECK_ARG(pairs && out_ids);
+  sp::argmax_merge_kernel<<<dim3((batch_size + 255) / 256), 256, 0, (hipStream_t)stream>>>(pairs, num_shards,
+                                                                                            batch_size, out_ids);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

@@ -10,7 +10,6 @@ RowParallelLinear + all-reduce (1033-1155), VocabParallelEmbedding + all-reduce
 (nn/layers/logits_processor.py:179-203, 344-376).  GEMMs stay on torch (hipBLASLt/rocBLAS):
 they are outside the path this package re-kernels.
 """
-from dataclasses import dataclass
 from typing import Any, Dict, Iterable, Optional, Tuple
 
 import torch
@@ -26,10 +25,57 @@ from .forward_info import ForwardBatch
 from .layers import RMSNorm, SiluAndMul, get_rope
 
 
-@dataclass
 class LogitsProcessorOutput:
-    next_token_logits: torch.Tensor
-    hidden_states: Optional[torch.Tensor] = None
+    """nn/layers/logits_processor.py LogitsProcessorOutput.  ``next_token_logits`` ([bs, vocab] fp32,
+    all-gathered over the TP group, padding columns cut: logits_processor.py:362-369) is what the
+    reference's callers read; here the forward leaves only this rank's vocab shard in the model dtype
+    (``shard_logits``) and the full fp32 matrix is built the first time somebody asks for it - the
+    sampler of a non-greedy batch, logprobs, tests.  A greedy batch never does (``greedy_token_ids``):
+    under TP it exchanges one (value, index) pair per row instead of [bs, vocab / tp] logits, and at
+    TP = 1 it skips the fp32 copy of the logits (131 MB at bs 256)."""
+
+    def __init__(self, next_token_logits: Optional[torch.Tensor] = None,
+                 hidden_states: Optional[torch.Tensor] = None,
+                 shard_logits: Optional[torch.Tensor] = None, vocab_size: Optional[int] = None,
+                 shard_offset: int = 0):
+        self._full = next_token_logits
+        self.hidden_states = hidden_states
+        self.shard_logits = shard_logits
+        self.vocab_size = vocab_size
+        self.shard_offset = shard_offset
+
+    @property
+    def next_token_logits(self) -> Optional[torch.Tensor]:
+        if self._full is None and self.shard_logits is not None:
+            logits = self.shard_logits
+            if get_tensor_model_parallel_world_size() > 1:
+                logits = tensor_model_parallel_all_gather(logits)
+            self._full = logits[:, : self.vocab_size].float()
+        return self._full
+
+    @next_token_logits.setter
+    def next_token_logits(self, value: Optional[torch.Tensor]) -> None:
+        self._full = value
+
+    def rows(self, n: int) -> "LogitsProcessorOutput":
+        """The first n rows (graph replay hands back the live rows of a padded bucket)."""
+        return LogitsProcessorOutput(
+            None if self._full is None else self._full[:n],
+            None if self.hidden_states is None else self.hidden_states[:n],
+            None if self.shard_logits is None else self.shard_logits[:n], self.vocab_size, self.shard_offset)
+
+    def greedy_token_ids(self) -> torch.Tensor:
+        """torch.argmax(next_token_logits, -1) (sampler.py:63-65) without materialising it."""
+        if self._full is not None or self.shard_logits is None:
+            return _native.argmax(self._full)
+        shard = self.shard_logits
+        cols = max(0, min(shard.shape[1], self.vocab_size - self.shard_offset))   # padding columns never win
+        tp = get_tensor_model_parallel_world_size()
+        if tp == 1:
+            return _native.argmax(shard[:, :cols])
+        pairs = _native.argmax_shard(shard, cols, self.shard_offset)
+        gathered = tensor_model_parallel_all_gather(pairs, dim=0)                 # rank-major [tp * bs, 2]
+        return _native.argmax_merge(gathered.view(tp, shard.shape[0], 2))
 
 
 # --------------------------------------------------------------------------- sharded linears
@@ -161,7 +207,8 @@ class ParallelLMHead(VocabParallelEmbedding):
 
 class LogitsProcessor(nn.Module):
     """logits_processor.py:140-376 for the greedy/throughput path: keep the last token of every
-    sequence on extend, matmul with the (vocab-sharded) head, all-gather, slice, fp32."""
+    sequence on extend, matmul with the (vocab-sharded) head.  The all-gather / slice / fp32 step of
+    _get_logits (362-369) is deferred to LogitsProcessorOutput (a greedy batch never needs it)."""
 
     def __init__(self, config):
         super().__init__()
@@ -175,10 +222,8 @@ class LogitsProcessor(nn.Module):
             last_index = torch.cumsum(forward_batch.extend_seq_lens, dim=0) - 1
             pruned = hidden_states[last_index]
         logits = _native.linear(pruned.to(lm_head.weight.dtype), lm_head.weight)
-        if self.do_tensor_parallel_all_gather:
-            logits = tensor_model_parallel_all_gather(logits)
-        logits = logits[:, : self.config.vocab_size].float()
-        return LogitsProcessorOutput(next_token_logits=logits)
+        return LogitsProcessorOutput(shard_logits=logits, vocab_size=self.config.vocab_size,
+                                     shard_offset=getattr(lm_head, "vocab_start_index", 0))
 
 
 # --------------------------------------------------------------------------- decoder

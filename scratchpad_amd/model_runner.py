@@ -237,7 +237,7 @@ class ModelRunner:
         greedy (sampler.py:63-67)."""
         info = forward_batch.sampling_info
         if info is None:
-            return _native.argmax(logits_output.next_token_logits)
+            return logits_output.greedy_token_ids()
         return self.sampler(logits_output, info)
 
 
@@ -349,8 +349,7 @@ class HipGraphRunner:
             forward_batch.seq_lens_sum + (bs - raw_bs) * self.seq_len_fill_value, self.encoder_lens,
             ForwardMode.DECODE, None, forward_batch.seq_lens_cpu)
         self.graphs[bs].replay()
-        out = self.output_buffers[bs]
-        return LogitsProcessorOutput(next_token_logits=out.next_token_logits[:raw_bs])
+        return self.output_buffers[bs].rows(raw_bs)
 
 
 class TpModelWorker:

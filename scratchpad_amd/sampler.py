@@ -151,6 +151,13 @@ class Sampler(nn.Module):
                 top_logprobs_nums: Optional[List[int]] = None,
                 token_ids_logprobs: Optional[List[Optional[List[int]]]] = None,
                 uniform: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if sampling_info.is_all_greedy and not return_logprob and not self.use_nan_detection \
+                and hasattr(logits_output, "greedy_token_ids"):
+            # vocab-parallel greedy: no [bs, vocab] gather, no fp32 copy (LogitsProcessorOutput)
+            ids = logits_output.greedy_token_ids()
+            if sampling_info.grammars:
+                self.sync_token_ids_across_tp(ids)
+            return ids
         logits = logits_output.next_token_logits
         if self.use_nan_detection and torch.any(torch.isnan(logits)):
             logits = torch.where(torch.isnan(logits), torch.full_like(logits, -1e5), logits)

@@ -203,22 +203,27 @@ class ScheduleBatch:
         """schedule_batch.py:1213-1215"""
         self.encoder_cached = [True] * len(self.reqs)
 
-    def mix_with_running(self, running_batch: "ScheduleBatch"):
-        """Chunked prefill + running decodes in one extend batch: the decode rows become
-        extend rows of length 1 (schedule_batch.py:1073-1101)."""
+    def mix_with_running(self, running_batch: "ScheduleBatch", enable_overlap: bool = False):
+        """Chunked prefill + running decodes in one extend batch: the decode rows become extend rows
+        of length 1 (schedule_batch.py:1073-1101).  Everything per-request that lives on the batch -
+        sampling parameters, encoder lengths, pending output ids - is merged through ``merge_batch``
+        exactly as the reference does; only input_ids / out_cache_loc are the concatenations built
+        here (merge_batch resets out_cache_loc)."""
         self.forward_mode = ForwardMode.MIXED
         running_bs = running_batch.batch_size()
+        for req in running_batch.reqs:
+            req.fill_ids = req.origin_input_ids + req.output_ids
         input_ids = torch.cat([self.input_ids, running_batch.input_ids])
         out_cache_loc = torch.cat([self.out_cache_loc, running_batch.out_cache_loc])
-        self.reqs = self.reqs + running_batch.reqs
-        self.req_pool_indices = torch.cat([self.req_pool_indices, running_batch.req_pool_indices])
-        self.seq_lens = torch.cat([self.seq_lens, running_batch.seq_lens])
-        self.seq_lens_sum += running_batch.seq_lens_sum
+        self.merge_batch(running_batch)
         self.input_ids = input_ids
         self.out_cache_loc = out_cache_loc
-        self.extend_num_tokens += running_bs
-        self.prefix_lens = self.prefix_lens + [len(r.fill_ids) - 1 for r in running_batch.reqs]
+        # with the overlap scheduler output_ids lags one step behind (schedule_batch.py:1088-1089)
+        delta = 0 if enable_overlap else -1
+        self.prefix_lens = self.prefix_lens + [len(r.origin_input_ids) + len(r.output_ids) + delta
+                                               for r in running_batch.reqs]
         self.extend_lens = self.extend_lens + [1] * running_bs
+        self.extend_num_tokens += running_bs
 
     def prepare_for_decode(self):
         self.forward_mode = ForwardMode.DECODE
@@ -301,9 +306,16 @@ class ScheduleBatch:
             self.sampling_info.filter_batch(keep_indices, keep)
 
     def merge_batch(self, other: "ScheduleBatch"):
-        """schedule_batch.py:1361-1397"""
-        if self.sampling_info is not None and other.sampling_info is not None:
-            self.sampling_info.merge_batch(other.sampling_info)
+        """schedule_batch.py:1361-1397.  The reference always carries a SamplingBatchInfo; here
+        ``None`` stands for "every request greedy", so a side without one is given its greedy rows
+        before the two are concatenated (row count must follow the merged request list)."""
+        if self.sampling_info is not None or other.sampling_info is not None:
+            from .sampler import SamplingBatchInfo
+            vocab = (self.sampling_info or other.sampling_info).vocab_size
+            mine = self.sampling_info or SamplingBatchInfo.from_schedule_batch(self, vocab)
+            theirs = other.sampling_info or SamplingBatchInfo.from_schedule_batch(other, vocab)
+            mine.merge_batch(theirs)
+            self.sampling_info = mine
         if self.is_encoder_decoder:
             self.encoder_lens = torch.cat([self.encoder_lens, other.encoder_lens])
             self.encoder_lens_cpu.extend(other.encoder_lens_cpu)
@@ -311,9 +323,9 @@ class ScheduleBatch:
         self.seq_lens = torch.cat([self.seq_lens, other.seq_lens])
         self.out_cache_loc = None
         self.seq_lens_sum += other.seq_lens_sum
-        if self.output_ids is not None:
+        if self.output_ids is not None and other.output_ids is not None:
             self.output_ids = torch.cat([self.output_ids, other.output_ids])
-        self.reqs.extend(other.reqs)
+        self.reqs = self.reqs + other.reqs
 
     def get_model_worker_batch(self) -> ModelWorkerBatch:
         global _bid

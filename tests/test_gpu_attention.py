@@ -213,13 +213,81 @@ def test_decode_rejects_bad_arguments(nat):
 
 # ----------------------------------------------------------------------------------- extend
 def run_extend(nat, q, kb, vb, r2t, req, seq, ext, start, scale, cap=0.0, causal=True, kv_start=None,
-               window_left=-1):
+               window_left=-1, plan=None):
     T_, Hq, D = q.shape
     ws = torch.empty(nat.extend_workspace_bytes(T_, len(seq), Hq, D, q.dtype), dtype=torch.uint8, device=DEV)
     o = torch.full_like(q, float("nan"))
     nat.extend_attention(o, q, kb, vb, r2t, req, seq, ext, start, scale, cap, causal,
-                         int(ext.max()), int(seq.max()), ws, kv_start, window_left=window_left)
+                         int(ext.max()), int(seq.max()), ws, kv_start, window_left=window_left, plan=plan)
     return o
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,rows", [(32, 8, 128, 64), (8, 1, 128, 64), (6, 3, 64, 128), (5, 5, 64, 256)])
+def test_extend_plan_lists_every_row_block_once_and_changes_nothing(nat, Hq, Hkv, D, rows):
+    """sp_extend_plan: every (request, row block) item exactly once; requests longest first, a
+    request's row blocks together and last rows first; and the kernel's output with the plan is
+    bit-identical to the unplanned launch (the plan only decides which workgroup computes which rows)."""
+    dtype = torch.bfloat16
+    pre = [0, 64, 300, 0, 5, 129, 0, 700]
+    ext = [130, 1, 70, 1, 257, 33, 512, 64]
+    p, q, ext_t, start = extend_problem(33, Hq, Hkv, D, pre, ext, dtype)
+    plan = nat.extend_plan(ext_t, p["seq_lens"], sum(ext), Hq, Hkv, True)
+    host = plan.cpu().tolist()
+    count, bm = host[0], host[1]
+    assert bm == rows
+    items = [(host[2 + 2 * i], host[3 + 2 * i]) for i in range(count)]
+    want = [(b, rb) for b, e in enumerate(ext) for rb in range((e + bm - 1) // bm)]
+    assert sorted(items) == sorted(want) and count == len(want)
+    order = []                                   # requests in plan order, each one's blocks contiguous
+    for b, rb in items:
+        if not order or order[-1][0] != b:
+            assert all(b != o[0] for o in order), "a request's row blocks stay together"
+            order.append((b, []))
+        order[-1][1].append(rb)
+    assert all(rbs == sorted(rbs, reverse=True) for _, rbs in order), "last rows first"
+    cls = [(pre[b] + ext[b] + 63) // 64 for b, _ in order]
+    assert cls == sorted(cls, reverse=True), "longest requests first"
+    args = (q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"], p["seq_lens"], ext_t, start,
+            D ** -0.5)
+    o_plain = run_extend(nat, *args)
+    o_plan = run_extend(nat, *args, plan=plan)
+    assert torch.isfinite(o_plan.float()).all() and torch.equal(o_plan, o_plain)
+    # a plan built for other head counts (another block size) is ignored, never half-applied
+    if rows != 64:
+        other = nat.extend_plan(ext_t, p["seq_lens"], sum(ext), 32, 8, True)
+        o_bad = run_extend(nat, *args, plan=other)
+        assert torch.isnan(o_bad.float()).all(), "mismatched plan: no workgroup writes"
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_extend_deferred_maximum_agrees_with_exact_running_maximum(nat, dt):
+    """The extend kernel advances its running row maximum only when a row's maximum grew by more than
+    2^6 (the O rescale becomes a rare branch).  Forcing the branch at every growth (threshold 0) and
+    with a spike that must trigger it late in the row gives the same result up to the rounding of P."""
+    dtype = DTYPES[dt]
+    Hq, Hkv, D = 8, 2, 128
+    pre, ext = [0, 300], [700, 257]
+    p, q, ext_t, start = extend_problem(52, Hq, Hkv, D, pre, ext, dtype)
+    # spike: one late key of request 0 matches one late query far better than anything before it
+    req0 = int(p["req_pool_indices"][0])
+    slot = int(p["req_to_token"][req0, 650])
+    p["k_buffer"][slot] = (q[660, :Hkv].float() * 3.0).to(dtype)
+    args = (q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"], p["seq_lens"], ext_t, start,
+            D ** -0.5)
+    try:
+        nat.debug_set("extend_defer_x10", 0)
+        o_exact = run_extend(nat, *args)
+        nat.debug_set("extend_defer_x10", 120)        # P up to 2^12 before a rescale is forced
+        o_never = run_extend(nat, *args)
+    finally:
+        nat.debug_set("extend_defer_x10", -1)
+    o_ship = run_extend(nat, *args)
+    c = cpu(p)
+    ref = ops.extend_attention(q.cpu().float(), c["k_buffer"].float(), c["v_buffer"].float(), c["req_to_token"],
+                               c["req_pool_indices"], c["seq_lens"], ext_t.cpu(), start.cpu(), D ** -0.5)
+    vmax = float(c["v_buffer"].float().abs().max())
+    for name, o in (("threshold 0", o_exact), ("shipped", o_ship), ("threshold 12", o_never)):
+        assert_close(o, ref, dtype, what=f"extend deferred max, {name}", vmax=vmax)
 
 
 @pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
@@ -329,7 +397,9 @@ def test_extend_sliding_window(nat, dt, window):
     ref = ops.extend_attention(q.cpu().float(), c["k_buffer"].float(), c["v_buffer"].float(),
                                c["req_to_token"], c["req_pool_indices"], c["seq_lens"], ext_t.cpu(),
                                start.cpu(), scale, window_left=window)
-    assert_close(o, ref, dtype, what=f"extend window {window}")
+    # few keys per row: one key can dominate, and its P (not exactly 1 under the deferred maximum)
+    # is rounded to the KV dtype like every other - the vmax allowance of assert_close
+    assert_close(o, ref, dtype, what=f"extend window {window}", vmax=float(c["v_buffer"].float().abs().max()))
     if window >= 4096:      # wider than every sequence: identical to no window at all
         full = run_extend(nat, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"],
                           p["seq_lens"], ext_t, start, scale)

@@ -73,6 +73,10 @@ def _rank_main(rank, world, port, case, q, custom_ar=False):
         assert out.next_token_logits.shape == ref.shape
         assert rel(out.next_token_logits, ref) <= 1e-4, ("prefill", rank, rel(out.next_token_logits, ref))
         assert torch.equal(nxt.cpu(), ref.argmax(-1))
+        # vocab-parallel greedy (one (value, index) pair per row exchanged) == argmax of the gathered logits
+        from scratchpad_amd import _native
+        assert out.shard_logits.shape[1] * world >= shape.vocab and out.shard_logits.shape[0] == 2
+        assert torch.equal(out.greedy_token_ids(), _native.argmax(out.next_token_logits))
         # decode step
         loc2 = torch.tensor([20, 21])
         table[0, 7] = 20
@@ -137,8 +141,33 @@ def _ar_main(rank, world, port, q):
                 assert all(torch.equal(gathered[0], t) for t in gathered), "every rank holds the same bits"
         big = torch.zeros(4 << 20, dtype=torch.float32, device="cuda")      # 16 MiB > max_bytes -> library path
         assert not ca.should_custom_ar(big) and ca.custom_all_reduce(big) is None
-        with ca.capture():
-            assert not ca.should_custom_ar(torch.zeros(64, device="cuda"))
+        # the launch carries no per-call argument (epoch counters are device state), so it can be captured
+        # into a HIP graph and replayed: every replay must still meet its peers at the right epoch
+        xs = torch.zeros(128, 8192, dtype=torch.bfloat16, device="cuda")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            d.tensor_model_parallel_all_reduce(xs)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with ca.capture(), torch.cuda.graph(graph):
+            ys = d.tensor_model_parallel_all_reduce(xs)
+            ys2 = d.tensor_model_parallel_all_reduce(ys)            # two dependent calls in one graph
+        for rep in range(4):
+            allx = torch.randn(world, 128, 8192, generator=gen).to(torch.bfloat16)
+            xs.copy_(allx[rank])
+            graph.replay()
+            torch.cuda.synchronize()
+            want = allx.float().sum(0)
+            err = (ys.float().cpu() - want).abs()
+            assert bool((err <= 2.0 ** -8 * want.abs() + 1e-5).all()), ("graph replay", rank, rep, float(err.max()))
+            assert torch.equal(ys2.float().cpu(), (ys.float().cpu() * world).to(torch.bfloat16).float())
+            y_eager = d.tensor_model_parallel_all_reduce(xs)        # eager calls interleave with replays
+            torch.cuda.synchronize()
+            assert torch.equal(y_eager, ys)
+        ca.check()                                                  # no barrier timed out
+        assert not ca.failed and ca.calls > 0
         torch.distributed.barrier()
         ca.close()
         q.put((rank, None))

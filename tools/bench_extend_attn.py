@@ -22,8 +22,9 @@ def main():
     ap.add_argument("--D", type=int, default=128)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--waves", default="0", help="comma list of sp_debug_set('extend_waves') values to time")
+    ap.add_argument("--waves", default="1,0", help="comma list: 1 = with the sp_extend_plan work list, 0 = without")
     ap.add_argument("--rounds", type=int, default=3, help="interleaved timing rounds per variant")
+    ap.add_argument("--defer-x10", type=int, default=-1, help="sp_debug_set('extend_defer_x10'): -1 = shipped")
     a = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
     dev = "cuda"
@@ -53,18 +54,21 @@ def main():
     start[1:] = torch.cumsum(ext_d[:-1], 0)
     ws = torch.empty(_native.extend_workspace_bytes(T, a.bs, a.Hq, a.D, dt), dtype=torch.uint8, device=dev)
     seq_d = seq.to(dev)
+    plan = _native.extend_plan(ext_d, seq_d, T, a.Hq, a.Hkv, True)
+    use_plan = [None]
     run = lambda: _native.extend_attention(o, q, kb, vb, r2t, req, seq_d, ext_d, start, a.D ** -0.5, 0.0, True,
-                                           int(ext.max()), int(seq.max()), ws)
+                                           int(ext.max()), int(seq.max()), ws, plan=use_plan[0])
     flops = 4 * a.Hq * a.D * float(((ext.double() ** 2) / 2 + ext.double() * pre.double()).sum())
+    _native.debug_set("extend_defer_x10", a.defer_x10)
     variants = [int(w) for w in a.waves.split(",")]
     times = {w: [] for w in variants}
     for w in variants:
-        _native.debug_set("extend_waves", w)
+        use_plan[0] = plan if w else None
         run()
     torch.cuda.synchronize()
     for _ in range(a.rounds):          # interleaved rounds in one process (same clocks, same device)
         for w in variants:
-            _native.debug_set("extend_waves", w)
+            use_plan[0] = plan if w else None
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
@@ -72,10 +76,9 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             times[w].append(e0.elapsed_time(e1) / a.iters)
-    _native.debug_set("extend_waves", 0)
     for w in variants:
         ms = sorted(times[w])[len(times[w]) // 2]
-        print(f"extend bs={a.bs} tokens={T} prefix={a.prefix} {a.dtype} waves={w}: {ms:.3f} ms (best {min(times[w]):.3f})  "
+        print(f"extend bs={a.bs} tokens={T} prefix={a.prefix} {a.dtype} plan={w} defer={a.defer_x10}: {ms:.3f} ms (best {min(times[w]):.3f})  "
               f"{flops / ms / 1e9:.1f} TFLOP/s (causal flops {flops / 1e12:.2f} T)", flush=True)
 
 

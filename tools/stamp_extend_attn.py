@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Where does a tile iteration of the extend kernel spend its cycles?  Runs the diagnostic twin of the
+library (tools/build_stamps.sh: s_memtime stamps between the segments of an iteration) on config-3
+shapes and prints the share of each segment, summed over all waves.  Read the SHARES, never the run
+time of this build (its fences forbid overlaps the real kernel has)."""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from scratchpad_amd import _native  # noqa: E402
+
+_native._LIB_PATH = os.path.join(ROOT, "scratchpad_amd", "lib", "libscratchpad_hip_stamps.so")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bs", type=int, default=64)
+    ap.add_argument("--len", default="uniform")
+    ap.add_argument("--waves", default="8,4")
+    a = ap.parse_args()
+    lib = _native.load()
+    lib.sp_debug_extend_stamp_buffer.argtypes = [ctypes.c_void_p]
+    dev, dt, Hq, Hkv, D = "cuda", torch.bfloat16, 32, 8, 128
+    g = torch.Generator().manual_seed(0)
+    ext = torch.randint(128, 4097, (a.bs,), generator=g) if a.len == "uniform" else torch.full((a.bs,), int(a.len))
+    total = int(ext.sum())
+    P = total + 64
+    kb = torch.empty(P + 1, Hkv, D, dtype=dt, device=dev).normal_(0, 0.5)
+    vb = torch.empty(P + 1, Hkv, D, dtype=dt, device=dev).normal_(0, 0.5)
+    perm = (torch.randperm(P, generator=g) + 1).to(torch.int32)
+    r2t = torch.zeros(a.bs, int(ext.max()) + 8, dtype=torch.int32)
+    off = 0
+    for b in range(a.bs):
+        n = int(ext[b])
+        r2t[b, :n] = perm[off:off + n]
+        off += n
+    r2t = r2t.to(dev)
+    q = torch.randn(total, Hq, D, device=dev).to(dt)
+    o = torch.empty_like(q)
+    req = torch.arange(a.bs, device=dev)
+    ext_d = ext.to(torch.int32).to(dev)
+    start = torch.zeros(a.bs, dtype=torch.int32, device=dev)
+    start[1:] = torch.cumsum(ext_d[:-1], 0)
+    ws = torch.empty(_native.extend_workspace_bytes(total, a.bs, Hq, D, dt), dtype=torch.uint8, device=dev)
+    seq_d = ext.to(dev)
+    run = lambda: _native.extend_attention(o, q, kb, vb, r2t, req, seq_d, ext_d, start, D ** -0.5, 0.0, True,
+                                           int(ext.max()), int(ext.max()), ws)
+    names = ["issue next gathers (+ index wait)", "K reads + S^T MFMA issue", "softmax (incl. wait for S^T)",
+             "V^T reads + O^T MFMA issue", "wait for gathers + LDS writes", "barrier"]
+    for w in [int(x) for x in a.waves.split(",")]:
+        run()
+        torch.cuda.synchronize()
+        buf = torch.zeros(8, dtype=torch.int64, device=dev)
+        lib.sp_debug_extend_stamp_buffer(buf.data_ptr())
+        run()
+        torch.cuda.synchronize()
+        lib.sp_debug_extend_stamp_buffer(None)
+        v = buf.tolist()
+        tot = sum(v[:6])
+        print(f"waves={w}: {v[7]} wave-iterations ({v[6]} with visible keys), {tot / max(v[7], 1):.0f} cycles per "
+              f"wave-iteration (stamped build)")
+        for i, n in enumerate(names):
+            print(f"   {n:38s} {v[i] / max(v[7], 1):8.0f} cyc  {100.0 * v[i] / tot:5.1f} %")
+
+
+if __name__ == "__main__":
+    main()
