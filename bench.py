@@ -12,13 +12,26 @@ in HBM before the timed region.
 
   python bench.py --gpus N --steps K --warmup W
 
-N > 1 runs N independent TP=1 replicas (one process per GPU, launched by torch.distributed.run);
-there is no data-path collective, ranks only meet at the timing barriers.
-Rank 0 prints ONE JSON line.
+N > 1 runs N independent TP=1 replicas, one process per GPU: started under torch.distributed.run
+(RANK/WORLD_SIZE in the environment) the process is one rank; started plainly, `python bench.py
+--gpus N` spawns its own N ranks through torch.distributed.run before touching a GPU and exits with
+their code (the reference's server spawns one process per rank the same way, server/server.py:252-265).
+There is no data-path collective: ranks only meet at the timing barriers.
+Rank 0 prints ONE JSON line.  After the decode measurement the same engine runs config 3 (64 prompts,
+lengths U[128,4096]) once warm and once timed: ttft_p50_ms / ttft_p99_ms / prefill_tokens_per_sec and a
+`roofline_prefill` block (extend attention kernel vs the dense bf16 MFMA peak) are part of the line.
+
+  python bench.py --mode tp --gpus 8 --tp 8 --model llama3-70b          (config 4)
+runs the REAL sharded model (heads, KV pool, linears per rank; RCCL all-reduce after o_proj / down_proj
+and the vocab-parallel embedding, vocab-parallel greedy) eager and, over RCCL, under HIP-graph replay;
+ranks that have to share GPUs (rehearsal on a 1-GPU box) talk over gloo instead and say so in the line.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,6 +42,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
 
 
 def parse_args():
@@ -38,8 +52,11 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--bs", type=int, default=256)
     ap.add_argument("--ctx", default="uniform", help='"uniform" = U[128,4096] seed 0, or a fixed length')
-    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama32-1b", "llama3-70b-tp8-rank"],
-                    help="llama3-70b-tp8-rank = one rank's shard of config 4 (no all-reduce): supplementary")
+    ap.add_argument("--model", default=None,
+                    choices=["llama3-8b", "llama32-1b", "llama3-70b", "llama3-70b-tp8-rank"],
+                    help="default llama3-8b (llama3-70b in --mode tp); llama3-70b-tp8-rank = one rank's shard "
+                         "of config 4 as a TP=1 model (no all-reduce): supplementary")
+    ap.add_argument("--tp", type=int, default=None, help="tp mode: tensor-parallel degree (default: --gpus)")
     ap.add_argument("--layers", type=int, default=None, help="override layer count (debug only)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -53,19 +70,39 @@ def parse_args():
     ap.add_argument("--sample", action="store_true",
                     help="serve mode: temperature 0.8 / top-p 0.9 / top-k 50 sampling instead of greedy")
     ap.add_argument("--rate", type=float, default=0.0, help="serve mode: Poisson arrival rate (req/s); 0 = all at t=0")
-    ap.add_argument("--mode", default="decode", choices=["decode", "prefill", "serve"],
-                    help="decode = the headline metric; prefill = config 3 (ragged prefill, TTFT)")
+    ap.add_argument("--mode", default="decode", choices=["decode", "prefill", "serve", "tp"],
+                    help="decode = the headline metric (+ the TTFT half); prefill = config 3 alone; "
+                         "tp = config 4 (sharded model, RCCL)")
+    ap.add_argument("--no-ttft", action="store_true", help="decode mode: skip the config-3 TTFT passes")
     ap.add_argument("--prefix", type=int, default=0, help="prefill mode: shared cached prefix length")
     ap.add_argument("--max-prefill-tokens", type=int, default=16384,
                     help="prefill mode: tokens per extend batch (server/args.py max_prefill_tokens)")
     ap.add_argument("--profile-steps", type=int, default=4,
                     help="extra eager steps with HIP events around every attention launch")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.model is None:
+        args.model = "llama3-70b" if args.mode == "tp" else "llama3-8b"
+    if args.mode == "tp" and args.bs == 256:
+        args.bs = 128                                   # config 4: bs 128
+    return args
 
 
-def build_engine(args, device_index, seed):
+def self_launch_if_needed(args) -> None:
+    """`python bench.py --gpus N` without a launcher: become the launcher.  Runs before anything
+    touches a GPU (importing torch does not); the children are ordinary torch.distributed.run ranks."""
+    if args.gpus <= 1 or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+def build_engine(args, device_index, seed, tp_rank=0, tp_size=1):
     from scratchpad_amd.model_runner import ModelConfig, ModelRunner, ServerArgs
-    total_steps = args.warmup + args.steps + args.profile_steps + 8
+    total_steps = 2 * (args.warmup + args.steps) + args.profile_steps + 16
     gen = torch.Generator().manual_seed(seed)
     if args.ctx == "uniform":
         ctx = torch.randint(128, 4097, (args.bs,), generator=gen)
@@ -73,6 +110,7 @@ def build_engine(args, device_index, seed):
         ctx = torch.full((args.bs,), int(args.ctx), dtype=torch.int64)
     context_len = int(ctx.max()) + total_steps + 4
     cfg = {"llama3-8b": ModelConfig.llama3_8b, "llama32-1b": ModelConfig.llama32_1b,
+           "llama3-70b": ModelConfig.llama3_70b,
            "llama3-70b-tp8-rank": ModelConfig.llama3_70b_tp8_rank}[args.model](context_len)
     if args.layers:
         cfg.num_hidden_layers = args.layers
@@ -80,7 +118,8 @@ def build_engine(args, device_index, seed):
     sargs = ServerArgs(max_total_tokens=pool_tokens, max_running_requests=args.bs,
                        disable_cuda_graph=args.no_graph, cuda_graph_max_bs=args.bs,
                        cuda_graph_bs=[args.bs], kv_cache_dtype=args.kv_cache_dtype)
-    mr = ModelRunner(cfg, sargs, dtype=torch.bfloat16, gpu_id=device_index, seed=seed)
+    mr = ModelRunner(cfg, sargs, tp_rank=tp_rank, tp_size=tp_size, dtype=torch.bfloat16, gpu_id=device_index,
+                     seed=seed)
     # synthetic cache contents (random, not zeros: zero operands run at a higher clock)
     for arena in (mr.token_to_kv_pool._k_arena, mr.token_to_kv_pool._v_arena):
         for layer in range(arena.shape[0]):
@@ -151,6 +190,80 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+def physical_cores() -> int:
+    """physical cores of the host (distinct (package, core) pairs in /proc/cpuinfo); 0 if unknown"""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen)
+    except OSError:
+        return 0
+
+
+def cores_note(cores: int) -> str:
+    return (f"torch.set_num_threads({cores}) = the cores this process may use (affinity mask / cgroup quota); "
+            f"the host has {physical_cores() or 'an unknown number of'} physical cores")
+
+
+def cpu_baseline_cfg1(prompt=16, steps=16):
+    """Config 1 in full (the reference's only e2e check has this shape,
+    tests/e2e/test_engine.py:8-57): Llama-3.2-1B shapes, bs = 1, a 16-token prompt and 16 greedy decode
+    steps on the oracle (oracle/llama.py, plain fp32 torch on the host cores), random-init weights."""
+    from oracle import llama as ollama
+    from oracle import ops
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    shape = ollama.LlamaShape(2048, 8192, 16, 32, 8, 128256, True, 500000.0, (32.0, 1.0, 4.0, 8192), 8192, 1e-5)
+    g = torch.Generator().manual_seed(0)
+    w = {"model.embed_tokens.weight": torch.randn(shape.vocab, shape.hidden, generator=g) * 0.02,
+         "model.norm.weight": torch.ones(shape.hidden)}
+    qkv_rows = (shape.Hq + 2 * shape.Hkv) * shape.D
+    for i in range(shape.layers):
+        p = f"model.layers.{i}."
+        w[p + "input_layernorm.weight"] = torch.ones(shape.hidden)
+        w[p + "post_attention_layernorm.weight"] = torch.ones(shape.hidden)
+        w[p + "self_attn.qkv_proj.weight"] = torch.randn(qkv_rows, shape.hidden, generator=g) * 0.02
+        w[p + "self_attn.o_proj.weight"] = torch.randn(shape.hidden, shape.hidden, generator=g) * 0.02
+        w[p + "mlp.gate_up_proj.weight"] = torch.randn(2 * shape.inter, shape.hidden, generator=g) * 0.02
+        w[p + "mlp.down_proj.weight"] = torch.randn(shape.hidden, shape.inter, generator=g) * 0.02
+    ctx = prompt + steps + 4
+    kv = ollama.OracleKV(shape, ctx, 1, ctx)
+    kv.req_to_token[0, :ctx] = torch.arange(1, ctx + 1, dtype=torch.int32)
+    cos_sin = ops.rope_cos_sin_cache(ctx, shape.rope_theta, shape.D, shape.rope_scaling)
+    ids = torch.randint(0, shape.vocab, (prompt,), generator=g)
+    req = torch.zeros(1, dtype=torch.int64)
+    ext = torch.tensor([prompt], dtype=torch.int32)
+    pos, start = ops.compute_position(torch.zeros(1, dtype=torch.int32), ext)
+    t0 = time.perf_counter()
+    logits = ollama.forward(shape, w, kv, mode="extend", input_ids=ids, positions=pos, req_pool_indices=req,
+                            seq_lens=torch.tensor([prompt]), out_cache_loc=torch.arange(1, prompt + 1),
+                            extend_seq_lens=ext, extend_start_loc=start, cos_sin_cache=cos_sin)
+    t_prefill = time.perf_counter() - t0
+    out, tok = [], logits.argmax(-1)
+    t0 = time.perf_counter()
+    for s in range(steps):
+        out.append(int(tok))
+        seq = torch.tensor([prompt + s + 1])
+        logits = ollama.forward(shape, w, kv, mode="decode", input_ids=tok, positions=ops.clamp_position(seq),
+                                req_pool_indices=req, seq_lens=seq, out_cache_loc=torch.tensor([prompt + s + 1]),
+                                cos_sin_cache=cos_sin)
+        tok = logits.argmax(-1)
+    t_decode = time.perf_counter() - t0
+    return {"value": round(steps / t_decode, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "ttft_ms": round(t_prefill * 1e3, 1),
+            "sample": f"config 1 in full: oracle/llama.py, fp32 torch, Llama-3.2-1B shapes (random-init), bs=1, "
+                      f"{prompt}-token prompt ({t_prefill * 1e3:.0f} ms) + {steps} greedy decode steps "
+                      f"({t_decode / steps * 1e3:.0f} ms/step); " + cores_note(cores)}
+
+
 def cpu_baseline(bs=8, ctx=512, layers=2, seconds=12.0):
     """The oracle's decode step (oracle/llama.py, plain torch fp32) on the host cores: Llama-3-8B
     layer shapes, `layers` layers, bs x ctx; extrapolated to 32 layers + lm_head."""
@@ -204,31 +317,30 @@ def cpu_baseline(bs=8, ctx=512, layers=2, seconds=12.0):
     return {"value": round(bs / step, 3), "unit": "tokens/s", "cores": cores, "kind": "port",
             "sample": f"oracle/llama.py decode step, fp32 torch, Llama-3-8B layer shapes, bs={bs} ctx={ctx}, "
                       f"{layers} layers x {n - 1} timed steps ({t_layer * 1e3:.1f} ms/layer) + lm_head "
-                      f"({t_head * 1e3:.1f} ms), extrapolated to 32 layers"}
+                      f"({t_head * 1e3:.1f} ms), extrapolated to 32 layers; " + cores_note(cores)}
 
 
-def prefill_main(args, rank, local_rank, world):
-    """Config 3: bs prompts with lengths U[128,4096] (seed 0), optionally on top of a shared cached
-    prefix, admitted in arrival order into extend batches of <= max_prefill_tokens new tokens (the
-    reference's PrefillAdder budget, server/args.py:33-34); TTFT of a request = time from the start
-    of the run to the end of the batch that contains it (all requests arrive at t = 0)."""
-    from scratchpad_amd.model_runner import ModelConfig, ModelRunner, ServerArgs, TpModelWorker
+def prefill_passes(args, mr, worker, rank, bs, warm, timed, profile_attention=False):
+    """Config 3 on an existing engine: bs prompts with lengths U[128,4096] (seed = rank), optionally on top
+    of a shared cached prefix, admitted in arrival order into extend batches of <= max_prefill_tokens new
+    tokens (the reference's PrefillAdder budget, server/args.py:33-34); TTFT of a request = time from the
+    start of the pass to the end of the batch that contains it (all requests arrive at t = 0).
+    Returns (median pass seconds, sorted TTFTs of that pass, lens, extend batches, attention profile)."""
+    from scratchpad_amd import _native
     from scratchpad_amd.schedule_batch import Req, ScheduleBatch
-    bs = 64 if args.bs == 256 else args.bs
     gen = torch.Generator().manual_seed(rank)
     lens = torch.randint(128, 4097, (bs,), generator=gen).tolist()
-    total = sum(lens) + args.prefix
-    cfg = ModelConfig.llama3_8b(4096 + args.prefix + 8)
-    if args.layers:
-        cfg.num_hidden_layers = args.layers
-    reps = args.warmup + args.steps
-    sargs = ServerArgs(max_total_tokens=total + 64, max_running_requests=bs, disable_cuda_graph=True)
-    mr = ModelRunner(cfg, sargs, dtype=torch.bfloat16, gpu_id=local_rank, seed=rank)
-    worker = TpModelWorker(mr)
-    dev = mr.device
-    vocab = cfg.vocab_size
+    dev, vocab, cfg = mr.device, mr.model_config.vocab_size, mr.model_config
     prompts = [torch.randint(0, vocab, (n,), generator=gen).tolist() for n in lens]
     prefix_ids = torch.randint(0, vocab, (args.prefix,), generator=gen).tolist()
+    batches, cur, cur_tok = [], [], 0
+    for i, n in enumerate(lens):
+        if cur and cur_tok + n > args.max_prefill_tokens:
+            batches.append(cur)
+            cur, cur_tok = [], 0
+        cur.append(i)
+        cur_tok += n
+    batches.append(cur)
 
     def one_pass():
         mr.req_to_token_pool.clear()
@@ -241,14 +353,6 @@ def prefill_main(args, rank, local_rank, world):
             worker.forward_batch_generation(pre.get_model_worker_batch())
             prefix_slots = pre.out_cache_loc.clone()
             mr.req_to_token_pool.free(pre.reqs[0].req_pool_idx)
-        batches, cur, cur_tok = [], [], 0
-        for i, n in enumerate(lens):
-            if cur and cur_tok + n > args.max_prefill_tokens:
-                batches.append(cur)
-                cur, cur_tok = [], 0
-            cur.append(i)
-            cur_tok += n
-        batches.append(cur)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ttft = [0.0] * bs
@@ -261,17 +365,60 @@ def prefill_main(args, rank, local_rank, world):
             t = time.perf_counter() - t0
             for i in ids:
                 ttft[i] = t
-        return time.perf_counter() - t0, ttft, len(batches)
+        return time.perf_counter() - t0, ttft
 
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(warm):
         one_pass()
     times, ttfts = [], []
-    for _ in range(args.steps):
-        el, tt, nb = one_pass()
+    for _ in range(timed):
+        el, tt = one_pass()
         times.append(el)
         ttfts.append(tt)
     el = sorted(times)[len(times) // 2]
     tt = sorted(ttfts[times.index(el)])
+
+    prof = None
+    if profile_attention:
+        # one more pass with HIP events around every extend-attention launch (on the stream it is
+        # launched on); flops of a launch = 4 Hq D sum(L^2 / 2 + L prefix) over its requests
+        import scratchpad_amd.attention as att
+        orig, events = _native.extend_attention, []
+
+        def timed_call(*a_, **k_):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(*a_, **k_)
+            e1.record()
+            events.append((e0, e1))
+
+        att._native.extend_attention = timed_call
+        try:
+            one_pass()
+            torch.cuda.synchronize()
+        finally:
+            att._native.extend_attention = orig
+        per_layer = cfg.num_hidden_layers
+        calls = events[-per_layer * len(batches):]         # the pass's own launches (not the prefix step)
+        ms = sum(a_.elapsed_time(b_) for a_, b_ in calls)
+        heads = cfg.num_attention_heads // mr.tp_size
+        flops = per_layer * sum(4.0 * heads * cfg.head_dim * (n * n / 2.0 + n * args.prefix) for n in lens)
+        prof = {"launches": len(calls), "avg_launch_ms": ms / len(calls), "tflops": flops / (ms * 1e-3) / 1e12,
+                "flops_per_launch": flops / len(calls)}
+    return el, tt, lens, len(batches), prof
+
+
+def prefill_main(args, rank, local_rank, world):
+    """Config 3 alone (`--mode prefill`)."""
+    from scratchpad_amd.model_runner import ModelConfig, ModelRunner, ServerArgs, TpModelWorker
+    bs = 64 if args.bs == 256 else args.bs
+    cfg = ModelConfig.llama3_8b(4096 + args.prefix + 8)
+    if args.layers:
+        cfg.num_hidden_layers = args.layers
+    sargs = ServerArgs(max_total_tokens=bs * 4096 + args.prefix + 64, max_running_requests=bs, disable_cuda_graph=True)
+    mr = ModelRunner(cfg, sargs, dtype=torch.bfloat16, gpu_id=local_rank, seed=rank)
+    worker = TpModelWorker(mr)
+    el, tt, lens, nb, prof = prefill_passes(args, mr, worker, rank, bs, max(args.warmup, 1), args.steps,
+                                            profile_attention=True)
     if rank != 0:
         return
     out = {"metric": "ttft_p50_ms", "value": round(tt[len(tt) // 2] * 1e3, 2), "unit": "ms", "n_gpus": world,
@@ -282,9 +429,20 @@ def prefill_main(args, rank, local_rank, world):
                                   f"cached prefix {args.prefix}, extend batches <= {args.max_prefill_tokens} tokens",
                       "prompt_tokens": sum(lens), "extend_batches": nb, "layers": cfg.num_hidden_layers},
            "ttft_p99_ms": round(tt[int(len(tt) * 0.99)] * 1e3, 2),
-           "prefill_tokens_per_sec": round(sum(lens) / el, 1)}
+           "prefill_tokens_per_sec": round(sum(lens) / el, 1),
+           "roofline_prefill": prefill_roofline(prof)}
     print(json.dumps(out), flush=True)
 
+
+def prefill_roofline(prof):
+    if prof is None:
+        return None
+    return {"bound": "mfma", "kernel": "extend_mfma_kernel", "achieved": round(prof["tflops"], 1),
+            "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(prof["tflops"] / MFMA_PEAK_TFLOPS, 4),
+            "traffic": None, "avg_launch_ms": round(prof["avg_launch_ms"], 4), "launches": prof["launches"],
+            "algorithmic_flops_per_launch": int(prof["flops_per_launch"]),
+            "note": "useful (causal) flops 4 Hq D sum(L^2/2) of every extend-attention launch / its HIP-event time; "
+                    "attention is ~5 % of the prefill flops, the projections (hipBLASLt) are the rest of TTFT"}
 
 
 def serve_main(args, rank, local_rank, world):
@@ -452,26 +610,181 @@ def serve_main(args, rank, local_rank, world):
            "itl_ms": {"p50": round(pct(itl, 0.5), 2), "p99": round(pct(itl, 0.99), 2)}}
     print(json.dumps(out), flush=True)
 
+def pmc_traffic(alg_bytes, args):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
+    (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; tools/pmc_decode_bf16.sh): the measured
+    traffic / algorithmic ratio of the same kernel SOURCES and workload, else None - a ratio recorded for
+    other kernel sources says nothing about this build."""
+    path = os.path.join(ROOT, "profiles", "r02_decode_attn_pmc.json")
+    if not os.path.exists(path) or args.model != "llama3-8b" or args.kv_cache_dtype != "auto" \
+            or args.bs != 256 or args.ctx != "uniform":
+        return None, "no PMC pass for this workload"
+    rec = json.load(open(path))
+    if rec.get("kernel_source_sha1") != decode_kernel_sources_sha1():
+        return None, "profiles/r02_decode_attn_pmc.json was recorded for other kernel sources (stale): not used"
+    return int(alg_bytes * rec["traffic_over_algorithmic"]), \
+        "profiles/r02_decode_attn_pmc.json (PMC ratio x algorithmic, same kernel sources)"
+
+
+def decode_kernel_sources_sha1() -> str:
+    h = hashlib.sha1()
+    for name in ("decode_mfma.hip", "decode_attention.hip", "attention_internal.h", "sp_common.h"):
+        h.update(open(os.path.join(ROOT, "scratchpad_amd", "csrc", name), "rb").read())
+    return h.hexdigest()
+
+
+def tp_main(args, rank, local_rank, world):
+    """Config 4: the sharded model over a TP group - every rank holds its heads, its KV pool and its
+    slices of the linears; SUM all-reduce of [bs, hidden] after o_proj and down_proj and after the
+    vocab-parallel embedding (RCCL, or the direct IPC kernel with SP_CUSTOM_ALLREDUCE=1), vocab-parallel
+    greedy.  Measured eager, then under HIP-graph replay with the collectives captured inside the graph
+    (distributed/parallel_state.py:256-302, model_executor/cuda_graph_runner.py:295-329)."""
+    import datetime
+    import torch.distributed as dist
+    from scratchpad_amd import distributed as d
+    from scratchpad_amd.model_runner import TpModelWorker
+    tp = args.tp or world
+    if world % tp:
+        raise SystemExit(f"--gpus {world} is not a multiple of --tp {tp}")
+    ndev = torch.cuda.device_count()
+    shared = ndev < world
+    backend = "gloo" if shared else "nccl"      # RCCL refuses two ranks on one device: rehearsal over gloo
+    if world > 1:
+        d.init_distributed_environment(world, rank, "env://", local_rank, backend=backend)
+    d.initialize_model_parallel(tp, backend=backend if world > 1 else None, local_rank=local_rank)
+    group = rank // tp                            # dp replica this rank belongs to
+    mr, ctx, gen = build_engine(args, local_rank, seed=group, tp_rank=rank % tp, tp_size=tp)
+    worker = TpModelWorker(mr)
+    batch = populate_batch(mr, ctx, gen)
+    cfg = mr.model_config
+    tpg = d.get_tp_group()
+    ca = getattr(tpg, "ca_comm", None)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(n):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            engine_step(worker, batch)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if backend == "gloo" else mr.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        if ca is not None:
+            ca.check()
+        return el
+
+    for _ in range(args.warmup):
+        engine_step(worker, batch)
+    eager_s = timed(args.steps)
+    graph_s, graph_note = None, None
+    if args.no_graph:
+        graph_note = "--no-graph"
+    elif tp > 1 and backend == "gloo" and ca is None:
+        graph_note = "not captured: gloo collectives cannot be recorded into a HIP graph (rehearsal; RCCL or " \
+                     "SP_CUSTOM_ALLREDUCE=1 can)"
+    else:
+        try:
+            mr.init_cuda_graphs()
+            for _ in range(max(args.warmup, 2)):
+                engine_step(worker, batch)
+            graph_s = timed(args.steps)
+        except Exception as e:        # noqa: BLE001 - reported in the line; the eager figure stands
+            graph_note = f"capture failed: {type(e).__name__}: {e}"
+            mr.graph_runner = None
+    # the collective alone, at the step's message size
+    ar_us, ar_bytes = None, args.bs * cfg.hidden_size * 2
+    if tp > 1:
+        x = torch.randn(args.bs, cfg.hidden_size, device=mr.device).to(torch.bfloat16)
+        for _ in range(10):
+            d.tensor_model_parallel_all_reduce(x.clone())
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        xs = [x.clone() for _ in range(50)]
+        e0.record()
+        for xi in xs:
+            d.tensor_model_parallel_all_reduce(xi)
+        e1.record()
+        barrier()
+        ar_us = e0.elapsed_time(e1) / len(xs) * 1e3
+    seen = [None] * world
+    me = (rank, socket.gethostname(), local_rank, torch.cuda.get_device_name(local_rank),
+          str(torch.cuda.get_device_properties(local_rank).uuid) if hasattr(
+              torch.cuda.get_device_properties(local_rank), "uuid") else "")
+    if world > 1:
+        dist.all_gather_object(seen, me)
+    else:
+        seen = [me]
+    if ca is not None:
+        ca.close()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    # the faster of the two is the figure (ranks that share one GPU are time-sliced by the driver, and a
+    # replayed graph that spins on a peer then costs a scheduling quantum per all-reduce: rehearsal only)
+    best = eager_s if graph_s is None else min(graph_s, eager_s)
+    dp = world // tp
+    value = dp * args.bs * args.steps / best
+    n_params = sum(p_.numel() for p_ in mr.model.parameters())
+    step_bytes = n_params * 2 + batch.seq_lens_sum * 2 * cfg.get_num_kv_heads(tp) * cfg.head_dim * 2 * cfg.num_hidden_layers
+    roof = args.bs / (step_bytes / (HBM_PEAK_GBPS * 1e9))
+    out = {"metric": "decode_tokens_per_sec", "value": round(value, 1), "unit": "tokens/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(best / args.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "strong" if dp == 1 else "weak", "vs_baseline": None,
+           "dtype": "bf16", "data": "synthetic (random-init weights, random KV, seeded contexts and slot permutation)",
+           "config": {"workload": f"{args.model} TP={tp} bf16 decode bs={args.bs} seq_len=1, "
+                                  f"ctx={'U[128,4096] seed 0' if args.ctx == 'uniform' else args.ctx}, page_size=1",
+                      "tp": tp, "dp_replicas": dp, "layers": cfg.num_hidden_layers,
+                      "backend": "RCCL (nccl)" if backend == "nccl" else
+                                 "gloo - REHEARSAL: ranks share GPUs, not an xGMI measurement",
+                      "all_reduce": "direct IPC kernel (SP_CUSTOM_ALLREDUCE=1)" if ca is not None else backend,
+                      "graph": graph_s is not None, "graph_note": graph_note,
+                      "value_from": "graph replay" if graph_s is not None and graph_s <= eager_s else "eager"},
+           "eager_tokens_per_sec": round(dp * args.bs * args.steps / eager_s, 1),
+           "eager_ms_per_step": round(eager_s / args.steps * 1e3, 3),
+           "graph_ms_per_step": None if graph_s is None else round(graph_s / args.steps * 1e3, 3),
+           "allreduce_us_per_call": None if ar_us is None else round(ar_us, 1), "allreduce_bytes": ar_bytes,
+           "allreduces_per_step": 2 * cfg.num_hidden_layers + 1,
+           "step_frac_of_hbm_roofline_per_rank": round(args.bs / (best / args.steps) / roof, 4),
+           "ranks_seen": len(seen), "devices_seen": len({(h, dv) for _, h, dv, _, _ in seen}),
+           "ranks": [{"rank": r, "host": h, "device": dv, "name": nm} for r, h, dv, nm, _ in seen]}
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
+    self_launch_if_needed(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     import torch.distributed as dist
     # one process per GPU; a box with fewer GPUs than ranks (rehearsals) shares devices round-robin
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
+    from scratchpad_amd import _native
+    from scratchpad_amd.model_runner import TpModelWorker
+    _native.load()
+    if args.mode == "tp":
+        if args.steps == 64:
+            args.steps, args.warmup = 32, 4
+        tp_main(args, rank, local_rank, world)
+        return
     if world > 1:
         # replicas share nothing on the data path: the only cross-rank traffic is the timing barrier
         # and the max over ranks of the elapsed time, so a host-side (gloo) group is all that is needed
         dist.init_process_group("gloo")
-
-    from scratchpad_amd import _native
-    from scratchpad_amd.model_runner import TpModelWorker
-    _native.load()
     if args.mode == "prefill":
         if args.steps == 64:
             args.steps, args.warmup = 3, 1
@@ -577,13 +890,7 @@ def main():
         kv_elem = 1 if args.kv_cache_dtype == "fp8_e5m2" else 2
         alg = attention_algorithmic_bytes(cfg, sums[-1], args.bs, kv_elem)     # the replayed step's lengths
         achieved = alg / (avg_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per
-        # the gfx950 correction + WRITE_SIZE, same shapes): measured traffic/algorithmic ratio
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_decode_attn_pmc.json")
-        if os.path.exists(pmc) and args.model == "llama3-8b" and args.kv_cache_dtype == "auto":
-            ratio = json.load(open(pmc))["traffic_over_algorithmic"]
-            traffic, traffic_src = int(alg * ratio), "profiles/r01_decode_attn_pmc.txt (PMC ratio x algorithmic)"
+        traffic, traffic_src = pmc_traffic(alg, args)
         roofline = {"bound": "hbm", "kernel": "decode_mfma_kernel+decode_merge_kernel",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
@@ -592,6 +899,19 @@ def main():
                     "avg_launch_ms_with_per_call_events": round(per_call_ms, 4),
                     "algorithmic_bytes_per_launch": int(alg)}
 
+    # ---- the other half of the metric: p50 TTFT of config 3 on the same engine (64 prompts, lengths
+    # U[128,4096], extend batches <= max_prefill_tokens): one warm pass, one timed pass, one pass with
+    # HIP events around the extend-attention launches (every rank runs them; rank 0 reports its own)
+    ttft = None
+    if not args.no_ttft and args.model == "llama3-8b" and cfg.context_len >= 4100:
+        el_p, tt_p, lens_p, nb_p, prof_p = prefill_passes(args, mr, worker, rank, 64, 1, 1, profile_attention=rank == 0)
+        ttft = {"ttft_p50_ms": round(tt_p[len(tt_p) // 2] * 1e3, 2), "ttft_p99_ms": round(tt_p[int(len(tt_p) * 0.99)] * 1e3, 2),
+                "prefill_tokens_per_sec": round(sum(lens_p) / el_p, 1),
+                "prefill_config": {"workload": f"llama3-8b TP=1 bf16 ragged prefill bs=64, prompt lengths U[128,4096] "
+                                               f"seed {rank}, extend batches <= {args.max_prefill_tokens} tokens",
+                                   "prompt_tokens": sum(lens_p), "extend_batches": nb_p, "pass_ms": round(el_p * 1e3, 1)},
+                "roofline_prefill": prefill_roofline(prof_p)}
+        barrier()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -608,6 +928,7 @@ def main():
         "metric": "decode_tokens_per_sec", "value": round(value, 1), "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "kv_cache_dtype": "bf16" if args.kv_cache_dtype == "auto" else args.kv_cache_dtype,
         "data": "synthetic (random-init weights, random KV, seeded contexts and slot permutation)",
         "config": {"workload": f"{args.model} TP=1 bf16 continuous-batching decode bs={args.bs} seq_len=1, "
                                f"ctx={'U[128,4096] seed 0' if args.ctx == 'uniform' else args.ctx}, page_size=1, "
@@ -618,10 +939,13 @@ def main():
         "step_hbm_roofline_tokens_per_sec": round(step_roofline_tok_s, 1),
         "step_frac_of_hbm_roofline": round(value / world / step_roofline_tok_s, 4),
     }
+    if ttft is not None:
+        out.update(ttft)
     if roofline is not None:
         out["roofline"] = roofline
-    if not args.no_cpu_baseline and world == 1:     # the CPU leg is timed on rank 0 of the 1-GPU run only
+    if not args.no_cpu_baseline and world == 1:     # the CPU legs are timed on rank 0 of the 1-GPU run only
         out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline_cfg1"] = cpu_baseline_cfg1()
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

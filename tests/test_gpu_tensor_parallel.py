@@ -190,3 +190,144 @@ def test_direct_all_reduce_through_ipc_regions(world):
         p.join(timeout=60)
     for rank, err in results:
         assert err is None, f"rank {rank}:\n{err}"
+
+
+def _rccl_main(rank, world, port, q, custom_ar):
+    """TP over RCCL with one GPU per rank: sharded forward vs the unsharded oracle, eager and under
+    HIP-graph replay with the all-reduces captured inside the graph."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["SP_CUSTOM_ALLREDUCE"] = "1" if custom_ar else "0"
+        from oracle import llama as ollama, ops
+        from scratchpad_amd import distributed as d
+        from scratchpad_amd.forward_info import ForwardMode, ModelWorkerBatch
+        from scratchpad_amd.model_runner import ModelConfig, ModelRunner, ServerArgs, TpModelWorker
+        from tests import smoke_impl
+        torch.cuda.set_device(rank)
+        d.init_distributed_environment(world, rank, f"tcp://127.0.0.1:{port}", rank, backend="nccl")
+        d.initialize_model_parallel(world, backend="nccl", local_rank=rank)
+        g, pfx, shape, w = smoke_impl.load_case("b")
+        cfg = ModelConfig(shape.hidden, shape.inter, shape.layers, shape.Hq, shape.Hkv, shape.vocab, context_len=60,
+                          rms_norm_eps=shape.rms_eps, rope_theta=shape.rope_theta, max_position_embeddings=shape.max_pos,
+                          tie_word_embeddings=shape.tie)
+        mr = ModelRunner(cfg, ServerArgs(max_total_tokens=96, max_running_requests=4, cuda_graph_bs=[2],
+                                         cuda_graph_max_bs=2),
+                         tp_rank=rank, tp_size=world, dtype=torch.float32, gpu_id=rank, init_weights=False)
+        mr.model.load_full_state_dict({k: v.to(mr.device) for k, v in w.items()})
+        worker = TpModelWorker(mr)
+        dev = mr.device
+        gen = torch.Generator().manual_seed(5)
+        lens = [7, 4]
+        ids = torch.randint(0, shape.vocab, (sum(lens),), generator=gen)
+        loc = torch.arange(1, 1 + sum(lens))
+        table = mr.req_to_token_pool.req_to_token
+        table[0, :7] = loc[:7].to(torch.int32).to(dev)
+        table[1, :4] = loc[7:].to(torch.int32).to(dev)
+        req = torch.tensor([0, 1])
+        batch = ModelWorkerBatch(bid=1, forward_mode=ForwardMode.EXTEND, input_ids=ids.to(dev),
+                                 req_pool_indices=req.to(dev), seq_lens=torch.tensor(lens).to(dev),
+                                 out_cache_loc=loc.to(dev), seq_lens_sum=sum(lens), extend_num_tokens=sum(lens),
+                                 extend_seq_lens=lens, extend_prefix_lens=[0, 0])
+        out, nxt = worker.forward_batch_generation(batch)
+        okv = ollama.OracleKV(shape, 96, 4, 64)
+        okv.req_to_token.copy_(table.cpu())
+        ext = torch.tensor(lens, dtype=torch.int32)
+        pos, start = ops.compute_position(torch.zeros(2, dtype=torch.int32), ext)
+        ref = ollama.forward(shape, w, okv, mode="extend", input_ids=ids, positions=pos, req_pool_indices=req,
+                             seq_lens=torch.tensor(lens), out_cache_loc=loc, extend_seq_lens=ext, extend_start_loc=start)
+        rel = lambda a, b: float((a.float().cpu() - b).abs().max() / b.abs().max())
+        assert rel(out.next_token_logits, ref) <= 1e-4, ("prefill over RCCL", rank)
+        assert torch.equal(nxt.cpu(), ref.argmax(-1))
+        loc2 = torch.tensor([20, 21])
+        table[0, 7] = 20
+        table[1, 4] = 21
+        seq2 = torch.tensor([8, 5])
+        okv.req_to_token.copy_(table.cpu())
+        ref2 = ollama.forward(shape, w, okv, mode="decode", input_ids=nxt.cpu(), positions=ops.clamp_position(seq2),
+                              req_pool_indices=req, seq_lens=seq2, out_cache_loc=loc2)
+
+        def decode_once():
+            b2 = ModelWorkerBatch(bid=2, forward_mode=ForwardMode.DECODE, input_ids=nxt, req_pool_indices=req.to(dev),
+                                  seq_lens=seq2.to(dev), out_cache_loc=loc2.to(dev), seq_lens_sum=13)
+            return worker.forward_batch_generation(b2)
+        out2, n2 = decode_once()                              # eager
+        assert rel(out2.next_token_logits, ref2) <= 1e-4, ("eager decode over RCCL", rank)
+        mr.init_cuda_graphs()                                 # collectives captured inside the graph
+        for _ in range(3):
+            out3, n3 = decode_once()
+            assert rel(out3.next_token_logits, ref2) <= 1e-4, ("graph decode over RCCL", rank)
+            assert torch.equal(n3, n2)
+        ca = d.get_tp_group().ca_comm
+        assert (ca is not None) == custom_ar
+        if ca is not None:
+            ca.check()
+            ca.close()
+        torch.distributed.barrier()
+        q.put((rank, None))
+    except Exception:
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: RCCL refuses two ranks on one device")
+@pytest.mark.parametrize("custom_ar", [False, True], ids=["rccl", "direct-all-reduce"])
+def test_tp2_over_rccl_matches_unsharded_oracle(custom_ar):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_main, args=(r, 2, port, q, custom_ar)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err in results:
+        assert err is None, f"rank {rank}:\n{err}"
+
+
+def _rccl_single_main(port, q):
+    """One rank, an RCCL communicator of size 1, collectives forced through the library: the RCCL
+    all-reduce inside a captured HIP graph replays (what a 1-GPU box can check of RCCL-in-graph)."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0,
+                                device_id=torch.device("cuda", 0))
+        x = torch.randn(128, 8192, device="cuda").to(torch.bfloat16)
+        want = x.clone()
+        dist.all_reduce(x)                                    # creates the communicator outside capture
+        torch.cuda.synchronize()
+        assert torch.equal(x, want)
+        xs = torch.zeros_like(x)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            dist.all_reduce(xs)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            ys = xs * 2
+            dist.all_reduce(ys)
+            zs = ys + 1
+        for rep in range(3):
+            xs.copy_(torch.randn(128, 8192, device="cuda").to(torch.bfloat16))
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(zs, xs * 2 + 1), rep
+        dist.destroy_process_group()
+        q.put((0, None))
+    except Exception:
+        q.put((0, traceback.format_exc()))
+
+
+def test_rccl_all_reduce_inside_a_hip_graph_single_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_main, args=(_free_port(), q))
+    p.start()
+    rank, err = q.get(timeout=300)
+    p.join(timeout=60)
+    assert err is None, err
