@@ -92,8 +92,9 @@ SP_API int sp_kv_store(void* k_buffer, void* v_buffer, const int64_t* loc, const
 /* ---- KV store into an fp8 (e5m2) pool: the `--kv-cache-dtype fp8_e5m2` branch of set_kv_buffer
  *      (memory/pool.py:401-412: cache_k.div_(k_scale); cache_k.to(float8_e5m2); stored as uint8).
  * k,v: [T, Hkv, D] in `src_dtype` (fp16/bf16/fp32); buffers: uint8 [P+1, Hkv, D], strides in
- * elements (= bytes).  Conversion = round-to-nearest-even to 1-5-2 (overflow -> inf), i.e.
- * torch's .to(torch.float8_e5m2); k_scale / v_scale divide first (pass 1.0 for none).            */
+ * elements (= bytes).  The reference's two steps with their two roundings: x / scale as an fp32
+ * division rounded to `src_dtype` (cache_k.div_(k_scale)), then round-to-nearest-even to 1-5-2
+ * (overflow -> inf), i.e. torch's .to(torch.float8_e5m2).  Pass 1.0 for an unscaled pool.        */
 SP_API int sp_kv_store_fp8(void* k_buffer, void* v_buffer, const int64_t* loc, const void* k, const void* v,
                     int64_t num_tokens, int num_kv_heads, int head_dim, int64_t k_stride,
                     int64_t v_stride, int64_t k_buffer_stride, int64_t v_buffer_stride, float k_scale,

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void kv_store_fp8_kernel(char* __restrict__
                                                                const void* __restrict__ v, int64_t num_tokens,
                                                                int row_elems, int64_t k_stride, int64_t v_stride,
                                                                int64_t kb_stride, int64_t vb_stride,
-                                                               float k_inv, float v_inv) {
+                                                               float k_scale, float v_scale) {
   typedef Elem<Tag> E;
   const int units = row_elems / 8;                     // per row
   const int64_t total = num_tokens * units * 2;
@@ -354,13 +354,16 @@ __global__ __launch_bounds__(kBlock) void kv_store_fp8_kernel(char* __restrict__
     const int64_t slot = loc[t];
     const void* src = is_v ? v : k;
     const int64_t sbase = t * (is_v ? v_stride : k_stride) + (int64_t)u * 8;
-    const float inv = is_v ? v_inv : k_inv;
+    // the reference's two steps and two roundings (memory/pool.py:401-412): cache_k.div_(k_scale) in
+    // the activation dtype (an fp32 division rounded back to that dtype), then .to(float8_e5m2)
+    const float scale = is_v ? v_scale : k_scale;
     u32x2 out;
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
       uint32_t word = 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) word |= f32_to_e5m2_bits(E::load(src, sbase + 4 * w + e) * inv) << (8 * e);
+      for (int e = 0; e < 4; ++e)
+        word |= f32_to_e5m2_bits(E::round(E::load(src, sbase + 4 * w + e) / scale)) << (8 * e);
       out[w] = word;
     }
     char* dst = (is_v ? vbuf + slot * vb_stride : kbuf + slot * kb_stride) + (int64_t)u * 8;
@@ -595,7 +598,7 @@ extern "C" int sp_kv_store_fp8(void* k_buffer, void* v_buffer, const int64_t* lo
   if (blocks > 256 * 16) blocks = 256 * 16;
   SP_DISPATCH_DTYPE(src_dtype, (kv_store_fp8_kernel<Tag><<<dim3((unsigned)blocks), kBlock, 0, (hipStream_t)stream>>>(
                                    (char*)k_buffer, (char*)v_buffer, loc, k, v, num_tokens, row, k_stride, v_stride,
-                                   k_buffer_stride, v_buffer_stride, 1.0f / k_scale, 1.0f / v_scale)));
+                                   k_buffer_stride, v_buffer_stride, k_scale, v_scale)));
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

@@ -323,7 +323,12 @@ class HipGraphRunner:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, pool=self.pool):
+        # thread-local capture mode: under TP the RCCL process group's watchdog thread polls the events
+        # of earlier collectives while this thread captures; in the default (global) mode any HIP call
+        # of another thread during a capture is an error ("operation not permitted when stream is
+        # capturing") and takes the process group down - found by
+        # tests/test_gpu_tensor_parallel.py::test_rccl_all_reduce_inside_a_hip_graph_single_rank
+        with torch.cuda.graph(graph, pool=self.pool, capture_error_mode="thread_local"):
             out = run_once()
         self.pool = graph.pool()
         return graph, out

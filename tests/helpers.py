@@ -47,9 +47,45 @@ def assert_close(hip, ref, dtype, kind="attn", what="", both_rounded=False, vmax
     if vmax is not None and dtype != torch.float32:
         bound = bound + 0.5 * {torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8}[dtype] * 0.5 * float(vmax)
     bad = err > bound
+    rel_scaled = float(err.max()) / scale if scale > 0 else 0.0
     assert not bool(bad.any()), (
         f"{what}: {int(bad.sum())}/{bad.numel()} out of tolerance, max err {float(err.max()):.3e} "
-        f"(scale {scale:.3e}, rtol {rtol:.2e})")
+        f"= {rel_scaled:.3e} of max|ref| (scale {scale:.3e}, rtol {rtol:.2e}), "
+        f"max err/bound {float((err / bound.clamp_min(1e-30)).max()):.3f}")
+
+
+UNIT_ROUNDOFF = {torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8}
+
+
+def attn_error_units(hip, ref, abs_ref, dtype):
+    """max over elements of |hip - ref| / (u * (|ref| + abs_ref)), u = the dtype's unit roundoff.
+
+    The error model of a 16-bit attention kernel with fp32 accumulation: the output is rounded once
+    (<= u |ref|), and the probabilities enter P.V rounded to the KV dtype like the reference's own
+    `p.to(v.dtype)` (decode_attention.py:427, extend_attention.py:155), which moves an output by at
+    most u * sum_i p_i |v_i| / l = u * A, where A is the attention output computed with |V|
+    (`abs_ref`).  Everything else (fp32 scores, exp2, sums) is orders of magnitude below u.  So a
+    correct kernel stays below ~1 unit; where |ref| ~ A (no cancellation) one unit is a relative
+    error of 2u = 9.8e-4 at fp16 - the north-star's "1e-3 relative fp16" - without the blanket
+    `1e-3 * max|ref|` allowance of assert_close."""
+    hip = hip.detach().float().cpu().double()
+    ref = ref.detach().float().cpu().double()
+    abs_ref = abs_ref.detach().float().cpu().double()
+    assert hip.shape == ref.shape == abs_ref.shape, (hip.shape, ref.shape, abs_ref.shape)
+    assert torch.isfinite(hip).all(), "non-finite output"
+    u = UNIT_ROUNDOFF[dtype]
+    denom = u * (ref.abs() + abs_ref) + 1e-30
+    return float(((hip - ref).abs() / denom).max())
+
+
+def assert_attn_close(hip, ref, abs_ref, dtype, what="", units=1.0):
+    """16-bit attention output against the fp32 oracle under the error model of attn_error_units:
+    at most one unit (measured on MI355X: 0.28 - 0.81 units over every kernel, dtype, shape and
+    full-size configuration of the suite)."""
+    got = attn_error_units(hip, ref, abs_ref, dtype)
+    print(f"[parity] {what}: max error {got:.3f} units of u(|ref| + A), u = 2^{int(torch.log2(torch.tensor(UNIT_ROUNDOFF[dtype])))}"
+          f" (bound {units})")
+    assert got <= units, f"{what}: max error {got:.3f} units of u*(|ref| + A) exceeds {units}"
 
 
 def paged_problem(seed, bs, Hq, Hkv, D, seq_lens, dtype, device, extra_slots=7, extra_rows=3,

@@ -39,11 +39,63 @@ def test_store_is_bitwise_torch_conversion(dtype):
     assert torch.equal(got_k[~nan], want_k[~nan]) and torch.equal(got_v, want_v)
     assert bool(torch.isnan(got_k[nan].view(torch.float8_e5m2).float()).all())
     assert int(kb.cpu()[0].sum()) == 0, "slot 0 untouched"
-    # scales divide first (pool.py:403-406)
-    _native.kv_store_fp8(kb, vb, loc.to(DEV), k.to(DEV), v.to(DEV), 2.0, 0.5)
-    fin = torch.isfinite(k.float())
-    want = (k.float() / 2.0).to(torch.float8_e5m2).view(torch.uint8)
-    assert torch.equal(kb.cpu()[loc][fin], want[fin])
+    # scales divide first, IN the activation dtype, then the cast (pool.py:403-408: cache_k.div_(k_scale);
+    # cache_k.to(self.dtype)): two roundings - reproduced bit for bit also for scales that are not
+    # powers of two
+    for ks, vs in ((2.0, 0.5), (1.7, 0.37), (3.0, 1.0 / 3.0)):
+        _native.kv_store_fp8(kb, vb, loc.to(DEV), k.to(DEV), v.to(DEV), ks, vs)
+        fin = torch.isfinite(k.float())
+        want_k = k.clone().div_(ks).to(torch.float8_e5m2).view(torch.uint8)
+        want_v = v.clone().div_(vs).to(torch.float8_e5m2).view(torch.uint8)
+        assert torch.equal(kb.cpu()[loc][fin], want_k[fin]), (ks, dtype)
+        assert torch.equal(vb.cpu()[loc], want_v), (vs, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_attention_applies_the_layer_scales_of_a_scaled_fp8_pool(dtype):
+    """flashinfer_backend.py:470-482 hands layer.k_scale / v_scale to the store AND to the kernels: the pool
+    holds k / k_scale and v / v_scale, so decode and extend over it with the scales must equal attention
+    over the re-scaled widened values (and differ from the unscaled call)."""
+    from scratchpad_amd import _native
+    Hq, Hkv, D = 8, 2, 128
+    lens = [5, 64, 130, 300]
+    bs = len(lens)
+    ks, vs = 1.7, 0.37
+    p = _fp8_problem(75, bs, Hq, Hkv, D, lens, dtype)
+    c = cpu(p)
+    kw = c["k_buffer"].view(torch.float8_e5m2).float() * ks
+    vw = c["v_buffer"].view(torch.float8_e5m2).float() * vs
+    scale = D ** -0.5
+    ref = ops.decode_attention(c["q"].float(), kw, vw, c["req_to_token"], c["req_pool_indices"], c["seq_lens"], scale)
+    vmax = float(vw.abs().max())
+    for chunk in (64, 512):
+        ws = torch.empty(_native.decode_workspace_bytes(bs, Hq, D, max(lens), chunk), dtype=torch.uint8, device=DEV)
+        o = torch.full_like(p["q"], float("nan"))
+        _native.decode_attention(o, p["q"], p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"],
+                                 p["seq_lens"], scale, 0.0, max(lens), chunk, ws, None, None, k_scale=ks, v_scale=vs)
+        assert_close(o, ref, dtype, what=f"scaled fp8 decode chunk {chunk}", vmax=vmax)
+    o1 = torch.full_like(p["q"], float("nan"))
+    ws = torch.empty(_native.decode_workspace_bytes(bs, Hq, D, max(lens), 64), dtype=torch.uint8, device=DEV)
+    _native.decode_attention(o1, p["q"], p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"],
+                             p["seq_lens"], scale, 0.0, max(lens), 64, ws)
+    assert float((o1.float() - o.float()).abs().max()) > 0.05, "the scales change the result"
+    # extend: every row of every request is new (prefix 0)
+    g = torch.Generator().manual_seed(76)
+    q = torch.randn(sum(lens), Hq, D, generator=g).to(dtype).to(DEV)
+    ext_t = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    start = torch.zeros(bs, dtype=torch.int32, device=DEV)
+    start[1:] = torch.cumsum(ext_t[:-1], 0)
+    ws = torch.empty(_native.extend_workspace_bytes(sum(lens), bs, Hq, D, dtype), dtype=torch.uint8, device=DEV)
+    oe = torch.full_like(q, float("nan"))
+    _native.extend_attention(oe, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"],
+                             p["seq_lens"], ext_t, start, scale, 0.0, True, max(lens), max(lens), ws,
+                             k_scale=ks, v_scale=vs)
+    refe = ops.extend_attention(q.cpu().float(), kw, vw, c["req_to_token"], c["req_pool_indices"], c["seq_lens"],
+                                ext_t.cpu(), start.cpu(), scale)
+    assert_close(oe, refe, dtype, what="scaled fp8 extend", vmax=vmax)
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        _native.decode_attention(o, p["q"], p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"],
+                                 p["seq_lens"], scale, 0.0, max(lens), 64, ws, k_scale=0.0)
 
 
 def _fp8_problem(seed, bs, Hq, Hkv, D, lens, dtype):

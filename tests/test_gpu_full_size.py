@@ -1,0 +1,168 @@
+"""BASELINE.json's configurations at their FULL sizes, through size-independent properties plus spot
+rows against the oracle (the oracle itself cannot run these sizes in test time):
+
+  config 2  Llama-3-8B head shape, bs = 256 decode, contexts U[128, 4096], random slot permutation
+  config 3  Llama-3-8B head shape, bs = 64 ragged prefill, prompt lengths U[128, 4096]
+
+16-bit outputs are held to the error model of helpers.attn_error_units (units of u * (|ref| + A))."""
+import pytest
+import torch
+
+from oracle import ops
+from tests.helpers import DTYPES, assert_attn_close, attn_error_units
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+HQ, HKV, D = 32, 8, 128
+SCALE = D ** -0.5
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from scratchpad_amd import _native
+    _native.load()
+    return _native
+
+
+def big_pool(seed, lens, dtype, extra=64):
+    """K/V pools and a fragmented req_to_token for the given context lengths, generated on the GPU."""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    gc = torch.Generator().manual_seed(seed)
+    total = sum(lens)
+    P = total + extra
+    kb = torch.empty(P + 1, HKV, D, dtype=dtype, device=DEV).normal_(0, 1, generator=g)
+    vb = torch.empty(P + 1, HKV, D, dtype=dtype, device=DEV).normal_(0, 1, generator=g)
+    perm = (torch.randperm(P, generator=gc) + 1).to(torch.int32)
+    bs = len(lens)
+    r2t = torch.zeros(bs, max(lens) + 8, dtype=torch.int32)
+    off = 0
+    for b, n in enumerate(lens):
+        r2t[b, :n] = perm[off:off + n]
+        off += n
+    return kb, vb, r2t.to(DEV)
+
+
+def oracle_rows(q_rows, kb, vb, r2t, req_rows, seq_rows, abs_v=False):
+    """fp32 oracle for single query rows: row i attends to the first seq_rows[i] keys of request req_rows[i]."""
+    v = vb.float().cpu()
+    return ops.decode_attention(q_rows.float().cpu(), kb.float().cpu(), v.abs() if abs_v else v, r2t.cpu(),
+                                torch.tensor(req_rows), torch.tensor(seq_rows), SCALE)
+
+
+def run_decode(nat, q, kb, vb, r2t, req, seq, chunk, plan=True):
+    bs = q.shape[0]
+    max_len = int(seq.max())
+    ws = torch.empty(nat.decode_workspace_bytes(bs, HQ, D, max_len, chunk), dtype=torch.uint8, device=DEV)
+    o = torch.full_like(q, float("nan"))
+    pl = None
+    if plan:
+        pl = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk) // 4, dtype=torch.int32, device=DEV)
+        nat.decode_plan(pl, seq, max_len, chunk)
+    nat.decode_attention(o, q, kb, vb, r2t, req, seq, SCALE, 0.0, max_len, chunk, ws, None, pl)
+    return o
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_config2_decode_bs256_full_size(nat, dt):
+    dtype = DTYPES[dt]
+    gen = torch.Generator().manual_seed(0)
+    bs = 256
+    lens = torch.randint(128, 4097, (bs,), generator=gen).tolist()       # bench.py's contexts (seed 0)
+    lens[3], lens[200] = 4096, 128
+    kb, vb, r2t = big_pool(2, lens, dtype)
+    q = torch.randn(bs, HQ, D, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)).to(dtype)
+    req = torch.arange(bs, device=DEV)
+    seq = torch.tensor(lens, device=DEV)
+    o512 = run_decode(nat, q, kb, vb, r2t, req, seq, 512)
+    assert torch.isfinite(o512.float()).all()
+    # (a) 8 spot rows against the fp32 oracle, error model without a max-scaled allowance
+    rows = [0, 3, 17, 64, 129, 200, 254, 255]
+    ref = oracle_rows(q[rows], kb, vb, r2t, rows, [lens[i] for i in rows])
+    aref = oracle_rows(q[rows], kb, vb, r2t, rows, [lens[i] for i in rows], abs_v=True)
+    assert_attn_close(o512[rows], ref, aref, dtype, what=f"config 2 bs=256 {dt}: 8 rows vs oracle")
+    # (b) split invariance at full size: the split size changes the partial sums, not the softmax; each
+    # result is within the model of the oracle rows, and the two roundings differ by at most 2 units
+    for chunk in (64, 256):
+        oc = run_decode(nat, q, kb, vb, r2t, req, seq, chunk, plan=chunk == 64)
+        assert_attn_close(oc[rows], ref, aref, dtype, what=f"config 2 {dt}: chunk {chunk} rows vs oracle")
+        diff = (oc.float() - o512.float()).abs()
+        u = {torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8}[dtype]
+        assert float(diff.max()) <= 2.5 * u * float(vb.float().abs().max()), f"chunk {chunk} vs 512: {float(diff.max()):.3e}"
+    # (c) KV page indexing is bit-exact: relocate every row of the pool (and the table) - same bits
+    P1 = kb.shape[0]
+    perm = torch.randperm(P1 - 1, generator=gen).to(DEV) + 1
+    perm = torch.cat([torch.zeros(1, dtype=torch.int64, device=DEV), perm])
+    kb2, vb2 = torch.empty_like(kb), torch.empty_like(vb)
+    kb2[perm], vb2[perm] = kb, vb
+    r2t2 = perm[r2t.long()].to(torch.int32)
+    assert torch.equal(run_decode(nat, q, kb2, vb2, r2t2, req, seq, 512), o512)
+    # (d) request-order invariance: a permuted batch gives the permuted rows, bit for bit
+    order = torch.randperm(bs, generator=gen).to(DEV)
+    o_perm = run_decode(nat, q[order].contiguous(), kb, vb, r2t, req[order].contiguous(), seq[order].contiguous(), 512)
+    assert torch.equal(o_perm, o512[order])
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_config3_extend_bs64_full_size(nat, dt):
+    dtype = DTYPES[dt]
+    gen = torch.Generator().manual_seed(0)
+    bs = 64
+    lens = torch.randint(128, 4097, (bs,), generator=gen).tolist()       # bench.py's prompt lengths (seed 0)
+    lens[5], lens[40] = 4096, 128
+    kb, vb, r2t = big_pool(4, lens, dtype)
+    T = sum(lens)
+    q = torch.randn(T, HQ, D, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)).to(dtype)
+    req = torch.arange(bs, device=DEV)
+    seq = torch.tensor(lens, device=DEV)
+    ext = seq.to(torch.int32)
+    start = torch.zeros(bs, dtype=torch.int32, device=DEV)
+    start[1:] = torch.cumsum(ext[:-1], 0)
+    ws = torch.empty(nat.extend_workspace_bytes(T, bs, HQ, D, dtype), dtype=torch.uint8, device=DEV)
+
+    def run(plan):
+        o = torch.full_like(q, float("nan"))
+        nat.extend_attention(o, q, kb, vb, r2t, req, seq, ext, start, SCALE, 0.0, True, max(lens), max(lens), ws,
+                             plan=plan)
+        return o
+    plan = nat.extend_plan(ext, seq, T, HQ, HKV, True)
+    o = run(plan)
+    assert torch.isfinite(o.float()).all()
+    assert torch.equal(run(None), o), "the work plan changes nothing"
+    starts = start.cpu().tolist()
+    # (a) spot rows (first, interior, block edges, last) of several requests against the fp32 oracle
+    spots = [(5, 0), (5, 63), (5, 64), (5, 2047), (5, 4095), (40, 127), (0, lens[0] - 1), (17, lens[17] // 2),
+             (63, lens[63] - 1), (33, 1)]
+    tok = [starts[b] + t for b, t in spots]
+    ref = oracle_rows(q[tok], kb, vb, r2t, [b for b, _ in spots], [t + 1 for _, t in spots])
+    aref = oracle_rows(q[tok], kb, vb, r2t, [b for b, _ in spots], [t + 1 for _, t in spots], abs_v=True)
+    assert_attn_close(o[tok], ref, aref, dtype, what=f"config 3 bs=64 {dt}: {len(spots)} rows vs oracle")
+    # (b) the last row of EVERY prompt is a decode step over the same keys: decode kernel vs extend kernel
+    last = [starts[b] + lens[b] - 1 for b in range(bs)]
+    od = torch.full_like(q[last], float("nan"))
+    wsd = torch.empty(nat.decode_workspace_bytes(bs, HQ, D, max(lens), 512), dtype=torch.uint8, device=DEV)
+    nat.decode_attention(od, q[last].contiguous(), kb, vb, r2t, req, seq, SCALE, 0.0, max(lens), 512, wsd)
+    aall = oracle_rows(q[last], kb, vb, r2t, list(range(bs)), lens, abs_v=True)
+    rall = oracle_rows(q[last], kb, vb, r2t, list(range(bs)), lens)
+    assert_attn_close(o[last], rall, aall, dtype, what=f"config 3 {dt}: last rows (extend kernel) vs oracle")
+    assert_attn_close(od, rall, aall, dtype, what=f"config 3 {dt}: last rows (decode kernel) vs oracle")
+    # (c) chunked prefill (the server splits at 8192 new tokens, server/args.py:33-34): a prompt that is
+    # cut in two - first part with no prefix, second part behind it as a cached prefix - gives the
+    # unchunked rows again (another summation order: equal within the model, not bit for bit)
+    for b, cut in ((5, 2048), (5, 1000), (0, 100), (17, lens[17] - 1)):
+        L = lens[b]
+        one = torch.tensor([b], device=DEV)
+        o2 = torch.full_like(q[starts[b]:starts[b] + L], float("nan"))
+        z = torch.zeros(1, dtype=torch.int32, device=DEV)
+        nat.extend_attention(o2[:cut], q[starts[b]:starts[b] + cut], kb, vb, r2t, one, torch.tensor([cut], device=DEV),
+                             torch.tensor([cut], dtype=torch.int32, device=DEV), z, SCALE, 0.0, True, cut, cut, ws)
+        nat.extend_attention(o2[cut:], q[starts[b] + cut:starts[b] + L], kb, vb, r2t, one, torch.tensor([L], device=DEV),
+                             torch.tensor([L - cut], dtype=torch.int32, device=DEV), z, SCALE, 0.0, True, L - cut, L, ws)
+        whole = o[starts[b]:starts[b] + L]
+        u = {torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8}[dtype]
+        diff = float((o2.float() - whole.float()).abs().max())
+        assert diff <= 2.5 * u * float(vb.float().abs().max()), f"chunked at {cut}: {diff:.3e}"
+        same = float((o2 == whole).float().mean())
+        print(f"[parity] config 3 {dt}: request {b} cut at {cut}: {100 * same:.1f} % of the outputs bit-identical, "
+              f"max |diff| {diff:.2e}")
+        # rows of the first part see exactly the same keys in the same tiles: bit for bit
+        assert torch.equal(o2[:cut // 64 * 64], whole[:cut // 64 * 64])

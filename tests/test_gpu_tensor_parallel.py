@@ -308,7 +308,9 @@ def _rccl_single_main(port, q):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread-local capture mode, as HipGraphRunner uses: the process group's watchdog thread keeps
+        # polling events while this thread captures (global mode makes that an error)
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             ys = xs * 2
             dist.all_reduce(ys)
             zs = ys + 1
@@ -328,6 +330,17 @@ def test_rccl_all_reduce_inside_a_hip_graph_single_rank():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_single_main, args=(_free_port(), q))
     p.start()
-    rank, err = q.get(timeout=300)
-    p.join(timeout=60)
+    import queue as _queue
+    err = "no result"
+    for _ in range(120):                     # <= 2 minutes, and notice a dead child at once
+        try:
+            _, err = q.get(timeout=1)
+            break
+        except _queue.Empty:
+            if not p.is_alive():
+                err = f"the rank process died (exit code {p.exitcode})"
+                break
+    p.join(timeout=30)
+    if p.is_alive():
+        p.kill()
     assert err is None, err
