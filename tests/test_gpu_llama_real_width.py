@@ -7,8 +7,12 @@ dtype (every op rounding its output, as torch does).
 The tiny-model tests (test_gpu_llama.py) use fixtures whose values are exact in bf16, so rounding and
 accumulation order cannot show there; here every GEMM has K = 4096 / 14336 of non-trivial operands, so
 an accumulation-order or rounding regression in any kernel of the path moves the logits.
-Measured deviations (max |logit - ref| / max |ref|) are printed; the asserted bounds sit ~2x above
-what MI355X measured when the test was written (see the assertion messages)."""
+Measured on MI355X (max |logit - ref| / max |ref| over prefill + 2 decode steps; printed by the test):
+  fp16: HIP vs fp32 oracle 1.7e-3 .. 2.1e-3, HIP vs fp16 oracle 1.2e-3 .. 1.3e-3  (fp16 oracle vs fp32: 1.9e-3 .. 2.1e-3)
+  bf16: HIP vs fp32 oracle 1.3e-2 .. 1.6e-2, HIP vs bf16 oracle 0.9e-2 .. 1.1e-2  (bf16 oracle vs fp32: 1.4e-2 .. 1.6e-2)
+i.e. with N(0, 0.02) weights (small logits) a 16-bit evaluation of these layers is itself 2e-3 / 1.5e-2
+of the logit scale away from fp32, torch's as much as ours; the HIP path is never further from fp32 than
+torch's own 16-bit evaluation.  The asserted bounds sit ~1.5x above the measurements."""
 import pytest
 import torch
 
@@ -18,7 +22,7 @@ from oracle import ops
 pytestmark = pytest.mark.gpu
 
 # asserted bounds on max|dlogit| / max|logit|: (vs fp32 oracle, vs same-dtype oracle)
-BOUNDS = {torch.float16: (2e-3, 2e-3), torch.bfloat16: (2.5e-2, 2.5e-2)}
+BOUNDS = {torch.float16: (3e-3, 2e-3), torch.bfloat16: (2.5e-2, 1.6e-2)}
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
@@ -78,4 +82,4 @@ def test_real_width_layers_against_fp32_and_same_dtype_oracle(dtype):
         assert d16 <= b16, f"{what}: {d16:.2e} of max|logit| vs the {name} oracle (bound {b16:.1e})"
         # the HIP path (fp32 accumulation inside every kernel, one rounding per op) must not be further
         # from the truth than torch's own 16-bit evaluation by more than a factor
-        assert d32 <= 2.0 * dor + 1e-4, f"{what}: HIP {d32:.2e} vs oracle-in-{name} {dor:.2e}"
+        assert d32 <= 1.25 * dor + 1e-4, f"{what}: HIP {d32:.2e} vs oracle-in-{name} {dor:.2e}"
