@@ -271,3 +271,57 @@ def test_ring_allocators_match_a_list_model_across_wraps():
                 rows.free(back)
                 rmodel.extend(back)
         assert rows.available_size() == len(rmodel) and rows.free_slots == rmodel
+
+
+def test_mixed_batch_merges_sampling_info_like_the_reference():
+    """mix_with_running goes through merge_batch (schedule_batch.py:1073-1101, 1361-1397): the running
+    decodes' sampling parameters, pending output ids and request list are merged in request order - a
+    running request that samples with temperature must not silently become greedy in a MIXED batch."""
+    from scratchpad_amd.sampler import SamplingBatchInfo, SamplingParams
+    from scratchpad_amd.schedule_batch import Req, ScheduleBatch
+
+    def batches(prefill_params, running_params):
+        r2t = ReqToTokenPool(8, 16, "cpu")
+        alloc = TokenToKVPoolAllocator(32, torch.float32, "cpu", None)
+        new = ScheduleBatch([Req("n0", [1, 2, 3, 4], sampling_params=prefill_params)], r2t, alloc, "cpu")
+        new.forward_mode = ForwardMode.EXTEND
+        new.input_ids = torch.tensor([1, 2, 3, 4])
+        new.out_cache_loc = torch.tensor([10, 11, 12, 13])
+        new.req_pool_indices = torch.tensor([0])
+        new.seq_lens = torch.tensor([4])
+        new.seq_lens_sum, new.extend_num_tokens = 4, 4
+        new.prefix_lens, new.extend_lens = [0], [4]
+        run = ScheduleBatch([Req("r0", [5, 6], output_ids=[7], sampling_params=running_params[0]),
+                             Req("r1", [8], output_ids=[9, 9], sampling_params=running_params[1])], r2t, alloc, "cpu")
+        run.forward_mode = ForwardMode.DECODE
+        run.input_ids = torch.tensor([7, 9])
+        run.out_cache_loc = torch.tensor([20, 21])
+        run.req_pool_indices = torch.tensor([1, 2])
+        run.seq_lens = torch.tensor([3, 3])
+        run.seq_lens_sum = 6
+        for b in (new, run):
+            if any(getattr(r, "sampling_params", None) is not None for r in b.reqs):
+                b.sampling_info = SamplingBatchInfo.from_schedule_batch(b, 100)
+        return new, run
+
+    hot = SamplingParams(temperature=0.7, top_k=40, top_p=0.9)
+    # prefill greedy (no info at all), running requests sample: the merged info has 3 rows in request order
+    new, run = batches(None, (hot, None))
+    assert new.sampling_info is None and run.sampling_info is not None
+    new.mix_with_running(run)
+    assert new.forward_mode == ForwardMode.MIXED and [r.rid for r in new.reqs] == ["n0", "r0", "r1"]
+    assert new.input_ids.tolist() == [1, 2, 3, 4, 7, 9] and new.out_cache_loc.tolist() == [10, 11, 12, 13, 20, 21]
+    assert new.extend_lens == [4, 1, 1] and new.prefix_lens == [0, 2, 2] and new.extend_num_tokens == 6
+    assert new.seq_lens.tolist() == [4, 3, 3] and new.seq_lens_sum == 10
+    info = new.sampling_info
+    assert len(info) == 3 and not info.is_all_greedy
+    assert info.top_ks.tolist() == [1, 40, 1] and info.temperatures.view(-1).tolist() == pytest.approx([1.0, 0.7, 1.0])
+    assert new.get_model_worker_batch().sampling_info is info
+    # the other way round, and the overlap scheduler's prefix_lens (output_ids lags one step)
+    new, run = batches(hot, (None, None))
+    new.mix_with_running(run, enable_overlap=True)
+    assert new.sampling_info.top_ks.tolist() == [40, 1, 1] and new.prefix_lens == [0, 3, 3]
+    # nobody samples: the batch stays "all greedy" without materialising anything
+    new, run = batches(None, (None, None))
+    new.mix_with_running(run)
+    assert new.sampling_info is None and len(new.reqs) == 3

@@ -17,18 +17,25 @@ tail -8 $R/sampling.log
 timeout -k 10 400 python bench.py --mode serve > $R/bench_serve.json 2> $R/bench_serve.err || { tail -20 $R/bench_serve.err; exit 1; }
 tail -1 $R/bench_serve.json | cut -c1-300
 timeout -k 10 400 python bench.py --mode serve --prefix 512 > $R/bench_serve_prefix.json 2> $R/bench_serve_prefix.err || { tail -20 $R/bench_serve_prefix.err; exit 1; }
-for b in 1 8 32; do timeout -k 10 200 python bench.py --bs $b --ctx 1024 --no-cpu-baseline 2>/dev/null | tail -1 > $R/bench_bs$b.json || exit 1; cut -c1-140 $R/bench_bs$b.json; done
-for c in 128 1024 4096; do timeout -k 10 300 python bench.py --ctx $c --no-cpu-baseline 2>/dev/null | tail -1 > $R/bench_ctx$c.json || exit 1; done
-timeout -k 10 300 python bench.py --kv-cache-dtype fp8_e5m2 --no-cpu-baseline 2>/dev/null | tail -1 > $R/bench_fp8kv.json || exit 1
+for b in 1 8 32; do timeout -k 10 200 python bench.py --bs $b --ctx 1024 --no-cpu-baseline --no-ttft 2>/dev/null | tail -1 > $R/bench_bs$b.json || exit 1; cut -c1-140 $R/bench_bs$b.json; done
+for c in 128 1024 4096; do timeout -k 10 300 python bench.py --ctx $c --no-cpu-baseline --no-ttft 2>/dev/null | tail -1 > $R/bench_ctx$c.json || exit 1; done
+timeout -k 10 300 python bench.py --kv-cache-dtype fp8_e5m2 --no-cpu-baseline --no-ttft 2>/dev/null | tail -1 > $R/bench_fp8kv.json || exit 1
 cut -c1-140 $R/bench_fp8kv.json
-timeout -k 10 300 python bench.py --model llama3-70b-tp8-rank --bs 128 --no-cpu-baseline 2>/dev/null | tail -1 > $R/bench_70b_rank.json || exit 1
+timeout -k 10 300 python bench.py --model llama3-70b-tp8-rank --bs 128 --no-cpu-baseline --no-ttft 2>/dev/null | tail -1 > $R/bench_70b_rank.json || exit 1
+# config 4 rehearsals on this 1-GPU box (ranks share the GPU: gloo, or the direct IPC all-reduce) and the
+# self-launching replica mode; the real thing needs the 8-GPU node: python bench.py --mode tp --gpus 8
+timeout -k 10 300 python bench.py --mode tp --gpus 2 --tp 2 --layers 8 --steps 8 --warmup 2 2>/dev/null | tail -1 > $R/bench_tp2_rehearsal_gloo.json || exit 1
+SP_CUSTOM_ALLREDUCE=1 timeout -k 10 300 python bench.py --mode tp --gpus 2 --tp 2 --layers 8 --steps 8 --warmup 2 2>/dev/null | tail -1 > $R/bench_tp2_rehearsal_direct.json || exit 1
+timeout -k 10 300 python bench.py --gpus 2 --layers 8 --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $R/bench_replicas2_rehearsal.json || exit 1
+cut -c1-200 $R/bench_tp2_rehearsal_gloo.json
+timeout -k 10 200 python tools/stamp_extend_attn.py --waves 8 > $R/extend_stamps.log 2>&1 || { tail -5 $R/extend_stamps.log; exit 1; }
 timeout -k 10 500 python tools/bench_mllama.py > $R/mllama.log 2>&1 || { tail -20 $R/mllama.log; exit 1; }
 grep mllama $R/mllama.log
 timeout -k 10 300 python tools/bench_gemv.py > $R/gemv.log 2>&1 || { tail -20 $R/gemv.log; exit 1; }
 grep "per-layer" $R/gemv.log
 fi
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$R/prof -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 4 --no-cpu-baseline > $GRAFT_REPO_ROOT/$R/prof_bench.json 2> $GRAFT_REPO_ROOT/$R/prof.err || { tail -20 $GRAFT_REPO_ROOT/$R/prof.err; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$R/prof -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-ttft > $GRAFT_REPO_ROOT/$R/prof_bench.json 2> $GRAFT_REPO_ROOT/$R/prof.err || { tail -20 $GRAFT_REPO_ROOT/$R/prof.err; exit 1; }
 cd $GRAFT_REPO_ROOT
 STATS=$(find $R/prof -name "*kernel_stats.csv" | head -1)
 TRACE=$(find $R/prof -name "*kernel_trace.csv" | head -1)
