@@ -281,6 +281,33 @@ __global__ __launch_bounds__(kSampThreads) void select_kernel(SelectArgs a) {
   }
 }
 
+// per-thread scan of a row for (maximum, first index): 16-byte loads (8 x 16-bit or 4 x fp32 values) when
+// the row allows it - a 2-byte load per lane leaves the memory pipeline at a quarter of its rate
+template <typename Tag>
+__device__ __forceinline__ void thread_argmax(const void* __restrict__ logits, int64_t base, int cols, int tid,
+                                              float& best, int& idx) {
+  constexpr int V = Elem<Tag>::kVec;
+  best = -INFINITY;
+  idx = 0x7fffffff;
+  const char* row = (const char*)logits + base * Elem<Tag>::kBytes;
+  int done = 0;
+  if ((((uintptr_t)row) & 15) == 0) {
+    const int nvec = cols / V;
+    for (int i = tid; i < nvec; i += kSampThreads) {
+      float f[V];
+      unpack16<Tag>(ld16(row + (int64_t)i * 16), f);
+#pragma unroll
+      for (int e = 0; e < V; ++e)
+        if (f[e] > best || idx == 0x7fffffff) { best = f[e]; idx = i * V + e; }   // ids ascend per thread
+    }
+    done = nvec * V;
+  }
+  for (int i = done + tid; i < cols; i += kSampThreads) {
+    const float v = Elem<Tag>::load(logits, base + i);
+    if (v > best || idx == 0x7fffffff || (v == best && i < idx)) { best = v; idx = i; }
+  }
+}
+
 // ---- greedy argmax (sampler.py:63-65): first maximal index, NaN-free input assumed -----------
 template <typename Tag>
 __global__ __launch_bounds__(kSampThreads) void argmax_kernel(const void* __restrict__ logits, int64_t row_stride,
@@ -289,12 +316,9 @@ __global__ __launch_bounds__(kSampThreads) void argmax_kernel(const void* __rest
   __shared__ int s_idx[kSampWaves];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t base = (int64_t)b * row_stride;
-  float best = -INFINITY;
-  int idx = 0x7fffffff;
-  for (int i = tid; i < vocab; i += kSampThreads) {
-    const float v = Elem<Tag>::load(logits, base + i);
-    if (v > best || idx == 0x7fffffff) { best = v; idx = i; }   // strided ids ascend per thread
-  }
+  float best;
+  int idx;
+  thread_argmax<Tag>(logits, base, vocab, tid, best, idx);
   auto better = [](float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); };
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -324,12 +348,9 @@ __global__ __launch_bounds__(kSampThreads) void argmax_shard_kernel(const void* 
   __shared__ int s_idx[kSampWaves];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t base = (int64_t)b * row_stride;
-  float best = -INFINITY;
-  int idx = 0x7fffffff;
-  for (int i = tid; i < cols; i += kSampThreads) {
-    const float v = Elem<Tag>::load(logits, base + i);
-    if (v > best || idx == 0x7fffffff) { best = v; idx = i; }
-  }
+  float best;
+  int idx;
+  thread_argmax<Tag>(logits, base, cols, tid, best, idx);
   auto better = [](float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); };
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {

@@ -199,3 +199,38 @@ def test_sampler_module_greedy_and_stochastic_paths():
     assert int(ids[2]) == int(logits[2].argmax())      # the greedy request inside a sampling batch
     with pytest.raises(ValueError):
         SamplingParams(top_p=0.0).verify()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_argmax_vector_path_ties_tails_and_vocab_shards(dtype):
+    """sp_argmax on 16-bit logits (16-byte loads, unaligned rows, ragged tails) returns torch.argmax's first
+    maximal index, and the vocab-parallel form (sp_argmax_shard per shard -> [bs, 2] words -> sp_argmax_merge)
+    returns the same ids as the argmax of the concatenated row - including ties across shards and shards
+    whose real-vocabulary columns are fewer than their width (padding columns must never win)."""
+    from scratchpad_amd import _native
+    g = torch.Generator().manual_seed(17)
+    bs, vocab = 9, 128256
+    logits = (torch.randn(bs, vocab, generator=g) * 3).to(dtype)
+    logits[1, 5] = logits[1, 77777] = 50.0            # tie: the first index wins
+    logits[2, vocab - 1] = 60.0                       # the maximum sits in the ragged tail
+    logits[3, 0] = 60.0
+    logits[4] = 1.0                                   # a constant row: index 0
+    dev = logits.cuda()
+    want = logits.float().argmax(-1)
+    assert torch.equal(_native.argmax(dev).cpu(), want)
+    odd = dev[:, 3:vocab - 5]                         # rows that start off a 16-byte boundary, odd length
+    assert torch.equal(_native.argmax(odd).cpu(), logits[:, 3:vocab - 5].float().argmax(-1))
+    # 8 shards of a vocabulary padded to 8 x 16064 (the last shard holds 15808 real columns + padding)
+    tp, width = 8, 16064
+    padded = torch.full((bs, tp * width), 99.0, dtype=dtype)      # padding columns hold a LARGER value
+    padded[:, :vocab] = logits
+    pairs = []
+    for r in range(tp):
+        shard = padded[:, r * width:(r + 1) * width].contiguous().cuda()
+        cols = max(0, min(width, vocab - r * width))
+        pairs.append(_native.argmax_shard(shard, cols, r * width))
+    ids = _native.argmax_merge(torch.stack(pairs).contiguous())
+    assert torch.equal(ids.cpu(), want)
+    empty = _native.argmax_shard(padded[:, :8].contiguous().cuda(), 0, 12345)     # a shard of padding only
+    assert torch.equal(_native.argmax_merge(torch.stack([pairs[0], empty]).contiguous()).cpu(),
+                       logits[:, :width].float().argmax(-1))
