@@ -49,5 +49,6 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
 // test / tuning hooks behind sp_debug_set
 void set_decode_kernel(int which);
 void set_extend_defer_x10(int tenths);
+void set_extend_dma(int v);
 
 }  // namespace sp

@@ -130,6 +130,7 @@ extern "C" int sp_debug_set(const char* key, int value) {
   SP_CHECK_ARG(key);
   if (!strcmp(key, "decode_kernel")) { set_decode_kernel(value); return SP_OK; }
   if (!strcmp(key, "extend_defer_x10")) { set_extend_defer_x10(value); return SP_OK; }
+  if (!strcmp(key, "extend_dma")) { set_extend_dma(value); return SP_OK; }
   return SP_ERR_INVALID_ARG;
 }
 

@@ -52,8 +52,9 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #endif
 
 // PLAIN: no logit cap and no sliding window (both compiled out of the tile loop)
-template <typename Tag, int D, int GK, int NW, bool KV8, bool PLAIN>
+template <typename Tag, int D, int GK, int NW, bool KV8, bool PLAIN, bool DMA>
 __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
+  static_assert(!DMA || (D == 128 && !KV8 && NW == 8), "the LDS-DMA image is laid out for 256-byte rows and 8 waves");
   constexpr int NT = NW * 64;
   constexpr int NB = 2;                // LDS tile buffers: tile t lives in buffer t & 1
   typedef ExtCfg<D, NT> C;
@@ -111,6 +112,8 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
       if constexpr (KV8 && std::is_same<Tag, bf16_tag>::value) qf[ks] = bf16x8_to_f16x8(qf[ks]);
     }
   }
+  // DMA: the Q loads stay ahead of the first DMA pieces, so that the prologue's counted wait covers them
+  if constexpr (DMA) __builtin_amdgcn_sched_barrier(0);
   const float cap = PLAIN ? 0.f : a.logit_cap;
   // scores enter the exponent as exp2(s * sc - m): sc carries the softmax scale (the capped form
   // rewrites s into the log2 domain first, so its sc is 1)
@@ -181,6 +184,13 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
   // tr-read address pieces: lane i of a 16-lane group supplies row (i>>2), columns 4*(i&3)..+3
   const int i16 = lane & 15, g16 = lane >> 4;
   const int tr_rowq = i16 >> 2, tr_col = ((g16 & 1) * 16 + (i16 & 3) * 4) * 2;  // bytes
+  // LDS-DMA image (DMA): rows of 256 B without padding (a DMA piece is 1 KiB of consecutive LDS = 4 rows),
+  // made conflict-free by the SOURCE address each lane asks for: K row r keeps its 16-byte chunk c at
+  // position c ^ (r & 15) (ds_read_b128 serves 16 lanes = 16 different rows mod 16 at a time), V row r
+  // keeps chunk c at c ^ ((r & 3) << 2) (a transposed read serves 4 rows x 64 B per 32 lanes).  Three
+  // K and three V buffers: tile t is consumed from buffer t % 3 while t+1 and t+2 are in flight.
+  constexpr int kDmaTile = 64 * 256;
+  const int k_swz = (c & 15) ^ h;
 
   // pipeline: the gathers of tiles t+1 and t+2 fly during compute(t); tile t+1 is written to the other
   // LDS buffer right after compute(t), and one barrier per tile both publishes tile t+1 and retires
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
   // S^T, mask, online softmax of tile t from LDS buffer `buf`; leaves P^T packed in pf (B operands of
   // the four 16-key k-steps).  Returns false when the wave has no visible key in the tile.
   auto qk_softmax = [&](int t, int buf, u32x4 (&pf)[4]) __attribute__((always_inline)) -> bool {
-    const char* ldsK = lds + buf * C::kTileBytes;
+    const char* ldsK = DMA ? lds + buf * kDmaTile : lds + buf * C::kTileBytes;
     const int key0 = t * BN;
     // a wave skips tiles that lie entirely above its rows' diagonal (wave-uniform)
     const bool visible = wave_live && (!a.causal || key0 <= P + min(r0 + 31, E - 1)) &&
@@ -204,14 +214,14 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-      const char* kp = ldsK + (kb * 32 + c) * SK + h * 16;
+      const char* kp = DMA ? ldsK + kb * 32 * 256 + c * 256 : ldsK + (kb * 32 + c) * SK + h * 16;
       // all fragment reads of the block are issued before its first MFMA (distinct registers), so
       // one LDS latency is exposed per block instead of one per MFMA; the sched_barrier keeps the
       // scheduler from sinking each read next to its MFMA again (it then reuses one register quad
       // and waits lgkmcnt(0) before every MFMA)
       u32x4 kf[KSTEPS];
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) kf[ks] = ld16(kp + ks * 32);
+      for (int ks = 0; ks < KSTEPS; ++ks) kf[ks] = ld16(DMA ? kp + (((2 * ks) ^ k_swz) << 4) : kp + ks * 32);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) s[kb] = mfma32<CT>(kf[ks], qf[ks], s[kb]);
@@ -278,6 +288,53 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
   };
   // ---- O^T += V^T . P^T with the V tile of LDS buffer `buf`
   auto pv = [&](int buf, const u32x4 (&pf)[4]) __attribute__((always_inline)) {
+    if constexpr (DMA) {
+      // The transposed reads are issued as asm text: hipcc puts s_waitcnt vmcnt(0) in front of every
+      // ds_read_tr INTRINSIC while LDS-DMA is in flight (it cannot tell that the pieces in flight go to
+      // another buffer), which would drain the two tiles of prefetch once per tile.  Their arrival
+      // is therefore counted by hand: the reads of k-step s+1 are issued before the wait for k-step s
+      // (8 reads per k-step, LDS returns in order), and the wait is tied to the registers it covers so
+      // that no MFMA can be scheduled above it.
+      uint32_t va[DBLK];
+      {
+        const uint32_t vbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds +
+                               (3 + buf) * kDmaTile + (4 * h + tr_rowq) * 256 + tr_col;
+#pragma unroll
+        for (int db = 0; db < DBLK; ++db) va[db] = vbase + ((db ^ tr_rowq) << 6);
+      }
+      u32x2 lo[2][DBLK], hi[2][DBLK];
+#define SP_TR_ISSUE(SET, STEP)                                                                       \
+  _Pragma("unroll") for (int db = 0; db < DBLK; ++db) {                                              \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[SET][db]) : "v"(va[db]), "n"((STEP) * 16 * 256));          \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[SET][db]) : "v"(va[db]), "n"((STEP) * 16 * 256 + 2048));   \
+  }
+#define SP_TR_WAIT(SET, N)                                                                           \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                           \
+               : "+v"(lo[SET][0]), "+v"(lo[SET][1]), "+v"(lo[SET][2]), "+v"(lo[SET][3]),             \
+                 "+v"(hi[SET][0]), "+v"(hi[SET][1]), "+v"(hi[SET][2]), "+v"(hi[SET][3]))
+#define SP_TR_MFMA(SET, STEP)                                                                        \
+  _Pragma("unroll") for (int db = 0; db < DBLK; ++db) {                                              \
+    u32x4 vf;                                                                                        \
+    vf[0] = lo[SET][db][0]; vf[1] = lo[SET][db][1]; vf[2] = hi[SET][db][0]; vf[3] = hi[SET][db][1];  \
+    oacc[db] = mfma32<CT>(vf, pf[STEP], oacc[db]);                                                   \
+  }
+      static_assert(!DMA || DBLK == 4, "wait lists are written for four d blocks");
+      SP_TR_ISSUE(0, 0)
+      SP_TR_ISSUE(1, 1)
+      SP_TR_WAIT(0, 8);
+      SP_TR_MFMA(0, 0)
+      SP_TR_ISSUE(0, 2)
+      SP_TR_WAIT(1, 8);
+      SP_TR_MFMA(1, 1)
+      SP_TR_ISSUE(1, 3)
+      SP_TR_WAIT(0, 8);
+      SP_TR_MFMA(0, 2)
+      SP_TR_WAIT(1, 0);
+      SP_TR_MFMA(1, 3)
+#undef SP_TR_ISSUE
+#undef SP_TR_WAIT
+#undef SP_TR_MFMA
+    } else {
     const char* ldsV = lds + buf * C::kTileBytes + BN * SK;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -303,8 +360,72 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
         for (int db = 0; db < DBLK; ++db) oacc[db] = mfma32<CT>(vf[db], pf[kb * 2 + sidx], oacc[db]);
       }
     }
+    }
   };
 
+  if constexpr (DMA) {
+    const int dR = lane >> 4, dp = lane & 15;
+    const int64_t row_off = (int64_t)hk * D * 2;
+    struct Slots { int s[2]; };
+    Slots s0, s1, s2;   // slot indices of tiles x with (x - tbeg) % 3 == 0, 1, 2
+    auto load_slots = [&](Slots& r, int tile) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int key = tile * BN + wave * 8 + 4 * j + dR;
+        r.s[j] = idx_row[max(min(key, kv_len - 1), 0)];   // see fetch_slots
+      }
+    };
+    auto dma = [&](const Slots& r, int buf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int R = wave * 8 + 4 * j + dR;
+        const int64_t off = (int64_t)r.s[j] * tok_bytes + row_off;
+        const char* ks = a.kbuf + off + ((dp ^ (R & 15)) << 4);
+        const char* vs = a.vbuf + off + ((dp ^ ((R & 3) << 2)) << 4);
+        char* kd = lds + buf * kDmaTile + (wave * 8 + 4 * j) * 256;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
+                                         (__attribute__((address_space(3))) void*)kd, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs,
+                                         (__attribute__((address_space(3))) void*)(kd + 3 * kDmaTile), 16, 0, 0);
+      }
+    };
+    // The compiler does not track LDS-DMA arrivals: the waits are placed by hand.  A tile step issues
+    // 2 index loads (tile +4) and then the 4 DMA pieces of tile +2; before the barrier that publishes tile
+    // +1, all but the 4 youngest vector memory operations must have landed.  The count must not depend
+    // on the index loads: hipcc hoists them ahead of the prologue's pieces and deletes them from the
+    // tail steps (unused values), so "all but the 4 youngest" = the pieces of tile +2 at most, always.
+    // A raw s_barrier: __syncthreads() would drain every DMA in flight (its fence waits vmcnt(0)).
+    load_slots(s0, tbeg);
+    load_slots(s1, tbeg + 1);
+    dma(s0, 0);
+    dma(s1, 1);
+    load_slots(s2, tbeg + 2);
+    load_slots(s0, tbeg + 3);
+    // (the s_waitcnt builtin, not asm text: hipcc's own wait insertion sees it and learns that the older
+    // loads - the Q fragments, the first index loads - have landed; an asm wait it cannot see leaves it
+    // believing they may still be pending at the loop head and it drains vmcnt(0) in every iteration)
+    __builtin_amdgcn_s_waitcnt(0x0F74);   // vmcnt(4): tile tbeg has landed, tile tbeg+1 may be in flight
+    asm volatile("s_barrier" ::: "memory");
+    auto step = [&](int t, int buf, Slots& refill, const Slots& issue) __attribute__((always_inline)) {
+      load_slots(refill, t + 4);
+      dma(issue, (buf + 2) % 3);
+      u32x4 pf[4];
+      if (qk_softmax(t, buf, pf)) pv(buf, pf);
+      __builtin_amdgcn_s_waitcnt(0x0074);   // vmcnt(4) lgkmcnt(0)
+      asm volatile("s_barrier" ::: "memory");
+    };
+    int t = tbeg;
+    for (; t + 2 < ntiles; t += 3) {
+      step(t, 0, s1, s2);
+      step(t + 1, 1, s2, s0);
+      step(t + 2, 2, s0, s1);
+    }
+    if (t < ntiles) {
+      step(t, 0, s1, s2);
+      if (t + 1 < ntiles) step(t + 1, 1, s2, s0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no DMA may outlive the workgroup's LDS
+  } else {
   fetch_slots(setA, tbeg);
   fetch_slots(setB, tbeg + 1);
   prefetch(setA, tbeg);
@@ -348,6 +469,7 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
     tile_step(t + 1, setB, setA);
   }
   if (t < ntiles) tile_step(t, setA, setB);
+  }
 #ifdef SP_EXTEND_STAMPS
   if (lane == 0 && g_stamp_buf) {
     for (int i = 0; i < 8; ++i) atomicAdd(&g_stamp_buf[i], stamp_sum[i]);
@@ -384,6 +506,9 @@ void set_extend_stamp_buffer(void* p) {
 }
 #endif
 
+static int g_extend_dma = 1;
+void set_extend_dma(int v) { g_extend_dma = v; }
+
 constexpr int kExtendWaves = 8;
 
 // row blocks per workgroup tile for a query-head group of width G (any G: Gk = the largest of 4, 2, 1
@@ -403,20 +528,25 @@ static int launch_extend(const ExtendArgs& a, int max_extend_len, int halves, hi
   // request x every possible row block (workgroups past a request's end exit at once)
   const dim3 grid(a.Hkv * halves, a.plan ? a.plan_items : (max_extend_len + BM - 1) / BM, a.plan ? 1 : a.bs);
   const bool plain = !(a.logit_cap > 0.f) && a.window < 0;
-#define SP_EXT_LAUNCH(KV8_, PLAIN_)                                                            \
-  do {                                                                                         \
-    static bool attr_set = false; /* benign race: idempotent */                                \
-    if (!attr_set && kLds > 64 * 1024) {                                                       \
-      (void)hipFuncSetAttribute((const void*)extend_mfma_kernel<Tag, D, GK, NW, KV8_, PLAIN_>, \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kLds);             \
-      attr_set = true;                                                                         \
-    }                                                                                          \
-    extend_mfma_kernel<Tag, D, GK, NW, KV8_, PLAIN_><<<grid, NW * 64, kLds, st>>>(a);          \
+#define SP_EXT_LAUNCH(KV8_, PLAIN_, DMA_)                                                            \
+  do {                                                                                               \
+    constexpr int lds_bytes = DMA_ ? 6 * 64 * 256 : kLds;                                            \
+    static bool attr_set = false; /* benign race: idempotent */                                      \
+    if (!attr_set && lds_bytes > 64 * 1024) {                                                        \
+      (void)hipFuncSetAttribute((const void*)extend_mfma_kernel<Tag, D, GK, NW, KV8_, PLAIN_, DMA_>, \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);              \
+      attr_set = true;                                                                               \
+    }                                                                                                \
+    extend_mfma_kernel<Tag, D, GK, NW, KV8_, PLAIN_, DMA_><<<grid, NW * 64, lds_bytes, st>>>(a);     \
   } while (0)
   if (a.kv8) {
-    if (plain) SP_EXT_LAUNCH(true, true); else SP_EXT_LAUNCH(true, false);
+    if (plain) SP_EXT_LAUNCH(true, true, false); else SP_EXT_LAUNCH(true, false, false);
+  } else if (D == 128 && g_extend_dma) {
+    if constexpr (D == 128) {
+      if (plain) SP_EXT_LAUNCH(false, true, true); else SP_EXT_LAUNCH(false, false, true);
+    }
   } else {
-    if (plain) SP_EXT_LAUNCH(false, true); else SP_EXT_LAUNCH(false, false);
+    if (plain) SP_EXT_LAUNCH(false, true, false); else SP_EXT_LAUNCH(false, false, false);
   }
 #undef SP_EXT_LAUNCH
   SP_LAUNCH_CHECK();

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--waves", default="1,0", help="comma list: 1 = with the sp_extend_plan work list, 0 = without")
+    ap.add_argument("--dma", default="0", help="comma list of sp_debug_set('extend_dma') values to compare")
     ap.add_argument("--rounds", type=int, default=3, help="interleaved timing rounds per variant")
     ap.add_argument("--defer-x10", type=int, default=-1, help="sp_debug_set('extend_defer_x10'): -1 = shipped")
     a = ap.parse_args()
@@ -60,15 +61,22 @@ def main():
                                            int(ext.max()), int(seq.max()), ws, plan=use_plan[0])
     flops = 4 * a.Hq * a.D * float(((ext.double() ** 2) / 2 + ext.double() * pre.double()).sum())
     _native.debug_set("extend_defer_x10", a.defer_x10)
-    variants = [int(w) for w in a.waves.split(",")]
+    variants = [(int(w), int(x)) for w in a.waves.split(",") for x in a.dma.split(",")]
     times = {w: [] for w in variants}
+    outs = []
     for w in variants:
-        use_plan[0] = plan if w else None
+        use_plan[0] = plan if w[0] else None
+        _native.debug_set("extend_dma", w[1])
+        o.zero_()
         run()
+        outs.append(o.clone())
     torch.cuda.synchronize()
+    for w, x in zip(variants[1:], outs[1:]):   # the variants differ in schedule only: same bits expected
+        print(f"variant {w} vs {variants[0]}: max |diff| = {(x.float() - outs[0].float()).abs().max().item():.3e}", flush=True)
     for _ in range(a.rounds):          # interleaved rounds in one process (same clocks, same device)
         for w in variants:
-            use_plan[0] = plan if w else None
+            use_plan[0] = plan if w[0] else None
+            _native.debug_set("extend_dma", w[1])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
@@ -78,7 +86,7 @@ def main():
             times[w].append(e0.elapsed_time(e1) / a.iters)
     for w in variants:
         ms = sorted(times[w])[len(times[w]) // 2]
-        print(f"extend bs={a.bs} tokens={T} prefix={a.prefix} {a.dtype} plan={w} defer={a.defer_x10}: {ms:.3f} ms (best {min(times[w]):.3f})  "
+        print(f"extend bs={a.bs} tokens={T} prefix={a.prefix} {a.dtype} plan={w[0]} dma={w[1]} defer={a.defer_x10}: {ms:.3f} ms (best {min(times[w]):.3f})  "
               f"{flops / ms / 1e9:.1f} TFLOP/s (causal flops {flops / 1e12:.2f} T)", flush=True)
 
 
