@@ -187,9 +187,10 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
   // LDS-DMA image (DMA): rows of 256 B without padding (a DMA piece is 1 KiB of consecutive LDS = 4 rows),
   // made conflict-free by the SOURCE address each lane asks for: K row r keeps its 16-byte chunk c at
   // position c ^ (r & 15) (ds_read_b128 serves 16 lanes = 16 different rows mod 16 at a time), V row r
-  // keeps chunk c at c ^ ((r & 3) << 2) (a transposed read serves 4 rows x 64 B per 32 lanes).  Three
-  // K and three V buffers: tile t is consumed from buffer t % 3 while t+1 and t+2 are in flight.
+  // keeps chunk c at c ^ ((r & 3) << 2) (a transposed read serves 4 rows x 64 B per 32 lanes).  Four
+  // K and four V buffers (128 KiB).
   constexpr int kDmaTile = 64 * 256;
+  constexpr int kDmaBufs = 4;   // tile t is consumed from buffer t % 4 while t+1, t+2 and t+3 are in flight
   const int k_swz = (c & 15) ^ h;
 
   // pipeline: the gathers of tiles t+1 and t+2 fly during compute(t); tile t+1 is written to the other
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
       uint32_t va[DBLK];
       {
         const uint32_t vbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds +
-                               (3 + buf) * kDmaTile + (4 * h + tr_rowq) * 256 + tr_col;
+                               (kDmaBufs + buf) * kDmaTile + (4 * h + tr_rowq) * 256 + tr_col;
 #pragma unroll
         for (int db = 0; db < DBLK; ++db) va[db] = vbase + ((db ^ tr_rowq) << 6);
       }
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
     const int dR = lane >> 4, dp = lane & 15;
     const int64_t row_off = (int64_t)hk * D * 2;
     struct Slots { int s[2]; };
-    Slots s0, s1, s2;   // slot indices of tiles x with (x - tbeg) % 3 == 0, 1, 2
+    Slots s0, s1, s2, s3;   // slot indices of tiles x with (x - tbeg) % 4 == 0, 1, 2, 3
     auto load_slots = [&](Slots& r, int tile) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -386,43 +387,73 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
                                          (__attribute__((address_space(3))) void*)kd, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs,
-                                         (__attribute__((address_space(3))) void*)(kd + 3 * kDmaTile), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(kd + kDmaBufs * kDmaTile), 16, 0, 0);
       }
     };
     // The compiler does not track LDS-DMA arrivals: the waits are placed by hand.  A tile step issues
-    // 2 index loads (tile +4) and then the 4 DMA pieces of tile +2; before the barrier that publishes tile
-    // +1, all but the 4 youngest vector memory operations must have landed.  The count must not depend
-    // on the index loads: hipcc hoists them ahead of the prologue's pieces and deletes them from the
-    // tail steps (unused values), so "all but the 4 youngest" = the pieces of tile +2 at most, always.
+    // 2 index loads (tile +5) and the 4 DMA pieces of tile +3; before the barrier that publishes tile +1,
+    // everything up to ITS pieces must have landed, i.e. all but the pieces of tiles +2 and +3.  The count
+    // must not rely on the index loads: hipcc hoists them ahead of the prologue's pieces and deletes
+    // them from the tail steps (unused values), so the wait is "all but the 8 youngest operations",
+    // which leaves at most the pieces of tiles +2 and +3 in flight whatever else was issued between them.
     // A raw s_barrier: __syncthreads() would drain every DMA in flight (its fence waits vmcnt(0)).
     load_slots(s0, tbeg);
     load_slots(s1, tbeg + 1);
+    load_slots(s2, tbeg + 2);
     dma(s0, 0);
     dma(s1, 1);
-    load_slots(s2, tbeg + 2);
-    load_slots(s0, tbeg + 3);
+    dma(s2, 2);
+    load_slots(s3, tbeg + 3);
+    load_slots(s0, tbeg + 4);
     // (the s_waitcnt builtin, not asm text: hipcc's own wait insertion sees it and learns that the older
     // loads - the Q fragments, the first index loads - have landed; an asm wait it cannot see leaves it
     // believing they may still be pending at the loop head and it drains vmcnt(0) in every iteration)
-    __builtin_amdgcn_s_waitcnt(0x0F74);   // vmcnt(4): tile tbeg has landed, tile tbeg+1 may be in flight
+    __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8): tile tbeg has landed
     asm volatile("s_barrier" ::: "memory");
     auto step = [&](int t, int buf, Slots& refill, const Slots& issue) __attribute__((always_inline)) {
-      load_slots(refill, t + 4);
-      dma(issue, (buf + 2) % 3);
+      SP_STAMP(ts0);
+#ifndef SP_EXTEND_NOGATHER   // diagnostic: the matrix pipeline alone (tiles hold whatever the prologue left)
+      load_slots(refill, t + 5);
+      dma(issue, (buf + 3) % 4);
+#endif
+      SP_STAMP(ts1);
       u32x4 pf[4];
-      if (qk_softmax(t, buf, pf)) pv(buf, pf);
-      __builtin_amdgcn_s_waitcnt(0x0074);   // vmcnt(4) lgkmcnt(0)
+#ifdef SP_EXTEND_NOCOMPUTE   // diagnostic: the gather pipeline alone
+      const bool visible = false;
+#else
+      const bool visible = qk_softmax(t, buf, pf);
+      if (visible) pv(buf, pf);
+#endif
+#ifdef SP_EXTEND_STAMPS
+      if (!visible) ts2 = ts3 = ts1;
+      stamp_sum[6] += visible ? 1 : 0;
+      stamp_sum[7] += 1;
+#endif
+      SP_STAMP(ts4);
+      __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0)
+      SP_STAMP(ts5);
       asm volatile("s_barrier" ::: "memory");
+      SP_STAMP(ts6);
+      SP_STAMP_ACC(0, ts0, ts1);   // index loads + issue of the DMA pieces three tiles ahead
+      SP_STAMP_ACC(1, ts1, ts2);
+      SP_STAMP_ACC(2, ts2, ts3);
+      SP_STAMP_ACC(3, ts3, ts4);
+      SP_STAMP_ACC(4, ts4, ts5);   // wait for the next tile's pieces
+      SP_STAMP_ACC(5, ts5, ts6);   // barrier
     };
     int t = tbeg;
-    for (; t + 2 < ntiles; t += 3) {
-      step(t, 0, s1, s2);
+    for (; t + 3 < ntiles; t += 4) {
+      step(t, 0, s1, s3);
       step(t + 1, 1, s2, s0);
-      step(t + 2, 2, s0, s1);
+      step(t + 2, 2, s3, s1);
+      step(t + 3, 3, s0, s2);
     }
     if (t < ntiles) {
-      step(t, 0, s1, s2);
-      if (t + 1 < ntiles) step(t + 1, 1, s2, s0);
+      step(t, 0, s1, s3);
+      if (t + 1 < ntiles) {
+        step(t + 1, 1, s2, s0);
+        if (t + 2 < ntiles) step(t + 2, 2, s3, s1);
+      }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no DMA may outlive the workgroup's LDS
   } else {
@@ -530,7 +561,7 @@ static int launch_extend(const ExtendArgs& a, int max_extend_len, int halves, hi
   const bool plain = !(a.logit_cap > 0.f) && a.window < 0;
 #define SP_EXT_LAUNCH(KV8_, PLAIN_, DMA_)                                                            \
   do {                                                                                               \
-    constexpr int lds_bytes = DMA_ ? 6 * 64 * 256 : kLds;                                            \
+    constexpr int lds_bytes = DMA_ ? 8 * 64 * 256 : kLds;                                            \
     static bool attr_set = false; /* benign race: idempotent */                                      \
     if (!attr_set && lds_bytes > 64 * 1024) {                                                        \
       (void)hipFuncSetAttribute((const void*)extend_mfma_kernel<Tag, D, GK, NW, KV8_, PLAIN_, DMA_>, \

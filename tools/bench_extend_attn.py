@@ -24,9 +24,12 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--waves", default="1,0", help="comma list: 1 = with the sp_extend_plan work list, 0 = without")
     ap.add_argument("--dma", default="0", help="comma list of sp_debug_set('extend_dma') values to compare")
+    ap.add_argument("--lib", default="", help="alternative library file under scratchpad_amd/lib (diagnostic builds)")
     ap.add_argument("--rounds", type=int, default=3, help="interleaved timing rounds per variant")
     ap.add_argument("--defer-x10", type=int, default=-1, help="sp_debug_set('extend_defer_x10'): -1 = shipped")
     a = ap.parse_args()
+    if a.lib:
+        _native._LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scratchpad_amd", "lib", a.lib)
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
     dev = "cuda"
     g = torch.Generator().manual_seed(0)
@@ -77,7 +80,7 @@ def main():
         for w in variants:
             use_plan[0] = plan if w[0] else None
             _native.debug_set("extend_dma", w[1])
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
                 run()

@@ -11,7 +11,7 @@ for f in scratchpad_amd/csrc/*.hip; do
     extend_mfma.hip) extra="-fno-honor-nans";;
   esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-value \
-    -DSP_EXTEND_STAMPS $extra -c $f -o build/stamps/$(basename $f .hip).o &
+    ${SP_STAMP_DEFS:--DSP_EXTEND_STAMPS} $extra -c $f -o build/stamps/$(basename $f .hip).o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scratchpad_amd/lib/libscratchpad_hip_stamps.so build/stamps/*.o
