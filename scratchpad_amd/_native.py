@@ -110,7 +110,7 @@ def _check(status: int, what: str):
 
 
 def debug_set(key: str, value: int) -> None:
-    """Test / tuning switch of the library (sp_debug_set): "decode_kernel", "extend_defer_x10"."""
+    """Test / tuning switch of the library (sp_debug_set): "decode_kernel", "extend_defer_x10", "extend_dma" (0 = register-staged tiles)."""
     _check(load().sp_debug_set(key.encode(), int(value)), f"sp_debug_set({key})")
 
 

@@ -317,6 +317,31 @@ def test_extend_deferred_maximum_agrees_with_exact_running_maximum(nat, dt):
         check_vs_oracle(o, dtype, f"extend deferred max {dt}, {name}", c["v_buffer"].float(), fn)
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("causal_window", [(-1, 0.0), (300, 0.0), (-1, 30.0)])
+def test_extend_dma_ring_and_register_staging_give_the_same_bits(nat, dt, causal_window):
+    """D = 128, 16-bit pools: the K/V tiles reach LDS by LDS-DMA into a swizzled four-buffer ring; every
+    other shape (and this one with sp_debug_set("extend_dma", 0)) stages them through registers into
+    padded rows.  Same tile order, same arithmetic: the outputs must be identical, ragged prefixes,
+    sliding window and logit cap included (the ring's hand-counted waits are what this would catch)."""
+    dtype = DTYPES[dt]
+    window, cap = causal_window
+    Hq, Hkv, D = 8, 2, 128
+    pre, ext = [0, 513, 64, 1], [700, 257, 64, 1]
+    p, q, ext_t, start = extend_problem(61, Hq, Hkv, D, pre, ext, dtype)
+    args = (q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"], p["seq_lens"], ext_t, start,
+            D ** -0.5)
+    kw = dict(cap=cap, window_left=window)
+    try:
+        nat.debug_set("extend_dma", 0)
+        o_reg = run_extend(nat, *args, **kw)
+    finally:
+        nat.debug_set("extend_dma", 1)
+    for _ in range(3):     # a miscounted wait shows as run-to-run differences
+        o_dma = run_extend(nat, *args, **kw)
+        assert torch.equal(o_dma, o_reg)
+
+
 @pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
 def test_extend_golden(nat, dt):
     dtype = DTYPES[dt]

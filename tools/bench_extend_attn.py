@@ -80,7 +80,7 @@ def main():
         for w in variants:
             use_plan[0] = plan if w[0] else None
             _native.debug_set("extend_dma", w[1])
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
                 run()
