@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--waves", default="1,0", help="comma list: 1 = with the sp_extend_plan work list, 0 = without")
-    ap.add_argument("--dma", default="0", help="comma list of sp_debug_set('extend_dma') values to compare")
+    ap.add_argument("--dma", default="1", help="comma list of sp_debug_set('extend_dma') values to compare")
     ap.add_argument("--lib", default="", help="alternative library file under scratchpad_amd/lib (diagnostic builds)")
     ap.add_argument("--rounds", type=int, default=3, help="interleaved timing rounds per variant")
     ap.add_argument("--defer-x10", type=int, default=-1, help="sp_debug_set('extend_defer_x10'): -1 = shipped")
