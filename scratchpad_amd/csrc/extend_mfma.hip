@@ -100,6 +100,15 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
   const int r0 = row0 + rb * 32;                   // this wave's first query row
   const int my_row = r0 + c;                       // this lane's query row (may be >= E: masked out)
   const bool wave_live = r0 < E;
+  if (ntiles <= tbeg) {
+    // no key at all (a request without encoder tokens): zeros, and no look at req_to_token, whose row
+    // need not hold a valid slot then.  Workgroup-uniform: taken before the first barrier.
+    if (my_row < E && wave_live) {
+      char* op = (char*)a.out + ((t0 + my_row) * a.o_stride + (int64_t)head * D) * 2;
+      for (int d = 4 * h; d < D; d += 8) *(u32x2*)(op + d * 2) = u32x2{0u, 0u};
+    }
+    return;
+  }
 
   // ---- Q fragments: B operand of S^T = K.Q^T, lane (c,h) holds Q[row c][16ks + 8h .. +7]
   u32x4 qf[KSTEPS];

@@ -420,6 +420,7 @@ def test_extend_cross_attention_and_kv_start(nat):
                     lambda v: ops.extend_attention(q.cpu().float(), c["k_buffer"].float(), v, c["req_to_token"],
                                                    c["req_pool_indices"], enc_t.cpu(), ext_t.cpu(), start.cpu(), 0.1,
                                                    causal=False), rows)
+    assert torch.all(o[20:25] == 0), "a request without encoder tokens: its rows are written as zeros"
     # decoder self-attention behind the encoder slots
     o = run_extend(nat, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"], seq_t,
                    ext_t, start, 0.1, causal=True, kv_start=enc_t)
