@@ -1,0 +1,25 @@
+// Entry points of extend_mfma.hip used by the C-ABI file (extend_attention.hip).  Internal to the library.
+// (Kept out of attention_internal.h so that the decode kernels' source hash - bench.py,
+// profiles/*_decode_attn_pmc.json - does not move when only the extend kernel changes.)
+#pragma once
+#include <cstdint>
+
+#include <hip/hip_runtime.h>
+
+namespace sp {
+
+// extend_mfma.hip: MFMA tile kernel for 16-bit ragged extend; SP_ERR_UNSUPPORTED -> use row-streams
+int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* v_buffer,
+                    const int32_t* req_to_token, int64_t req_to_token_stride,
+                    const void* req_pool_indices, const void* seq_lens, const void* kv_start,
+                    int idx64, const int32_t* extend_seq_lens, const int32_t* extend_start_loc,
+                    int batch_size, int num_q_heads, int num_kv_heads, int head_dim, int64_t q_stride,
+                    int64_t out_stride, int64_t kv_buffer_stride, float sm_scale, float logit_cap,
+                    float out_scale, int causal, int window_left, int max_extend_len, const int32_t* plan,
+                    int plan_items, int dtype, int kv8, hipStream_t st);
+
+// test / tuning hooks behind sp_debug_set
+void set_extend_defer_x10(int tenths);
+void set_extend_dma(int v);   // 0: register-staged K/V tiles for every shape (the LDS-DMA ring is the default where it applies)
+
+}  // namespace sp

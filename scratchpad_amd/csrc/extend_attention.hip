@@ -14,6 +14,7 @@
 #include <cstring>
 
 #include "attention_internal.h"
+#include "extend_api.h"
 
 namespace sp {
 

@@ -3,6 +3,7 @@
 #include <type_traits>
 
 #include "attention_internal.h"
+#include "extend_api.h"
 
 namespace sp {
 
