@@ -31,7 +31,7 @@ def main(tag):
     open(os.path.join(P, f"{tag}_bench_kernel_stats.txt"), "w").write(hdr + body + tail)
     for src, dst in (("bench_serve.json", "serve_trace.json"), ("bench_serve_prefix.json", "serve_trace_prefix512.json"),
                      ("mllama.log", "mllama11b.txt"), ("gemv.log", "gemv.txt"), ("sampling.log", "sampling.txt"),
-                     ("extend_attn.log", "extend_attn.txt"), ("extend_stamps.log", "extend_stamps.txt")):
+                     ("extend_attn.log", "extend_attn.txt"), ("extend_stamps.log", "extend_stamps_dma.txt")):
         p = os.path.join(R, src)
         if os.path.exists(p):
             text = "".join(line for line in open(p) if "amdgpu.ids" not in line)
