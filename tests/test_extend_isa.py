@@ -35,8 +35,9 @@ def dma_kernel_asm(tmp_path_factory):
 def test_tile_loop_keeps_its_dma_in_flight(dma_kernel_asm):
     lines = [l.strip() for l in dma_kernel_asm.splitlines()]
     barriers = [i for i, l in enumerate(lines) if l.startswith("s_barrier")]
-    assert len(barriers) >= 5, "prologue barrier + one per unrolled tile step"
-    loop = lines[barriers[0] + 1:barriers[-1]]            # everything between the first and the last barrier
+    assert len(barriers) >= 6, "prologue barrier + one per unrolled tile step + the epilogue's"
+    loop = lines[barriers[0] + 1:barriers[-2]]            # between the prologue's barrier and the last tile step's (the
+                                                          # epilogue has its own barrier behind a full drain)
     assert sum(l.startswith("global_load_lds_dwordx4") for l in loop) >= 16, "4 DMA pieces per tile step"
     drained = [l for l in loop if re.match(r"s_waitcnt.*vmcnt\(0\)", l)]
     assert not drained, f"the tile loop drains the DMA ring: {drained[:3]}"
