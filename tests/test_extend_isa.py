@@ -25,8 +25,8 @@ def dma_kernel_asm(tmp_path_factory):
            os.path.join(ROOT, "scratchpad_amd", "csrc", "extend_mfma.hip"), "-o", str(out)]
     subprocess.run(cmd, check=True, capture_output=True)
     text = open(out).read()
-    # bf16, D 128, GK 4, 8 waves, 16-bit pool, PLAIN, DMA
-    m = re.search(r"^(_ZN2sp18extend_mfma_kernelINS_8bf16_tagELi128ELi4ELi8ELb0ELb1ELb1EEEvNS_10ExtendArgsE):[^\n]*\n(.*?)^\.Lfunc_end",
+    # bf16, D 128, GK 4, 8 waves, 16-bit pool, PLAIN, DMA (, not persistent)
+    m = re.search(r"^(_ZN2sp18extend_mfma_kernelINS_8bf16_tagELi128ELi4ELi8ELb0ELb1ELb1(?:ELb0)?EEEvNS_10ExtendArgsE):[^\n]*\n(.*?)^\.Lfunc_end",
                   text, re.S | re.M)
     assert m, "headline LDS-DMA instantiation not found"
     return m.group(2)
