@@ -135,7 +135,7 @@ extern "C" int sp_debug_set(const char* key, int value) {
   return SP_ERR_INVALID_ARG;
 }
 
-#ifdef SP_EXTEND_STAMPS
+#if defined(SP_EXTEND_STAMPS) || defined(SP_EXTEND_WGSTAMPS)
 namespace sp { void set_extend_stamp_buffer(void* p); }
 extern "C" SP_API int sp_debug_extend_stamp_buffer(void* device_u64x8) {
   sp::set_extend_stamp_buffer(device_u64x8);

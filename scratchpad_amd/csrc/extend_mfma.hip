@@ -37,8 +37,22 @@ namespace sp {
 // s_memtime stamps between the segments of a tile iteration, summed per wave and added to a
 // caller-supplied buffer, to see where an iteration spends its cycles (cdna_hip_programming.md
 // section 7 'In-kernel stamps').
-#ifdef SP_EXTEND_STAMPS
+#if defined(SP_EXTEND_STAMPS) || defined(SP_EXTEND_WGSTAMPS)
 __device__ unsigned long long* g_stamp_buf = nullptr;
+#endif
+// Second diagnostic form (-DSP_EXTEND_WGSTAMPS): the timeline of a whole workgroup - entry, metadata decoded,
+// first tile landed, tile loop done, output written - summed over workgroups (wave 0), same buffer.
+#ifdef SP_EXTEND_WGSTAMPS
+#define SP_WGSTAMP(var)                                                                     \
+  do {                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");             \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+  } while (0)
+#else
+#define SP_WGSTAMP(var) do { } while (0)
+#endif
+#ifdef SP_EXTEND_STAMPS
 #define SP_STAMP(var)                                                                       \
   do {                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                      \
@@ -64,6 +78,10 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
   constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK;
   constexpr int BM = 32 * (NW / GK);
   extern __shared__ __attribute__((aligned(16))) char lds[];
+#ifdef SP_EXTEND_WGSTAMPS
+  unsigned long long wg0 = 0, wg1 = 0, wg2 = 0, wg3 = 0, wg4 = 0;
+  SP_WGSTAMP(wg0);
+#endif
 
   int b, row0;
   if (a.plan) {                                    // planned: items are sorted heaviest first
@@ -92,6 +110,7 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
   // sliding window (causal only): the first row of the block reaches furthest back
   const bool windowed = !PLAIN && a.causal && a.window >= 0;
   const int tbeg = windowed ? max(0, P + row0 - a.window) / BN : 0;
+  SP_WGSTAMP(wg1);
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int c = lane & 31, h = lane >> 5;
@@ -424,6 +443,7 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
     // believing they may still be pending at the loop head and it drains vmcnt(0) in every iteration)
     __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8): tile tbeg has landed
     asm volatile("s_barrier" ::: "memory");
+    SP_WGSTAMP(wg2);
     auto step = [&](int t, int buf, Slots& refill, const Slots& issue) __attribute__((always_inline)) {
       SP_STAMP(ts0);
 #ifndef SP_EXTEND_NOGATHER   // diagnostic: the matrix pipeline alone (tiles hold whatever the prologue left)
@@ -470,6 +490,7 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
       }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): no DMA may outlive the workgroup's LDS
+    SP_WGSTAMP(wg3);
   } else {
   fetch_slots(setA, tbeg);
   fetch_slots(setB, tbeg + 1);
@@ -559,6 +580,16 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
       }
     }
   }
+#ifdef SP_EXTEND_WGSTAMPS
+  SP_WGSTAMP(wg4);
+  if (threadIdx.x == 0 && g_stamp_buf && wg2) {
+    atomicAdd(&g_stamp_buf[0], wg1 - wg0);   // entry -> metadata decoded
+    atomicAdd(&g_stamp_buf[1], wg2 - wg1);   // -> first tile landed and published (Q loads, index loads, first pieces)
+    atomicAdd(&g_stamp_buf[2], wg3 - wg2);   // tile loop
+    atomicAdd(&g_stamp_buf[3], wg4 - wg3);   // barrier + output through LDS + stores issued
+    atomicAdd(&g_stamp_buf[7], 1ULL);
+  }
+#endif
 }
 
 // test hook (set through sp_debug_set, never read from the environment on the call path): how far the
@@ -566,7 +597,7 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
 // every growth of a row maximum) with the shipped threshold.
 static float g_extend_defer = kDeferLog2;
 void set_extend_defer_x10(int tenths) { g_extend_defer = tenths < 0 ? kDeferLog2 : 0.1f * tenths; }
-#ifdef SP_EXTEND_STAMPS
+#if defined(SP_EXTEND_STAMPS) || defined(SP_EXTEND_WGSTAMPS)
 void set_extend_stamp_buffer(void* p) {
   unsigned long long* q = (unsigned long long*)p;
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &q, sizeof(q));
