@@ -200,17 +200,30 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
     const int ntile = (n + TK - 1) / TK;
 
     raw_t kr[NLD], vr[NLD];
-    auto issue = [&](int tile) {
+    raw_t kr2[NLD], vr2[NLD];   // KV8 only: a second set (see the loop below); unused and optimised away otherwise
+    auto issue_from = [&](int tile, int idxreg, int nkeys, raw_t (&kd)[NLD], raw_t (&vd)[NLD]) {
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
         const int key = tile * TK + i * RPL + ld_row;         // key within the piece
-        const int slot = __shfl(myidx, key & 63, 64);
+        const int slot = __shfl(idxreg, key & 63, 64);
         // source chunk is XOR-swizzled by the tile row so that the LDS image is conflict-free
         const int R = i * RPL + ld_row;
-        const int64_t off = (key < n ? (int64_t)slot : 0) * tok_bytes + head_off +
+        const int64_t off = (key < nkeys ? (int64_t)slot : 0) * tok_bytes + head_off +
                             ((ld_ch ^ (R & (CPR - 1))) * SRC_CH_B);
-        kr[i] = *(const raw_t*)(a.kbuf + off);
-        vr[i] = *(const raw_t*)(a.vbuf + off);
+        kd[i] = *(const raw_t*)(a.kbuf + off);
+        vd[i] = *(const raw_t*)(a.vbuf + off);
+      }
+    };
+    auto issue_to = [&](int tile, raw_t (&kd)[NLD], raw_t (&vd)[NLD]) { issue_from(tile, myidx, n, kd, vd); };
+    auto issue = [&](int tile) { issue_to(tile, kr, vr); };
+    auto stage_from = [&](const raw_t (&ks)[NLD], const raw_t (&vs)[NLD]) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int R = i * RPL + ld_row;
+        if constexpr (KV8) {
+          st16(ldsK + R * ROW_B + ld_ch * 16, expand_e5m2x8(ks[i]));
+          st16(ldsV + R * ROW_B + ld_ch * 16, expand_e5m2x8(vs[i]));
+        }
       }
     };
     auto stage = [&]() {
@@ -284,11 +297,34 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
     // one register set: the tile's registers are free as soon as they are in LDS, so the next
     // tile's gathers are issued right there and fly during this tile's MFMAs and softmax (and under
     // the other waves of the SIMD: ~100 VGPRs => 4 waves per SIMD)
+#ifdef SP_DEC_ONESET   // diagnostic build: one register set for byte pools too
+    constexpr bool kTwoSets = false;
+#else
+    constexpr bool kTwoSets = KV8;
+#endif
+    if constexpr (kTwoSets) {
+      // a byte pool moves half the bytes per gather: with one tile in flight per wave the CU has half the
+      // bytes in flight of the 16-bit kernel (5.1 vs 5.7 TB/s).  Two register sets (8 B per lane and gather:
+      // 16 registers more), tiles t+1 and t+2 in flight while tile t is consumed.
+      issue_to(0, kr, vr);
+      if (1 < ntile) issue_to(1, kr2, vr2);
+      for (int t = 0; t < ntile; t += 2) {
+        stage_from(kr, vr);
+        if (t + 2 < ntile) issue_to(t + 2, kr, vr);
+        consume(t);
+        if (t + 1 < ntile) {
+          stage_from(kr2, vr2);
+          if (t + 3 < ntile) issue_to(t + 3, kr2, vr2);
+          consume(t + 1);
+        }
+      }
+    } else {
     issue(0);
     for (int t = 0; t < ntile; ++t) {
       stage();
       if (t + 1 < ntile) issue(t + 1);
       consume(t);
+    }
     }
   }
 

@@ -25,10 +25,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--kv", default="same", choices=["same", "fp8"], help="fp8 = e5m2 byte pool")
+    ap.add_argument("--lib", default="", help="diagnostic library under scratchpad_amd/lib")
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--no-plan", action="store_true")
     ap.add_argument("--gemm", action="store_true", help="interleave a bf16 GEMM between launches (as in a model)")
     a = ap.parse_args()
+    if a.lib:
+        _native._LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scratchpad_amd", "lib", a.lib)
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
     dev = "cuda"
     g = torch.Generator().manual_seed(0)
