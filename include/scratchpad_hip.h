@@ -49,8 +49,10 @@ SP_API const char* sp_status_string(int status);
 /* Test / tuning hook (no reference counterpart): process-wide kernel-selection switches for A/B
  * measurements and parity tests of the non-default kernels.  Keys: "decode_kernel" (0 = default,
  * 1 = VALU kernel, 2 = matrix-core kernel), "extend_defer_x10" (how far the extend kernel's running
- * row maximum may trail, in tenths of a log2 unit; < 0 = the shipped value).  Nothing on the call
- * path reads the environment.  Returns SP_ERR_INVALID_ARG for an unknown key.                    */
+ * row maximum may trail, in tenths of a log2 unit; < 0 = the shipped value), "extend_dma" (1 = K/V tiles
+ * by LDS-DMA into the swizzled ring where it applies - D 128, 16-bit pools - the default; 0 = register-
+ * staged tiles for every shape: same bits).  Nothing on the call path reads the environment.  Returns
+ * SP_ERR_INVALID_ARG for an unknown key.                                                          */
 SP_API int sp_debug_set(const char* key, int value);
 
 /* ---- RMSNorm: replaces flashinfer.norm.rmsnorm / fused_add_rmsnorm
