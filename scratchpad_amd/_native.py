@@ -150,7 +150,7 @@ def _rows(t: torch.Tensor) -> torch.Tensor:
 def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
     _gpu(x, weight)
     x2 = _rows(x)
-    out = torch.empty((x2.shape[0], x2.shape[1]), dtype=x.dtype, device=x.device)
+    out = empty_rows(x2.shape[0], x2.shape[1], x.dtype, x.device)      # spare rows behind it: see library_rows
     w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
     _check(load().sp_rmsnorm(out.data_ptr(), x2.data_ptr(), w.data_ptr(), x2.shape[0], x2.shape[1],
                              x2.stride(0), out.stride(0), eps, _dt(x), _stream()), "sp_rmsnorm")
@@ -172,7 +172,7 @@ def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
     _gpu(x)
     x2 = _rows(x)
     d = x2.shape[1] // 2
-    out = torch.empty((x2.shape[0], d), dtype=x.dtype, device=x.device)
+    out = empty_rows(x2.shape[0], d, x.dtype, x.device)      # spare rows behind it: see library_rows
     _check(load().sp_silu_and_mul(out.data_ptr(), x2.data_ptr(), x2.shape[0], d, x2.stride(0),
                                   out.stride(0), _dt(x), _stream()), "sp_silu_and_mul")
     return out.view(*x.shape[:-1], d)
@@ -528,9 +528,53 @@ def skinny_gemm_pays(M: int, N: int, K: int) -> bool:
     return M <= 8 and K <= 8192 and N <= 65536
 
 
+# ---- the row count the library is handed -----------------------------------------------------------------------
+# hipBLASLt's kernel choice is erratic in the row count M (tools/bench_gemm_rows.py, device time under graph
+# replay, cold weights, MI355X / ROCm 7.2): qkv_proj (N 6144, K 4096) takes 40 us at 256 rows and 28 us at 264;
+# down_proj (N 4096, K 14336) 103 us at 192 rows and 59 us at 208.  GEMM rows are independent, so for those
+# (shape, M) pairs the product of M rows is computed as the first M rows of an M' > M row product: the input is
+# re-viewed over M' rows of its OWN storage (every activation this package allocates carries ROW_SLACK spare rows
+# behind it; whatever they hold only reaches output rows that are sliced away), no copy, no extra launch.
+ROW_SLACK = 64
+_LIBRARY_ROWS = {
+    (6144, 4096): {136: 176, 144: 176, 152: 176, 192: 200, 224: 232, 256: 264},      # qkv_proj  (8B)
+    (4096, 4096): {96: 104, 192: 208},                                                # o_proj
+    (28672, 4096): {16: 40, 48: 56, 80: 96},                                          # gate_up_proj
+    (4096, 14336): {72: 80, 96: 112, 128: 136, 160: 208, 192: 208},                   # down_proj
+}
+_LIBROWS_ON = os.environ.get("SP_LIBRARY_ROWS", "1") != "0"
+SLACK_MAX_ROWS = 256          # decode-sized steps only; prefill products are left exactly as F.linear
+
+
+def library_rows(M: int, N: int, K: int) -> int:
+    """rows to hand the library GEMM for an M-row product of shape (N, K): M, or the measured better M' > M"""
+    if not _LIBROWS_ON:
+        return M
+    return _LIBRARY_ROWS.get((N, K), {}).get(M, M)
+
+
+def empty_rows(rows: int, cols: int, dtype, device, zero: bool = False) -> torch.Tensor:
+    """[rows, cols] activation with ROW_SLACK readable spare rows behind it in the same allocation"""
+    full = (torch.zeros if zero else torch.empty)((rows + ROW_SLACK, cols), dtype=dtype, device=device)
+    return full[:rows]
+
+
+def extend_rows(x: torch.Tensor, rows: int) -> Optional[torch.Tensor]:
+    """x re-viewed over `rows` >= x.shape[0] rows of its own storage, or None if the storage ends before"""
+    if rows <= x.shape[0]:
+        return x
+    if x.dim() != 2 or x.stride(1) != 1 or x.stride(0) < x.shape[1]:
+        return None
+    last = x.storage_offset() + (rows - 1) * x.stride(0) + x.shape[1]
+    if last * x.element_size() > x.untyped_storage().nbytes():
+        return None
+    return torch.as_strided(x, (rows, x.shape[1]), (x.stride(0), 1), x.storage_offset())
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """x @ weight.T.  Small-batch 16-bit products go to the weight-streaming kernel
-    (sp_gemm_skinny) where it pays; everything else is the library GEMM, exactly F.linear."""
+    (sp_gemm_skinny) where it pays; everything else is the library GEMM - exactly F.linear, except
+    that a decode-sized product may be computed over more rows than asked for (library_rows)."""
     if (_SKINNY_ON and x.is_cuda and x.dim() == 2 and 0 < x.shape[0] <= SKINNY_MAX_ROWS
             and skinny_gemm_pays(x.shape[0], weight.shape[0], x.shape[1])
             and x.dtype in (torch.float16, torch.bfloat16) and weight.dtype == x.dtype
@@ -539,8 +583,19 @@ def linear(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
             and x.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0):
         M, K = x.shape
         N = weight.shape[0]
-        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+        out = empty_rows(M, N, x.dtype, x.device)
         _check(load().sp_gemm_skinny(out.data_ptr(), x.data_ptr(), weight.data_ptr(), M, N, K, x.stride(0),
                                      weight.stride(0), out.stride(0), _dt(x), _stream()), "sp_gemm_skinny")
         return out
+    if (x.is_cuda and x.dim() == 2 and 0 < x.shape[0] <= SLACK_MAX_ROWS and weight.dim() == 2
+            and x.dtype in (torch.float16, torch.bfloat16) and weight.dtype == x.dtype and x.stride(1) == 1):
+        M, K = x.shape
+        N = weight.shape[0]
+        Mp = library_rows(M, N, K)
+        xe = extend_rows(x, Mp) if Mp > M else x
+        if xe is None:                      # producer without spare rows (e.g. the embedding): run as asked
+            xe, Mp = x, M
+        out = torch.empty((Mp + ROW_SLACK, N), dtype=x.dtype, device=x.device)
+        torch.mm(xe, weight.t(), out=out[:Mp])
+        return out[:M]
     return torch.nn.functional.linear(x, weight)

@@ -316,7 +316,8 @@ class HipAttnBackend(AttentionBackend):
         # The kernels leave a row with no visible key untouched (sp_decode_attention: seq_len 0).
         # Only cross-attention has such rows (text-only requests, encoder_len 0); they must read as
         # zeros because the model multiplies them by the row mask (mllama.py:621-622).
-        return torch.zeros_like(q) if layer.is_cross_attention else torch.empty_like(q)
+        # (allocated with spare rows behind it, like every activation that feeds a projection: _native.library_rows)
+        return _native.empty_rows(q.shape[0], q.shape[1], q.dtype, q.device, zero=layer.is_cross_attention)
 
     def _store(self, layer, forward_batch, k, v, save_kv_cache):
         if k is None or not save_kv_cache:

@@ -54,3 +54,27 @@ def test_skinny_gemm_views_fallbacks_and_determinism():
     lib = __import__("ctypes").CDLL(_native.lib_path())
     assert lib.sp_gemm_skinny(None, None, None, 4, 8, 64, 64, 64, 8, 2, None) == -1      # null pointers
     assert lib.sp_gemm_skinny(1, 1, 1, 17, 8, 64, 64, 64, 8, 2, None) == -2              # unsupported rows
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_linear_hands_the_library_a_faster_row_count_and_returns_the_same_rows(dtype):
+    """_native.library_rows: for some (shape, M) the product is computed over M' > M rows of the input's own
+    storage (hipBLASLt is faster there).  Rows are independent: whatever the spare rows hold - NaN here - must
+    not reach the M rows returned; an input without spare rows is run as asked."""
+    from scratchpad_amd import _native
+    g = torch.Generator().manual_seed(3)
+    for M, N, K in [(256, 6144, 4096), (192, 4096, 14336), (128, 4096, 14336), (16, 28672, 4096), (40, 4096, 4096)]:
+        Mp = _native.library_rows(M, N, K)
+        w = (torch.randn(N, K, generator=g) * 0.05).to(dtype).cuda()
+        x = _native.empty_rows(M, K, dtype, "cuda")
+        assert _native.extend_rows(x, Mp) is not None
+        torch.as_strided(x, (M + _native.ROW_SLACK, K), (K, 1)).fill_(float("nan"))    # the whole allocation
+        x.copy_(torch.randn(M, K, generator=g).to(dtype))
+        got = _native.linear(x, w)
+        assert got.shape == (M, N) and torch.isfinite(got.float()).all()
+        check(got, x, w, dtype)
+        assert _native.extend_rows(got, M + _native.ROW_SLACK) is not None, "outputs carry spare rows for the next projection"
+        tight = x.clone()                                     # an exact allocation: no spare rows behind it
+        if Mp > M:
+            assert _native.extend_rows(tight, Mp) is None
+        check(_native.linear(tight, w), x, w, dtype)

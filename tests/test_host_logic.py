@@ -325,3 +325,23 @@ def test_mixed_batch_merges_sampling_info_like_the_reference():
     new, run = batches(None, (None, None))
     new.mix_with_running(run)
     assert new.sampling_info is None and len(new.reqs) == 3
+
+
+def test_spare_row_views_and_library_row_table():
+    """_native.extend_rows re-views an activation over more rows of its own storage only when the storage
+    really extends that far; library_rows never shrinks a product and is the identity off its table."""
+    import torch
+    from scratchpad_amd import _native
+    x = _native.empty_rows(5, 8, torch.float32, "cpu")
+    assert x.shape == (5, 8) and x.is_contiguous()
+    v = _native.extend_rows(x, 5 + _native.ROW_SLACK)
+    assert v is not None and v.shape == (5 + _native.ROW_SLACK, 8) and v.data_ptr() == x.data_ptr()
+    assert _native.extend_rows(x, 6 + _native.ROW_SLACK) is None
+    assert _native.extend_rows(torch.zeros(5, 8), 6) is None
+    part = torch.zeros(10, 16)[2:6, :8]                   # row-strided view in the middle of a buffer
+    assert _native.extend_rows(part, 8).shape == (8, 8) and _native.extend_rows(part, 9) is None
+    assert _native.extend_rows(x, 3) is x
+    for (N, K), table in _native._LIBRARY_ROWS.items():
+        for M, Mp in table.items():
+            assert M < Mp <= M + _native.ROW_SLACK and _native.library_rows(M, N, K) == Mp
+    assert _native.library_rows(255, 6144, 4096) == 255 and _native.library_rows(256, 1234, 4096) == 256
