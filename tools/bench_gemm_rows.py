@@ -14,8 +14,15 @@ from tools.bench_gemm256 import timeit  # noqa: E402
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b-tp8"])
+    a = ap.parse_args()
     dev, dt, L = "cuda", torch.bfloat16, 8
-    for name, N, K in [("qkv", 6144, 4096), ("o", 4096, 4096), ("gate_up", 28672, 4096), ("down", 4096, 14336)]:
+    shapes = {"llama3-8b": [("qkv", 6144, 4096), ("o", 4096, 4096), ("gate_up", 28672, 4096), ("down", 4096, 14336)],
+              # per-rank shards at TP = 8 (hidden 8192, 64/8 heads, inter 28672)
+              "llama3-70b-tp8": [("qkv", 1280, 8192), ("o", 8192, 1024), ("gate_up", 7168, 8192), ("down", 8192, 3584)]}
+    for name, N, K in shapes[a.model]:
         Ws = [torch.randn(N, K, device=dev, dtype=dt) * 0.02 for _ in range(L)]
         rows = list(range(16, 257, 8)) + list(range(264, 385, 8))
         t = {}
