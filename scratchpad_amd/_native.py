@@ -541,6 +541,10 @@ _LIBRARY_ROWS = {
     (4096, 4096): {96: 104, 192: 208},                                                # o_proj
     (28672, 4096): {16: 40, 48: 56, 80: 96},                                          # gate_up_proj
     (4096, 14336): {72: 80, 96: 112, 128: 136, 160: 208, 192: 208},                   # down_proj
+    # Llama-3-70B shards at TP = 8 (profiles/r02_gemm_rows_70b_tp8.txt); nothing to gain at config 4's 128 rows
+    (7168, 8192): {192: 200, 224: 232, 256: 264},                                     # gate_up_proj / 8
+    (8192, 3584): {192: 208, 224: 232, 256: 264},                                     # down_proj / 8
+    (1280, 8192): {64: 72},                                                           # qkv_proj / 8
 }
 _LIBROWS_ON = os.environ.get("SP_LIBRARY_ROWS", "1") != "0"
 SLACK_MAX_ROWS = 256          # decode-sized steps only; prefill products are left exactly as F.linear
