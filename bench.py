@@ -77,6 +77,9 @@ def parse_args():
     ap.add_argument("--prefix", type=int, default=0, help="prefill mode: shared cached prefix length")
     ap.add_argument("--max-prefill-tokens", type=int, default=16384,
                     help="prefill mode: tokens per extend batch (server/args.py max_prefill_tokens)")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="allow ranks to SHARE a GPU (a box with fewer GPUs than --gpus): the line is then labelled "
+                         "REHEARSAL and is not a scaling measurement; without it such a run exits non-zero")
     ap.add_argument("--profile-steps", type=int, default=4,
                     help="extra eager steps with HIP events around every attention launch")
     args = ap.parse_args()
@@ -92,12 +95,66 @@ def self_launch_if_needed(args) -> None:
     touches a GPU (importing torch does not); the children are ordinary torch.distributed.run ranks."""
     if args.gpus <= 1 or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
         return
+    pick_device(args, 0, args.gpus)         # refuses here, before any rank starts, when GPUs would be shared
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.exit(subprocess.call(cmd))
+
+
+def pick_device(args, local_rank, world) -> int:
+    """One process per GPU (the reference spawns one process per rank, server/server.py:252-265).  A box with
+    fewer GPUs than ranks is refused unless --rehearsal says the ranks may share devices."""
+    ndev = torch.cuda.device_count()
+    if ndev <= 0:
+        raise SystemExit("bench.py needs a GPU")
+    if world > ndev and not args.rehearsal:
+        raise SystemExit(f"--gpus {world} but this box has {ndev} GPU(s): ranks would share devices and the line "
+                         f"would not be an N-GPU measurement; pass --rehearsal to run it anyway (labelled)")
+    return local_rank % ndev if args.rehearsal else local_rank
+
+
+def device_identity(rank, local_rank, device_index):
+    props = torch.cuda.get_device_properties(device_index)
+    uuid = str(getattr(props, "uuid", "")) or f"{socket.gethostname()}:{device_index}"
+    return {"rank": rank, "host": socket.gethostname(), "local_rank": local_rank, "device": device_index,
+            "name": props.name, "uuid": uuid}
+
+
+def gather_identities(me, world, group=None):
+    """Every rank's (host, device, UUID): the proof that an N-GPU line ran on N devices."""
+    import torch.distributed as dist
+    seen = [None] * world
+    if world > 1:
+        dist.all_gather_object(seen, me, group=group)
+    else:
+        seen = [me]
+    return seen
+
+
+def devices_seen(seen) -> int:
+    return len({(r["host"], r["uuid"]) for r in seen})
+
+
+def rccl_sanity(world, device_index, shared):
+    """One RCCL SUM all-reduce over all ranks (a fresh nccl group beside the gloo one): the N replicas
+    can talk over xGMI, and their count is what the launcher said.  Ranks that share a GPU cannot form an
+    RCCL communicator (RCCL refuses two ranks on one device): reported, not attempted."""
+    import torch.distributed as dist
+    if world <= 1:
+        return None, None
+    if shared:
+        return None, "not attempted: ranks share a GPU (rehearsal) and RCCL refuses two ranks on one device"
+    try:
+        g = dist.new_group(list(range(world)), backend="nccl")
+        t = torch.ones(1, dtype=torch.float32, device=f"cuda:{device_index}")
+        dist.all_reduce(t, group=g)
+        torch.cuda.synchronize()
+        return int(round(float(t.item()))), None
+    except Exception as e:        # noqa: BLE001 - reported in the line; the measurement does not depend on it
+        return None, f"{type(e).__name__}: {e}"
 
 
 def build_engine(args, device_index, seed, tp_rank=0, tp_size=1):
@@ -714,14 +771,7 @@ def tp_main(args, rank, local_rank, world):
         e1.record()
         barrier()
         ar_us = e0.elapsed_time(e1) / len(xs) * 1e3
-    seen = [None] * world
-    me = (rank, socket.gethostname(), local_rank, torch.cuda.get_device_name(local_rank),
-          str(torch.cuda.get_device_properties(local_rank).uuid) if hasattr(
-              torch.cuda.get_device_properties(local_rank), "uuid") else "")
-    if world > 1:
-        dist.all_gather_object(seen, me)
-    else:
-        seen = [me]
+    seen = gather_identities(device_identity(rank, int(os.environ.get("LOCAL_RANK", "0")), local_rank), world)
     if ca is not None:
         ca.close()
     if rank != 0:
@@ -740,7 +790,8 @@ def tp_main(args, rank, local_rank, world):
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(best / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "strong" if dp == 1 else "weak", "vs_baseline": None,
            "dtype": "bf16", "data": "synthetic (random-init weights, random KV, seeded contexts and slot permutation)",
-           "config": {"workload": f"{args.model} TP={tp} bf16 decode bs={args.bs} seq_len=1, "
+           "config": {"workload": ("REHEARSAL (ranks share a GPU: not an xGMI measurement) " if shared else "")
+                                  + f"{args.model} TP={tp} bf16 decode bs={args.bs} seq_len=1, "
                                   f"ctx={'U[128,4096] seed 0' if args.ctx == 'uniform' else args.ctx}, page_size=1",
                       "tp": tp, "dp_replicas": dp, "layers": cfg.num_hidden_layers,
                       "backend": "RCCL (nccl)" if backend == "nccl" else
@@ -754,8 +805,8 @@ def tp_main(args, rank, local_rank, world):
            "allreduce_us_per_call": None if ar_us is None else round(ar_us, 1), "allreduce_bytes": ar_bytes,
            "allreduces_per_step": 2 * cfg.num_hidden_layers + 1,
            "step_frac_of_hbm_roofline_per_rank": round(args.bs / (best / args.steps) / roof, 4),
-           "ranks_seen": len(seen), "devices_seen": len({(h, dv) for _, h, dv, _, _ in seen}),
-           "ranks": [{"rank": r, "host": h, "device": dv, "name": nm} for r, h, dv, nm, _ in seen]}
+           "ranks_seen": len(seen), "devices_seen": devices_seen(seen), "rehearsal": bool(shared),
+           "ranks": [{k: r[k] for k in ("rank", "host", "device", "name", "uuid")} for r in seen]}
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -770,8 +821,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     import torch.distributed as dist
-    # one process per GPU; a box with fewer GPUs than ranks (rehearsals) shares devices round-robin
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    launcher_local_rank = local_rank
+    local_rank = pick_device(args, local_rank, world)
     torch.cuda.set_device(local_rank)
     from scratchpad_amd import _native
     from scratchpad_amd.model_runner import TpModelWorker
@@ -785,6 +836,11 @@ def main():
         # replicas share nothing on the data path: the only cross-rank traffic is the timing barrier
         # and the max over ranks of the elapsed time, so a host-side (gloo) group is all that is needed
         dist.init_process_group("gloo")
+    # who runs where, before anything is built: an N-GPU line must come from N distinct devices
+    seen = gather_identities(device_identity(rank, launcher_local_rank, local_rank), world)
+    shared = devices_seen(seen) < world
+    if shared and not args.rehearsal:      # (pick_device already refuses on one host; this covers odd launchers)
+        raise SystemExit(f"{world} ranks on {devices_seen(seen)} device(s): refusing without --rehearsal")
     if args.mode == "prefill":
         if args.steps == 64:
             args.steps, args.warmup = 3, 1
@@ -912,6 +968,7 @@ def main():
                                    "prompt_tokens": sum(lens_p), "extend_batches": nb_p, "pass_ms": round(el_p * 1e3, 1)},
                 "roofline_prefill": prefill_roofline(prof_p)}
         barrier()
+    rccl_ranks, rccl_note = rccl_sanity(world, local_rank, shared)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -939,6 +996,14 @@ def main():
         "step_hbm_roofline_tokens_per_sec": round(step_roofline_tok_s, 1),
         "step_frac_of_hbm_roofline": round(value / world / step_roofline_tok_s, 4),
     }
+    if world > 1:
+        # the proof of N devices (a replica line must not be able to lie about n_gpus)
+        if shared:
+            out["config"]["workload"] = "REHEARSAL (ranks share a GPU: not an N-GPU measurement) " + \
+                out["config"]["workload"]
+        out.update({"ranks_seen": len(seen), "devices_seen": devices_seen(seen), "rehearsal": bool(shared),
+                    "rccl_ranks": rccl_ranks, "rccl_note": rccl_note,
+                    "ranks": [{k: r[k] for k in ("rank", "host", "device", "name", "uuid")} for r in seen]})
     if ttft is not None:
         out.update(ttft)
     if roofline is not None:

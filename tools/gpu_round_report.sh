@@ -24,9 +24,9 @@ cut -c1-140 $R/bench_fp8kv.json
 timeout -k 10 300 python bench.py --model llama3-70b-tp8-rank --bs 128 --no-cpu-baseline --no-ttft 2>/dev/null | tail -1 > $R/bench_70b_rank.json || exit 1
 # config 4 rehearsals on this 1-GPU box (ranks share the GPU: gloo, or the direct IPC all-reduce) and the
 # self-launching replica mode; the real thing needs the 8-GPU node: python bench.py --mode tp --gpus 8
-timeout -k 10 300 python bench.py --mode tp --gpus 2 --tp 2 --layers 8 --steps 8 --warmup 2 2>/dev/null | tail -1 > $R/bench_tp2_rehearsal_gloo.json || exit 1
-SP_CUSTOM_ALLREDUCE=1 timeout -k 10 300 python bench.py --mode tp --gpus 2 --tp 2 --layers 8 --steps 8 --warmup 2 2>/dev/null | tail -1 > $R/bench_tp2_rehearsal_direct.json || exit 1
-timeout -k 10 300 python bench.py --gpus 2 --layers 8 --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $R/bench_replicas2_rehearsal.json || exit 1
+timeout -k 10 300 python bench.py --rehearsal --mode tp --gpus 2 --tp 2 --layers 8 --steps 8 --warmup 2 2>/dev/null | tail -1 > $R/bench_tp2_rehearsal_gloo.json || exit 1
+SP_CUSTOM_ALLREDUCE=1 timeout -k 10 300 python bench.py --rehearsal --mode tp --gpus 2 --tp 2 --layers 8 --steps 8 --warmup 2 2>/dev/null | tail -1 > $R/bench_tp2_rehearsal_direct.json || exit 1
+timeout -k 10 300 python bench.py --rehearsal --gpus 2 --layers 8 --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $R/bench_replicas2_rehearsal.json || exit 1
 cut -c1-200 $R/bench_tp2_rehearsal_gloo.json
 timeout -k 10 200 python tools/stamp_extend_attn.py --waves 8 > $R/extend_stamps.log 2>&1 || { tail -5 $R/extend_stamps.log; exit 1; }
 timeout -k 10 500 python tools/bench_mllama.py > $R/mllama.log 2>&1 || { tail -20 $R/mllama.log; exit 1; }
