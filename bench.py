@@ -1004,6 +1004,7 @@ def main():
         out.update({"ranks_seen": len(seen), "devices_seen": devices_seen(seen), "rehearsal": bool(shared),
                     "rccl_ranks": rccl_ranks, "rccl_note": rccl_note,
                     "ranks": [{k: r[k] for k in ("rank", "host", "device", "name", "uuid")} for r in seen]})
+    out["library_rows"] = _native.library_rows_report()     # which projections ran with a substituted row count
     if ttft is not None:
         out.update(ttft)
     if roofline is not None:

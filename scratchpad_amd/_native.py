@@ -535,8 +535,17 @@ def skinny_gemm_pays(M: int, N: int, K: int) -> bool:
 # (shape, M) pairs the product of M rows is computed as the first M rows of an M' > M row product: the input is
 # re-viewed over M' rows of its OWN storage (every activation this package allocates carries ROW_SLACK spare rows
 # behind it; whatever they hold only reaches output rows that are sliced away), no copy, no extra launch.
+#
+# The table is a measurement of ONE library build, so it is gated on that build (SP_LIBRARY_ROWS):
+#   "table" (default) - the table below, used only while torch / HIP report the versions it was measured on;
+#   "auto"            - nothing is assumed: ModelRunner.init_cuda_graphs() times every (projection shape, graph
+#                       bucket) against M' = M + 8 .. M + ROW_SLACK on the box it runs on and keeps a substitute
+#                       only where it measured faster (calibrate_library_rows); on this build that reproduces the
+#                       table, on another library it falls back to M wherever the table's entry does not pay;
+#   "0"               - off: every product is run with the row count it was asked for.
 ROW_SLACK = 64
-_LIBRARY_ROWS = {
+_LIBRARY_ROWS_MEASURED_ON = {"torch": "2.10", "hip": "7.0"}      # version prefixes of the build the table is for
+_LIBRARY_ROWS_TABLE = {
     (6144, 4096): {136: 176, 144: 176, 152: 176, 192: 200, 224: 232, 256: 264},      # qkv_proj  (8B)
     (4096, 4096): {96: 104, 192: 208},                                                # o_proj
     (28672, 4096): {16: 40, 48: 56, 80: 96},                                          # gate_up_proj
@@ -546,15 +555,97 @@ _LIBRARY_ROWS = {
     (8192, 3584): {192: 208, 224: 232, 256: 264},                                     # down_proj / 8
     (1280, 8192): {64: 72},                                                           # qkv_proj / 8
 }
-_LIBROWS_ON = os.environ.get("SP_LIBRARY_ROWS", "1") != "0"
-SLACK_MAX_ROWS = 256          # decode-sized steps only; prefill products are left exactly as F.linear
+SLACK_MAX_ROWS = 256          # decode-sized steps only; larger products are exactly F.linear
+
+
+def library_versions_match() -> bool:
+    hip = getattr(torch.version, "hip", None) or ""
+    return (torch.__version__.startswith(_LIBRARY_ROWS_MEASURED_ON["torch"])
+            and hip.startswith(_LIBRARY_ROWS_MEASURED_ON["hip"]))
+
+
+def _library_rows_mode() -> str:
+    m = os.environ.get("SP_LIBRARY_ROWS", "table").lower()
+    return {"1": "table", "on": "table", "off": "0"}.get(m, m)
+
+
+_LIBROWS_MODE = _library_rows_mode()
+if _LIBROWS_MODE == "table" and library_versions_match():
+    _LIBRARY_ROWS = {k: dict(v) for k, v in _LIBRARY_ROWS_TABLE.items()}
+else:
+    _LIBRARY_ROWS = {}        # off, another library build, or "auto" before calibrate_library_rows() has run
+_LIBROWS_USED = {}            # (N, K, M) -> M' of every substitution made so far (reported by bench.py)
 
 
 def library_rows(M: int, N: int, K: int) -> int:
     """rows to hand the library GEMM for an M-row product of shape (N, K): M, or the measured better M' > M"""
-    if not _LIBROWS_ON:
-        return M
     return _LIBRARY_ROWS.get((N, K), {}).get(M, M)
+
+
+def library_rows_report() -> dict:
+    """What bench.py records: the mode, whether the version gate passed, and every substitution that was used."""
+    return {"mode": _LIBROWS_MODE, "versions_match": library_versions_match(),
+            "measured_on": dict(_LIBRARY_ROWS_MEASURED_ON),
+            "running_on": {"torch": torch.__version__, "hip": getattr(torch.version, "hip", None)},
+            "substituted": {f"N={n} K={k} M={m}": mp for (n, k, m), mp in sorted(_LIBROWS_USED.items())}}
+
+
+def _time_mm(x: torch.Tensor, weights, reps: int = 3) -> float:
+    """device microseconds of x @ W.T, one call per weight captured into a HIP graph (the weights of different
+    layers are cycled so that no call finds its weights in L2 / the Infinity Cache, as in the decode step)"""
+    outs = [torch.empty((x.shape[0], w.shape[0]), dtype=x.dtype, device=x.device) for w in weights[:2]]
+    st = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        for i, w in enumerate(weights):
+            torch.mm(x, w.t(), out=outs[i % 2])
+        st.synchronize()
+        with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+            for i, w in enumerate(weights):
+                torch.mm(x, w.t(), out=outs[i % 2])
+    torch.cuda.synchronize()
+    g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (reps * len(weights)) * 1e3
+
+
+def calibrate_library_rows(weights_by_shape, rows, min_gain: float = 0.05, step: int = 8) -> dict:
+    """SP_LIBRARY_ROWS=auto.  weights_by_shape: {(N, K): [weight tensors of that shape]} (the model's own
+    projections); rows: the batch-size buckets of the decode graphs.  Every (shape, M) is timed against
+    M' = M + step .. M + ROW_SLACK; a substitute is kept only where it is at least `min_gain` faster than M
+    itself ON THIS BOX.  Replaces the active table and returns it."""
+    global _LIBRARY_ROWS
+    found = {}
+    for (N, K), ws in weights_by_shape.items():
+        ws = list(ws)[:8]
+        if not ws or ws[0].dtype not in (torch.float16, torch.bfloat16) or not ws[0].is_cuda:
+            continue
+        xbuf = torch.randn((max(rows) + ROW_SLACK, K), device=ws[0].device).to(ws[0].dtype) * 0.1
+        cache = {}
+
+        def t_of(m):
+            if m not in cache:
+                cache[m] = _time_mm(xbuf[:m], ws)
+            return cache[m]
+
+        for M in sorted(set(rows)):
+            if not 16 < M <= SLACK_MAX_ROWS:        # <= 16 rows: the skinny kernel's territory
+                continue
+            base = t_of(M)
+            best_t, best_m = base, M
+            for Mp in range((M // step + 1) * step, M + ROW_SLACK + 1, step):
+                t = t_of(Mp)
+                if t < best_t:
+                    best_t, best_m = t, Mp
+            if best_m != M and best_t <= base * (1.0 - min_gain):
+                found.setdefault((N, K), {})[M] = best_m
+    _LIBRARY_ROWS = found
+    return found
 
 
 def empty_rows(rows: int, cols: int, dtype, device, zero: bool = False) -> torch.Tensor:
@@ -578,7 +669,8 @@ def extend_rows(x: torch.Tensor, rows: int) -> Optional[torch.Tensor]:
 def linear(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """x @ weight.T.  Small-batch 16-bit products go to the weight-streaming kernel
     (sp_gemm_skinny) where it pays; everything else is the library GEMM - exactly F.linear, except
-    that a decode-sized product may be computed over more rows than asked for (library_rows)."""
+    that a product of at most SLACK_MAX_ROWS rows whose (shape, rows) is in the active library_rows
+    table is computed over more rows than asked for (first M rows returned; rows are independent)."""
     if (_SKINNY_ON and x.is_cuda and x.dim() == 2 and 0 < x.shape[0] <= SKINNY_MAX_ROWS
             and skinny_gemm_pays(x.shape[0], weight.shape[0], x.shape[1])
             and x.dtype in (torch.float16, torch.bfloat16) and weight.dtype == x.dtype
@@ -591,7 +683,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
         _check(load().sp_gemm_skinny(out.data_ptr(), x.data_ptr(), weight.data_ptr(), M, N, K, x.stride(0),
                                      weight.stride(0), out.stride(0), _dt(x), _stream()), "sp_gemm_skinny")
         return out
-    if (x.is_cuda and x.dim() == 2 and 0 < x.shape[0] <= SLACK_MAX_ROWS and weight.dim() == 2
+    if (_LIBRARY_ROWS and x.is_cuda and x.dim() == 2 and 0 < x.shape[0] <= SLACK_MAX_ROWS and weight.dim() == 2
             and x.dtype in (torch.float16, torch.bfloat16) and weight.dtype == x.dtype and x.stride(1) == 1):
         M, K = x.shape
         N = weight.shape[0]
@@ -599,7 +691,16 @@ def linear(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
         xe = extend_rows(x, Mp) if Mp > M else x
         if xe is None:                      # producer without spare rows (e.g. the embedding): run as asked
             xe, Mp = x, M
-        out = torch.empty((Mp + ROW_SLACK, N), dtype=x.dtype, device=x.device)
-        torch.mm(xe, weight.t(), out=out[:Mp])
-        return out[:M]
+        # the output carries spare rows only where another measured projection may consume it (one whose input
+        # width is this output's width); anything else - the LM head above all - is exactly F.linear
+        if Mp > M or _feeds_a_measured_shape(N):
+            if Mp > M:
+                _LIBROWS_USED[(N, K, M)] = Mp
+            out = torch.empty((Mp + ROW_SLACK, N), dtype=x.dtype, device=x.device)
+            torch.mm(xe, weight.t(), out=out[:Mp])
+            return out[:M]
     return torch.nn.functional.linear(x, weight)
+
+
+def _feeds_a_measured_shape(width: int) -> bool:
+    return any(k == width for (_n, k) in _LIBRARY_ROWS)

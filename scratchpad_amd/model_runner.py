@@ -205,7 +205,24 @@ class ModelRunner:
         """model_runner.py:490-504."""
         if self.server_args.disable_cuda_graph:
             return
+        if _native._LIBROWS_MODE == "auto":
+            # SP_LIBRARY_ROWS=auto: measure, on this box and this library build, which graph buckets are
+            # cheaper when the library is handed a few more rows (_native.calibrate_library_rows)
+            self.library_rows_table = _native.calibrate_library_rows(
+                self._projection_weights(),
+                get_batch_sizes_to_capture(self.server_args, self.req_to_token_pool.size))
         self.graph_runner = HipGraphRunner(self)
+
+    def _projection_weights(self):
+        """{(N, K): [weights]} of every projection that goes through _native.linear (one list per shape: the
+        layers' weights are cycled by the calibration so that no call finds its weights in a cache)."""
+        by_shape = {}
+        for mod in self.model.modules():
+            w = getattr(mod, "weight", None)
+            if isinstance(w, torch.nn.Parameter) and w.dim() == 2 and hasattr(mod, "shard_from_full") \
+                    and not isinstance(mod, torch.nn.Embedding) and type(mod).__name__ != "VocabParallelEmbedding":
+                by_shape.setdefault((w.shape[0], w.shape[1]), []).append(w.data)
+        return by_shape
 
     # ------------------------------------------------------------------ forward
     def _run_model(self, forward_batch: ForwardBatch) -> LogitsProcessorOutput:

@@ -78,3 +78,33 @@ def test_linear_hands_the_library_a_faster_row_count_and_returns_the_same_rows(d
         if Mp > M:
             assert _native.extend_rows(tight, Mp) is None
         check(_native.linear(tight, w), x, w, dtype)
+
+
+def test_library_rows_auto_calibration_keeps_only_what_measures_faster_here():
+    """SP_LIBRARY_ROWS=auto (_native.calibrate_library_rows): every (shape, bucket) is timed on THIS box against
+    M + 8 .. M + ROW_SLACK rows; a substitute is kept only with a measured gain, and whatever the table then says,
+    linear() returns the first M rows of the M'-row library product bit for bit."""
+    from scratchpad_amd import _native
+    saved = {k: dict(v) for k, v in _native._LIBRARY_ROWS.items()}
+    g = torch.Generator().manual_seed(5)
+    try:
+        ws = [(torch.randn(6144, 4096, generator=g) * 0.02).to(torch.bfloat16).cuda() for _ in range(4)]
+        table = _native.calibrate_library_rows({(6144, 4096): ws}, [192, 256])
+        assert _native._LIBRARY_ROWS is table or _native._LIBRARY_ROWS == table
+        for (N, K), sub in table.items():
+            assert (N, K) == (6144, 4096)
+            for M, Mp in sub.items():
+                assert M in (192, 256) and M < Mp <= M + _native.ROW_SLACK and Mp % 8 == 0
+        print("auto-calibrated rows for qkv_proj (N 6144, K 4096):", table, "; shipped table:",
+              _native._LIBRARY_ROWS_TABLE[(6144, 4096)])
+        for M in (192, 256):
+            x = _native.empty_rows(M, 4096, torch.bfloat16, "cuda")
+            torch.as_strided(x, (M + _native.ROW_SLACK, 4096), (4096, 1)).fill_(float("nan"))
+            x.copy_((torch.randn(M, 4096, generator=g) * 0.5).to(torch.bfloat16))
+            got = _native.linear(x, ws[0])
+            Mp = _native.library_rows(M, 6144, 4096)
+            xe = _native.extend_rows(x, Mp)
+            ref = torch.mm(xe, ws[0].t())[:M]
+            assert torch.equal(got, ref) and torch.isfinite(got.float()).all()
+    finally:
+        _native._LIBRARY_ROWS = saved

@@ -341,7 +341,36 @@ def test_spare_row_views_and_library_row_table():
     part = torch.zeros(10, 16)[2:6, :8]                   # row-strided view in the middle of a buffer
     assert _native.extend_rows(part, 8).shape == (8, 8) and _native.extend_rows(part, 9) is None
     assert _native.extend_rows(x, 3) is x
-    for (N, K), table in _native._LIBRARY_ROWS.items():
+    for (N, K), table in _native._LIBRARY_ROWS_TABLE.items():
         for M, Mp in table.items():
-            assert M < Mp <= M + _native.ROW_SLACK and _native.library_rows(M, N, K) == Mp
+            assert M < Mp <= M + _native.ROW_SLACK
+            if _native._LIBROWS_MODE == "table" and _native.library_versions_match():
+                assert _native.library_rows(M, N, K) == Mp
     assert _native.library_rows(255, 6144, 4096) == 255 and _native.library_rows(256, 1234, 4096) == 256
+
+
+def test_library_row_table_is_gated_on_the_build_it_was_measured_on(monkeypatch):
+    """The (shape, M) -> M' table is a measurement of one hipBLASLt build: on another torch / HIP version, with
+    SP_LIBRARY_ROWS=0, and under SP_LIBRARY_ROWS=auto before the calibration has run, nothing is substituted."""
+    import importlib
+    import torch
+    from scratchpad_amd import _native
+    try:
+        monkeypatch.setenv("SP_LIBRARY_ROWS", "table")
+        monkeypatch.setattr(torch, "__version__", "2.11.0+rocm7.1")
+        importlib.reload(_native)
+        assert not _native.library_versions_match() and _native._LIBRARY_ROWS == {}
+        assert _native.library_rows(256, 6144, 4096) == 256
+        rep = _native.library_rows_report()
+        assert rep["versions_match"] is False and rep["substituted"] == {}
+        monkeypatch.undo()
+        for mode in ("0", "auto"):
+            monkeypatch.setenv("SP_LIBRARY_ROWS", mode)
+            importlib.reload(_native)
+            assert _native._LIBROWS_MODE == mode and _native.library_rows(256, 6144, 4096) == 256
+        monkeypatch.undo()
+    finally:
+        monkeypatch.undo()
+        importlib.reload(_native)
+    if _native.library_versions_match():
+        assert _native.library_rows(256, 6144, 4096) == 264
