@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 3
+#define SP_ABI_VERSION 4
 #define SP_API __attribute__((visibility("default")))
 
 typedef enum { SP_F32 = 0, SP_F16 = 1, SP_BF16 = 2, SP_FP8_E5M2 = 3 /* KV pool only */ } sp_dtype;
@@ -255,10 +255,14 @@ SP_API int sp_gemm_skinny(void* out, const void* x, const void* w, int M, int N,
  *      reduce-scatter + all-gather above); `regions[r]` = rank r's region as mapped in this process;
  *      calls are collective (every rank issues the same sequence; the call counters live in the regions,
  *      so the launch is graph-capturable - the role of pynccl inside the reference's graphs,
- *      parallel_state.py:256-302).  sp_ar_status reads the region's status word (1 = a peer barrier timed
- *      out, results since then are invalid); it synchronises and is meant for check points, not the call
- *      path.  Opt-in (see allreduce.hip: not yet run across xGMI).  sp_ar_alloc/import are the only
- *      entries that allocate; the region is owned by the caller's object.                              */
+ *      parallel_state.py:256-302).
+ *      Failure is collective: a peer barrier that waits longer than `timeout_us` (<= 0: 30 s) raises the
+ *      status word of EVERY rank's region and the caller's `host_status` word (device pointer of the pinned
+ *      word from sp_ar_host_status_alloc, or NULL), which the host reads as plain memory at every forward
+ *      boundary; a launch that finds its region's status raised raises its own host word and stops
+ *      waiting.  sp_ar_status reads the region's status word through a synchronising copy (check points).
+ *      Opt-in (see allreduce.hip: not yet run across xGMI).  sp_ar_alloc / sp_ar_ipc_import /
+ *      sp_ar_host_status_alloc are the only entries that allocate; the caller's object owns the memory.  */
 SP_API size_t sp_ar_flag_bytes(void);
 SP_API int sp_ar_alloc(void** ptr, size_t bytes);
 SP_API int sp_ar_free(void* ptr);
@@ -266,8 +270,26 @@ SP_API int sp_ar_ipc_export(void* ptr, void* handle64);
 SP_API int sp_ar_ipc_import(const void* handle64, void** ptr);
 SP_API int sp_ar_ipc_close(void* ptr);
 SP_API int sp_ar_status(const void* own_region, int* status);
+SP_API int sp_ar_host_status_alloc(void** host_ptr, void** device_ptr);
+SP_API int sp_ar_host_status_free(void* host_ptr);
 SP_API int sp_custom_all_reduce(void* out, const void* in, int64_t num_elems, int dtype, void* const* regions,
-                         int rank, int world, size_t data_bytes, void* stream);
+                         int rank, int world, size_t data_bytes, int64_t timeout_us, void* host_status,
+                         void* stream);
+
+/* ---- Fused all-reduce + residual add + RMSNorm on the same regions: RowParallelLinear's all-reduce
+ *      (nn/layers/linear.py:1148-1149) followed by the next RMSNorm(x, residual) of the decoder layer
+ *      (nn/models/llama/llama.py:216, 222, 268 -> nn/layers/layernorm.py:22-32), 2 x layers per step.
+ *      x [T, hidden]: this rank's partial sums in, the normalised activations out; residual [T, hidden]
+ *      in/out.  Bit for bit  x <- sp_custom_all_reduce(x); sp_fused_add_rmsnorm(x, residual, w, eps)
+ *      (one rounding of the fp32 rank-order sum, then the norm kernel's rounding points and summation
+ *      order).  One-shot up to 256 KiB, else reduce-scatter by rows + gather of the bf16 sums with the
+ *      norm applied on arrival.  Collective, graph-capturable, same failure protocol as above.
+ *      SP_ERR_UNSUPPORTED (caller runs the two-step form): hidden not a multiple of the 16-byte vector or
+ *      above 8192 elements, unaligned pointers/strides.  Strides in elements.                           */
+SP_API int sp_fused_allreduce_add_rmsnorm(void* x, void* residual, const void* weight, int64_t num_tokens,
+                                   int hidden, int64_t x_stride, int64_t res_stride, float eps, int dtype,
+                                   void* const* regions, int rank, int world, size_t data_bytes,
+                                   int64_t timeout_us, void* host_status, void* stream);
 
 #ifdef __cplusplus
 }

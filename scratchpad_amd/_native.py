@@ -74,7 +74,11 @@ SIGNATURES = {
     "sp_ar_ipc_import": (_i32, [_vp, _vp]),
     "sp_ar_ipc_close": (_i32, [_vp]),
     "sp_ar_status": (_i32, [_vp, _vp]),
-    "sp_custom_all_reduce": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _sz, _vp]),
+    "sp_ar_host_status_alloc": (_i32, [_vp, _vp]),
+    "sp_ar_host_status_free": (_i32, [_vp]),
+    "sp_custom_all_reduce": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _sz, _i64, _vp, _vp]),
+    "sp_fused_allreduce_add_rmsnorm": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp, _i32, _i32,
+                                              _sz, _i64, _vp, _vp]),
     "sp_gemm_skinny": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp]),
 }
 
@@ -97,7 +101,7 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.sp_abi_version() != 3:
+    if lib.sp_abi_version() != 4:
         raise RuntimeError("libscratchpad_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -21,7 +21,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hi
 # extend_mfma.hip: without -fno-honor-nans every fmaxf on an MFMA result is preceded by a canonicalising
 # v_max_f32 x, x (58 instead of 25 vector instructions for a tile's row maximum); nothing in that file
 # relies on NaN propagation (masked scores are -inf, never NaN)
-PER_FILE_FLAGS = {"elementwise.hip": ["-ffp-contract=off"], "extend_mfma.hip": ["-fno-honor-nans"]}
+# allreduce.hip: its fused all-reduce + add + RMSNorm kernel reproduces elementwise.hip's norm bit for bit
+PER_FILE_FLAGS = {"elementwise.hip": ["-ffp-contract=off"], "allreduce.hip": ["-ffp-contract=off"],
+                  "extend_mfma.hip": ["-fno-honor-nans"]}
 
 
 def _newer(target, deps):

@@ -1,16 +1,25 @@
 """Direct all-reduce for the TP group: the object GroupCoordinator.ca_comm expects
 (distributed/parallel_state.py:266-267, 326-347: ``should_custom_ar(t)``, ``custom_all_reduce(t)``,
 ``capture()``).  The reference declares the slot and leaves it None; here it can be filled with the IPC
-kernel of csrc/allreduce.hip (opt-in: ``SP_CUSTOM_ALLREDUCE=1``; RCCL stays the default and the
-fallback for large or unaligned messages).
+kernels of csrc/allreduce.hip (opt-in: ``SP_CUSTOM_ALLREDUCE=1``; RCCL stays the default and carries
+large or unaligned messages).  On top of the reference's interface it offers the fusion of the
+row-parallel all-reduce with the residual add + RMSNorm that follows it in every decoder layer
+(``fused_all_reduce_add_rmsnorm``; linear.py:1148-1149 -> llama.py:216/222 -> layernorm.py:22-32).
 
-Set-up: every rank allocates one fine-grained region (flags + call counters + status | data | reduced),
-exports its IPC handle, the handles travel over the group's gloo twin, and every rank maps every region.
-Per call: one kernel launch with call-independent arguments (the epoch counters are device state), so
-the launch can be captured into a HIP graph and replayed - a captured decode step needs no library
-collective.  A peer barrier that times out raises the region's status word: ``check()`` reads it (after
-every call with ``SP_CUSTOM_ALLREDUCE_DEBUG=1``, always in ``close()``; ``bench.py --mode tp`` calls it
-after its timed regions) and raises; the communicator then hands every later call to RCCL."""
+Set-up: every rank allocates one fine-grained region (flags + call counters + status | data | reduced)
+and one pinned host status word, exports the region's IPC handle, the handles travel over the group's
+gloo twin, and every rank maps every region.  Per call: one kernel launch with call-independent arguments
+(the epoch counters are device state), so the launch can be captured into a HIP graph and replayed - a
+captured decode step needs no library collective.
+
+Failure handling (a time-out is FATAL and COLLECTIVE): a peer barrier that waits longer than
+``SP_CUSTOM_ALLREDUCE_TIMEOUT_S`` (default 30 s of wall clock) raises the status word of every rank's
+region and the timing-out rank's host word; every later launch on any rank sees its region's word, raises
+its own host word and stops waiting.  ``poll()`` reads the host word as plain memory - no synchronisation
+- and raises; ModelRunner.forward() calls it at every forward / graph-replay boundary, ``check()`` (a
+synchronising read of the region itself) runs in ``close()`` and after timed bench regions.  There is no
+per-rank fallback to RCCL after a failure: a rank that changed transport alone would mismatch its peers'
+collectives, so every later call raises as well."""
 import contextlib
 import ctypes
 import os
@@ -35,9 +44,14 @@ class CustomAllReduce:
         self.data_bytes = int(max_bytes)
         self.flag_bytes = int(lib.sp_ar_flag_bytes())
         self.region_bytes = self.flag_bytes + 2 * self.data_bytes
+        self.timeout_us = int(float(os.environ.get("SP_CUSTOM_ALLREDUCE_TIMEOUT_S", "30")) * 1e6)
         own = ctypes.c_void_p()
         _native._check(lib.sp_ar_alloc(ctypes.byref(own), self.region_bytes), "sp_ar_alloc")
         self._own = own.value
+        host, dev = ctypes.c_void_p(), ctypes.c_void_p()
+        _native._check(lib.sp_ar_host_status_alloc(ctypes.byref(host), ctypes.byref(dev)), "sp_ar_host_status_alloc")
+        self._host_status, self._host_status_dev = host.value, dev.value
+        self._host_word = ctypes.c_uint32.from_address(self._host_status)
         handle = ctypes.create_string_buffer(64)
         _native._check(lib.sp_ar_ipc_export(self._own, handle), "sp_ar_ipc_export")
         handles = [None] * self.world
@@ -55,42 +69,99 @@ class CustomAllReduce:
             self._mapped.append(peer.value)
         self._regions = regions
         self._capturing = False
-        self.failed = False          # a barrier timed out: every later call goes to RCCL
+        self.failed = False          # a barrier timed out somewhere in the group: every later call raises
         self.calls = 0
+        self.fused_calls = 0
+        self.fuse_norm = os.environ.get("SP_CUSTOM_ALLREDUCE_FUSE_NORM", "1") != "0"
         self.debug = os.environ.get("SP_CUSTOM_ALLREDUCE_DEBUG", "0") == "1"
         torch.distributed.barrier(group=group.cpu_group)
 
     # ---- the ca_comm interface --------------------------------------------------------------
-    def should_custom_ar(self, t: torch.Tensor) -> bool:
+    def _eligible(self, t: torch.Tensor) -> bool:
         nbytes = t.numel() * t.element_size()
-        return (not self.failed and t.is_cuda and t.is_contiguous() and nbytes % 16 == 0
+        return (t.is_cuda and t.is_contiguous() and nbytes % 16 == 0
                 and 0 < nbytes <= self.data_bytes and t.data_ptr() % 16 == 0
                 and t.dtype in (torch.float32, torch.float16, torch.bfloat16))
+
+    def should_custom_ar(self, t: torch.Tensor) -> bool:
+        # a pure function of the tensor's shape / dtype / alignment: the same answer on every rank (the
+        # failure state is NOT part of it - a failed communicator raises instead of changing transport)
+        return self._eligible(t)
+
+    def _fail_if_failed(self):
+        if self.failed:
+            raise RuntimeError(f"direct all-reduce: the communicator failed earlier (rank {self.rank}); "
+                               "the TP group must be torn down")
 
     def custom_all_reduce(self, t: torch.Tensor) -> Optional[torch.Tensor]:
         if not self.should_custom_ar(t):
             return None
+        self._fail_if_failed()
         out = torch.empty_like(t)
         _native._check(self.lib.sp_custom_all_reduce(out.data_ptr(), t.data_ptr(), t.numel(), _native._dt(t),
                                                      self._regions, self.rank, self.world, self.data_bytes,
+                                                     self.timeout_us, self._host_status_dev,
                                                      _native._stream()), "sp_custom_all_reduce")
         self.calls += 1
         if self.debug and not self._capturing:
             self.check()
         return out
 
+    def should_fuse_norm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor) -> bool:
+        """Shape-only decision (identical on every rank) whether the fused kernel takes this call."""
+        if not self.fuse_norm or x.dim() != 2 or residual.shape != x.shape or residual.dtype != x.dtype:
+            return False
+        vec = 16 // x.element_size()
+        H = x.shape[1]
+        return (self._eligible(x) and residual.is_cuda and residual.stride(1) == 1 and H % vec == 0 and H <= 8192
+                and residual.stride(0) % vec == 0 and residual.data_ptr() % 16 == 0 and weight.numel() == H)
+
+    def fused_all_reduce_add_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
+                                     eps: float) -> bool:
+        """x: this rank's partial sums [T, hidden].  In place: residual <- round(all_reduce(x) + residual),
+        x <- RMSNorm(residual) * weight - bit for bit custom_all_reduce(x) followed by
+        _native.fused_add_rmsnorm(x, residual, weight, eps).  False (nothing done) when the shape is not
+        taken: the caller runs the two-step form."""
+        if not self.should_fuse_norm(x, residual, weight):
+            return False
+        self._fail_if_failed()
+        w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+        if w.data_ptr() % 16:
+            return False
+        _native._check(self.lib.sp_fused_allreduce_add_rmsnorm(
+            x.data_ptr(), residual.data_ptr(), w.data_ptr(), x.shape[0], x.shape[1], x.stride(0),
+            residual.stride(0), float(eps), _native._dt(x), self._regions, self.rank, self.world,
+            self.data_bytes, self.timeout_us, self._host_status_dev, _native._stream()),
+            "sp_fused_allreduce_add_rmsnorm")
+        self.fused_calls += 1
+        if self.debug and not self._capturing:
+            self.check()
+        return True
+
+    # ---- failure detection --------------------------------------------------------------------
+    def poll(self) -> None:
+        """Non-blocking: read the pinned host status word the kernels raise on a time-out (no stream
+        synchronisation, no copy).  Cheap enough for every forward boundary."""
+        if self._host_status is not None and self._host_word.value != 0:
+            self._raise_failed("poll")
+
     def check(self) -> None:
-        """Read the status word of this rank's region (synchronises).  Raises if a peer barrier timed
-        out since the communicator was created; the communicator is then disabled."""
+        """Synchronising: read the status word of this rank's region itself (check points: close(), after a
+        timed bench region, every call in debug mode)."""
         if self._own is None:
             return
         status = ctypes.c_int(0)
         _native._check(self.lib.sp_ar_status(self._own, ctypes.byref(status)), "sp_ar_status")
-        if status.value != 0:
-            self.failed = True
-            raise RuntimeError(
-                f"direct all-reduce: a peer barrier timed out on rank {self.rank} (after {self.calls} calls); "
-                "results since then are invalid - falling back to RCCL for the rest of the run")
+        if status.value != 0 or self._host_word.value != 0:
+            self._raise_failed("check")
+
+    def _raise_failed(self, where: str):
+        self.failed = True
+        raise RuntimeError(
+            f"direct all-reduce ({where}): a peer barrier timed out in the TP group (seen on rank {self.rank} after "
+            f"{self.calls} all-reduce / {self.fused_calls} fused calls, time-out {self.timeout_us / 1e6:.0f} s); "
+            "results since then are invalid on EVERY rank - the failure is published to all regions, every rank "
+            "raises at its next poll, and the group must be torn down")
 
     @contextlib.contextmanager
     def capture(self):
@@ -114,6 +185,9 @@ class CustomAllReduce:
             if self._own:
                 self.lib.sp_ar_free(self._own)
                 self._own = None
+            if self._host_status:
+                self.lib.sp_ar_host_status_free(self._host_status)
+                self._host_status = None
 
 
 def maybe_attach(group) -> Optional[CustomAllReduce]:

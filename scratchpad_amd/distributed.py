@@ -61,6 +61,22 @@ class GroupCoordinator:
         dist.all_reduce(input_, group=self.device_group)
         return input_
 
+    def fused_all_reduce_add_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
+                                     eps: float) -> bool:
+        """RowParallelLinear's all-reduce (linear.py:1148-1149) + the RMSNorm(x, residual) that follows it
+        (llama.py:216, 222) as ONE kernel, when the custom all-reduce slot is filled and takes the shape:
+        in place on x and residual, True.  False: nothing was done, the caller runs all_reduce() and the norm.
+        The decision depends on shapes only, so every rank takes the same branch."""
+        ca_comm = self.ca_comm
+        if self.world_size == 1 or ca_comm is None or not hasattr(ca_comm, "fused_all_reduce_add_rmsnorm"):
+            return False
+        return ca_comm.fused_all_reduce_add_rmsnorm(x, residual, weight, eps)
+
+    def poll(self) -> None:
+        """Raise if the custom all-reduce has reported a failure (host-visible status word; no sync)."""
+        if self.ca_comm is not None and hasattr(self.ca_comm, "poll"):
+            self.ca_comm.poll()
+
     def all_gather(self, input_: torch.Tensor, dim: int = -1) -> torch.Tensor:
         world_size = self.world_size
         if world_size == 1:
@@ -132,6 +148,12 @@ class _SingleRankGroup:
 
     def all_gather(self, input_, dim: int = -1):
         return input_
+
+    def fused_all_reduce_add_rmsnorm(self, x, residual, weight, eps) -> bool:
+        return False
+
+    def poll(self) -> None:
+        pass
 
     def broadcast_object(self, obj=None, src: int = 0):
         return obj

@@ -19,7 +19,7 @@ from torch import nn
 from . import _native
 from .attention import RadixAttention
 from .distributed import (divide, get_tensor_model_parallel_rank,
-                          get_tensor_model_parallel_world_size, tensor_model_parallel_all_gather,
+                          get_tensor_model_parallel_world_size, get_tp_group, tensor_model_parallel_all_gather,
                           tensor_model_parallel_all_reduce)
 from .forward_info import ForwardBatch
 from .layers import RMSNorm, SiluAndMul, get_rope
@@ -157,11 +157,23 @@ class RowParallelLinear(_ShardedLinear):
         n = self.input_size_per_partition
         return full[:, rank * n:(rank + 1) * n]
 
-    def forward(self, x):
+    def forward(self, x, reduce_output: bool = True):
+        """reduce_output=False leaves this rank's PARTIAL sums: the caller owes them the all-reduce and
+        pays it inside the next norm (norm_after_row_parallel)."""
         out = _native.linear(x, self.weight)
-        if self.reduce_results and self.tp_size > 1:
+        if self.reduce_results and reduce_output and self.tp_size > 1:
             out = tensor_model_parallel_all_reduce(out)
         return out, None
+
+
+def norm_after_row_parallel(norm: RMSNorm, x_partial: torch.Tensor, residual: torch.Tensor):
+    """RMSNorm(all_reduce(x_partial), residual): the all-reduce RowParallelLinear would have run
+    (linear.py:1148-1149) and the fused-add RMSNorm that follows it in the decoder layer (llama.py:216,
+    222, 268), as one kernel where the TP group's custom all-reduce offers it, else as the same two steps
+    the unfused path runs - the results are bit-identical either way."""
+    if get_tp_group().fused_all_reduce_add_rmsnorm(x_partial, residual, norm.weight.data, norm.variance_epsilon):
+        return x_partial, residual
+    return norm(tensor_model_parallel_all_reduce(x_partial), residual)
 
 
 class VocabParallelEmbedding(nn.Module):
@@ -236,10 +248,10 @@ class LlamaMLP(nn.Module):
             raise ValueError(f"Unsupported activation: {hidden_act}. Only silu is supported for now.")
         self.act_fn = SiluAndMul()
 
-    def forward(self, x):
+    def forward(self, x, reduce_output: bool = True):
         gate_up, _ = self.gate_up_proj(x)
         x = self.act_fn(gate_up)
-        x, _ = self.down_proj(x)
+        x, _ = self.down_proj(x, reduce_output)
         return x
 
 
@@ -277,7 +289,7 @@ class LlamaAttention(nn.Module):
                                    num_kv_heads=self.num_kv_heads, layer_id=layer_id)
 
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor,
-                forward_batch: ForwardBatch) -> torch.Tensor:
+                forward_batch: ForwardBatch, reduce_output: bool = True) -> torch.Tensor:
         qkv, _ = self.qkv_proj(hidden_states)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         backend = forward_batch.attn_backend
@@ -289,7 +301,7 @@ class LlamaAttention(nn.Module):
         else:
             q, k = self.rotary_emb(positions, q, k)       # in place on the qkv views
             attn_output = self.attn(q, k, v, forward_batch)
-        output, _ = self.o_proj(attn_output)
+        output, _ = self.o_proj(attn_output, reduce_output)
         return output
 
 
@@ -311,16 +323,26 @@ class LlamaDecoderLayer(nn.Module):
         self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
     def forward(self, positions, hidden_states, forward_batch: ForwardBatch,
-                residual: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+                residual: Optional[torch.Tensor], defer_reduce: bool = False
+                ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """llama.py:202-224.  defer_reduce (tensor parallelism only): the all-reduces of o_proj and
+        down_proj are paid inside the norm that follows each of them (norm_after_row_parallel), so the
+        hidden_states that come IN (from the previous layer's down_proj) and go OUT are partial sums."""
         if residual is None:
             residual = hidden_states
             hidden_states = self.input_layernorm(hidden_states)
+        elif defer_reduce:
+            hidden_states, residual = norm_after_row_parallel(self.input_layernorm, hidden_states, residual)
         else:
             hidden_states, residual = self.input_layernorm(hidden_states, residual)
         hidden_states = self.self_attn(positions=positions, hidden_states=hidden_states,
-                                       forward_batch=forward_batch)
-        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
-        hidden_states = self.mlp(hidden_states)
+                                       forward_batch=forward_batch, reduce_output=not defer_reduce)
+        if defer_reduce:
+            hidden_states, residual = norm_after_row_parallel(self.post_attention_layernorm, hidden_states,
+                                                              residual)
+        else:
+            hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        hidden_states = self.mlp(hidden_states, reduce_output=not defer_reduce)
         return hidden_states, residual
 
 
@@ -338,9 +360,14 @@ class LlamaModel(nn.Module):
                 input_embeds: torch.Tensor = None) -> torch.Tensor:
         hidden_states = self.embed_tokens(input_ids) if input_embeds is None else input_embeds
         residual = None
+        # under TP every row-parallel all-reduce is handed to the norm behind it (2 x layers per step)
+        defer = get_tensor_model_parallel_world_size() > 1
         for layer in self.layers:
-            hidden_states, residual = layer(positions, hidden_states, forward_batch, residual)
-        hidden_states, _ = self.norm(hidden_states, residual)
+            hidden_states, residual = layer(positions, hidden_states, forward_batch, residual, defer)
+        if defer:
+            hidden_states, _ = norm_after_row_parallel(self.norm, hidden_states, residual)
+        else:
+            hidden_states, _ = self.norm(hidden_states, residual)
         return hidden_states
 
 

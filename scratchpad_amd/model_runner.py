@@ -240,6 +240,9 @@ class ModelRunner:
         return self._run_model(forward_batch)
 
     def forward(self, forward_batch: ForwardBatch) -> LogitsProcessorOutput:
+        # every forward / graph-replay boundary: has a direct all-reduce of an EARLIER step timed out?
+        # (a read of a pinned host word the kernels raise, no synchronisation; raises on every rank)
+        dist_.get_tp_group().poll()
         if (forward_batch.forward_mode.is_cuda_graph() and self.graph_runner is not None
                 and self.graph_runner.can_run(forward_batch)):
             return self.graph_runner.replay(forward_batch)

@@ -95,8 +95,10 @@ def _rank_main(rank, world, port, case, q, custom_ar=False):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,case,custom_ar", [(2, "a", False), (2, "b", False), (4, "a", False), (2, "b", True)],
-                         ids=["tp2-kv-replicated", "tp2-kv-sharded", "tp4-kv-replicated", "tp2-direct-all-reduce"])
+@pytest.mark.parametrize("world,case,custom_ar", [(2, "a", False), (2, "b", False), (4, "a", False), (2, "b", True),
+                                                  (4, "a", True)],
+                         ids=["tp2-kv-replicated", "tp2-kv-sharded", "tp4-kv-replicated", "tp2-direct-all-reduce",
+                              "tp4-direct-all-reduce-fused-norm"])
 def test_sharded_forward_matches_unsharded_oracle(world, case, custom_ar):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -183,6 +185,176 @@ def test_direct_all_reduce_through_ipc_regions(world):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_ar_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err in results:
+        assert err is None, f"rank {rank}:\n{err}"
+
+
+def _fused_main(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        from scratchpad_amd import _native, distributed as d
+        from scratchpad_amd.custom_all_reduce import CustomAllReduce
+        d.init_distributed_environment(world, rank, f"tcp://127.0.0.1:{port}", 0, backend="gloo")
+        d.initialize_model_parallel(world, backend="gloo", local_rank=0)
+        torch.cuda.set_device(0)
+        tp = d.get_tp_group()
+        ca = CustomAllReduce(tp, max_bytes=4 << 20)
+        tp.ca_comm = ca
+        gen = torch.Generator().manual_seed(200)        # the same stream on every rank: rank r's input is slice r
+        eps = 1e-5
+        # (dtype, T, hidden): two-shot at 70B's [128, 8192], one-shot below 256 KiB, fewer rows than ranks, rows
+        # that do not divide by the world size, fp16 / fp32, Llama-3-8B's width
+        cases = ((torch.bfloat16, 128, 8192), (torch.bfloat16, 8, 8192), (torch.bfloat16, 1, 8192),
+                 (torch.bfloat16, 3, 4096), (torch.bfloat16, 130, 8192), (torch.float16, 40, 4096),
+                 (torch.float32, 7, 1024), (torch.float32, 70, 2048), (torch.bfloat16, 256, 4096))
+        for dtype, T, H in cases:
+            for rep in range(2):
+                allx = (torch.randn(world, T, H, generator=gen) * 2.0).to(dtype)
+                res0 = (torch.randn(T, H, generator=gen) * 3.0).to(dtype).cuda()     # replicated, like the residual stream
+                w = (1.0 + 0.25 * torch.randn(H, generator=gen)).to(dtype).cuda()
+                # the two-step form: all-reduce (direct kernel), then the fused-add RMSNorm kernel
+                y = ca.custom_all_reduce(allx[rank].cuda())
+                res_ref = res0.clone()
+                _native.fused_add_rmsnorm(y, res_ref, w, eps)
+                # the one-kernel form, in place on the partial sums and the residual
+                x = allx[rank].cuda()
+                res = res0.clone()
+                assert tp.fused_all_reduce_add_rmsnorm(x, res, w, eps) is True
+                torch.cuda.synchronize()
+                assert torch.equal(res, res_ref), ("residual", rank, dtype, T, H, rep)
+                assert torch.equal(x, y), ("normed", rank, dtype, T, H, rep,
+                                           float((x.float() - y.float()).abs().max()))
+                # and against plain torch on the host: sum in fp32, one rounding, add, norm
+                s = allx.float().sum(0).to(dtype).float() + res0.float().cpu()
+                want = (s * torch.rsqrt(s.pow(2).mean(-1, keepdim=True) + eps)).to(dtype).float() * w.float().cpu()
+                tol = {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10, torch.float32: 1e-5}[dtype]
+                err = (x.float().cpu() - want).abs()
+                assert bool((err <= tol * want.abs() + tol).all()), (rank, dtype, T, H, float(err.max()))
+        # shapes the fused kernel does not take are refused on every rank alike, nothing touched
+        odd = torch.zeros(4, 8200, dtype=torch.bfloat16, device="cuda")
+        assert tp.fused_all_reduce_add_rmsnorm(odd, odd.clone(), torch.ones(8200, dtype=torch.bfloat16, device="cuda"), eps) is False
+        # captured into a HIP graph next to a plain all-reduce, replayed with fresh inputs, eager calls in between
+        T, H = 128, 8192
+        xs = torch.zeros(T, H, dtype=torch.bfloat16, device="cuda")
+        rs = torch.zeros(T, H, dtype=torch.bfloat16, device="cuda")
+        w = (1.0 + 0.25 * torch.randn(H, generator=gen)).to(torch.bfloat16).cuda()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            tp.fused_all_reduce_add_rmsnorm(xs, rs, w, eps)
+            d.tensor_model_parallel_all_reduce(xs)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with ca.capture(), torch.cuda.graph(graph):
+            tp.fused_all_reduce_add_rmsnorm(xs, rs, w, eps)
+            again = d.tensor_model_parallel_all_reduce(xs)          # a dependent plain all-reduce in the same graph
+        for rep in range(3):
+            allx = torch.randn(world, T, H, generator=gen).to(torch.bfloat16)
+            res0 = torch.randn(T, H, generator=gen).to(torch.bfloat16).cuda()
+            y = ca.custom_all_reduce(allx[rank].cuda())
+            res_ref = res0.clone()
+            _native.fused_add_rmsnorm(y, res_ref, w, eps)
+            xs.copy_(allx[rank])
+            rs.copy_(res0)
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(rs, res_ref) and torch.equal(xs, y), ("graph replay", rank, rep)
+            assert torch.equal(again.float(), (y.float() * world).to(torch.bfloat16).float())
+        ca.poll()
+        ca.check()
+        assert not ca.failed and ca.fused_calls > 0
+        torch.distributed.barrier()
+        ca.close()
+        q.put((rank, None))
+    except Exception:
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_fused_all_reduce_add_rmsnorm_is_bit_identical_to_the_two_step_form(world):
+    """sp_fused_allreduce_add_rmsnorm (the TP path of config 4: o_proj / down_proj all-reduce + the next
+    RMSNorm(x, residual), linear.py:1148-1149 -> llama.py:216/222) against sp_custom_all_reduce followed by
+    sp_fused_add_rmsnorm: bit-identical x and residual, one-shot and two-shot, eager and replayed from a HIP
+    graph.  Ranks share this GPU (IPC within one device): NOT a test of xGMI transport."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fused_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err in results:
+        assert err is None, f"rank {rank}:\n{err}"
+
+
+def _timeout_main(rank, world, port, q):
+    try:
+        import time
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["SP_CUSTOM_ALLREDUCE_TIMEOUT_S"] = "0.5"
+        from scratchpad_amd import distributed as d
+        from scratchpad_amd.custom_all_reduce import CustomAllReduce
+        d.init_distributed_environment(world, rank, f"tcp://127.0.0.1:{port}", 0, backend="gloo")
+        d.initialize_model_parallel(world, backend="gloo", local_rank=0)
+        torch.cuda.set_device(0)
+        tp = d.get_tp_group()
+        ca = CustomAllReduce(tp, max_bytes=1 << 20)
+        x = torch.ones(64, 1024, dtype=torch.bfloat16, device="cuda")
+        y = ca.custom_all_reduce(x)                     # a healthy call first
+        torch.cuda.synchronize()
+        assert float(y[0, 0]) == world
+        ca.poll()
+        tp.barrier()
+        if rank == 0:
+            # rank 1 does not show up for this call: the barrier gives up after 0.5 s of WALL CLOCK, publishes the
+            # failure to both regions and to this rank's host word
+            t0 = time.perf_counter()
+            ca.custom_all_reduce(x)
+            torch.cuda.synchronize()
+            waited = time.perf_counter() - t0
+            assert 0.3 <= waited <= 10.0, f"time-out of 0.5 s took {waited:.2f} s"
+            with pytest.raises(RuntimeError, match="timed out"):
+                ca.poll()                               # no synchronisation needed: a pinned host word
+            assert ca.failed
+            with pytest.raises(RuntimeError, match="failed earlier"):
+                ca.custom_all_reduce(x)                 # no silent change of transport on one rank
+        tp.barrier()
+        if rank == 1:
+            # the peer's failure reached this rank's region: its next launch does not wait, raises the host word
+            t0 = time.perf_counter()
+            ca.custom_all_reduce(x)
+            torch.cuda.synchronize()
+            assert time.perf_counter() - t0 < 0.3, "a launch after a published failure must not wait for the peer"
+            with pytest.raises(RuntimeError, match="timed out"):
+                ca.poll()
+        tp.barrier()
+        try:
+            ca.close()
+        except RuntimeError:
+            pass                                        # close() checks the region once more: failed, as expected
+        q.put((rank, None))
+    except Exception:
+        q.put((rank, traceback.format_exc()))
+
+
+def test_direct_all_reduce_timeout_is_published_to_every_rank():
+    """ADVICE r2 (medium): a barrier time-out must not stay rank-local and silent.  Rank 1 skips a collective;
+    rank 0's kernel gives up after the configured wall-clock bound, raises both regions' status words and its
+    host word; poll() (a host-memory read) raises on rank 0, and rank 1 learns of it at its next launch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_timeout_main, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in procs]
