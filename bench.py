@@ -771,6 +771,34 @@ def tp_main(args, rank, local_rank, world):
         e1.record()
         barrier()
         ar_us = e0.elapsed_time(e1) / len(xs) * 1e3
+    # the collective TOGETHER with what follows it in every layer half (residual add + RMSNorm): as the two
+    # launches of the unfused path, and as the one fused kernel where the direct all-reduce offers it
+    ar_norm_two_step_us = ar_norm_fused_us = None
+    if tp > 1:
+        from scratchpad_amd import _native as nat
+        wn = torch.ones(cfg.hidden_size, dtype=torch.bfloat16, device=mr.device)
+        res = torch.randn(args.bs, cfg.hidden_size, device=mr.device).to(torch.bfloat16)
+
+        def time_pairs(fn, n=50):
+            xs_ = [x.clone() for _ in range(n)]
+            for xi in xs_[:5]:
+                fn(xi)
+            barrier()
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            for xi in xs_:
+                fn(xi)
+            a1.record()
+            barrier()
+            return a0.elapsed_time(a1) / n * 1e3
+
+        def two_step(xi):
+            y = d.tensor_model_parallel_all_reduce(xi)
+            nat.fused_add_rmsnorm(y, res, wn, 1e-5)
+
+        ar_norm_two_step_us = time_pairs(two_step)
+        if ca is not None and ca.should_fuse_norm(x, res, wn):
+            ar_norm_fused_us = time_pairs(lambda xi: tpg.fused_all_reduce_add_rmsnorm(xi, res, wn, 1e-5))
     seen = gather_identities(device_identity(rank, int(os.environ.get("LOCAL_RANK", "0")), local_rank), world)
     if ca is not None:
         ca.close()
@@ -804,6 +832,10 @@ def tp_main(args, rank, local_rank, world):
            "graph_ms_per_step": None if graph_s is None else round(graph_s / args.steps * 1e3, 3),
            "allreduce_us_per_call": None if ar_us is None else round(ar_us, 1), "allreduce_bytes": ar_bytes,
            "allreduces_per_step": 2 * cfg.num_hidden_layers + 1,
+           "allreduce_plus_norm_us": {"two_launches": None if ar_norm_two_step_us is None else round(ar_norm_two_step_us, 1),
+                                      "fused_kernel": None if ar_norm_fused_us is None else round(ar_norm_fused_us, 1),
+                                      "per_step_calls": 2 * cfg.num_hidden_layers,
+                                      "fused_in_model": bool(ca is not None and ca.fused_calls > 0)},
            "step_frac_of_hbm_roofline_per_rank": round(args.bs / (best / args.steps) / roof, 4),
            "ranks_seen": len(seen), "devices_seen": devices_seen(seen), "rehearsal": bool(shared),
            "ranks": [{k: r[k] for k in ("rank", "host", "device", "name", "uuid")} for r in seen]}

@@ -127,9 +127,27 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  * A row with seq_lens[b] == 0 (no visible key) is left untouched: pre-fill `out` where that can
  * happen (cross-attention of text-only requests).
  * kv_start may be NULL (= 0); it is the encoder offset of encoder-decoder models
- * (flashinfer_backend.py:593-621).  `chunk` tokens per split and `max_seq_len` (an upper bound
- * on every seq_lens[b], e.g. the context length under graph capture) fix the launch geometry:
- * num_splits = ceil(max_seq_len / chunk).  workspace: sp_decode_attention_workspace_bytes().
+ * (flashinfer_backend.py:593-621).  `max_seq_len`: an upper bound on every seq_lens[b] (the context
+ * length under graph capture); a device-side seq_lens[b] above it is clamped to it, never followed.
+ *
+ * Split-KV geometry (ABI 4).  A request is cut into splits of `chunk` keys; split c of request b writes
+ * its partial (o, log-sum-exp) to SLOT slot0[b] + c of the workspace ([max_slots, Hq, D] + [max_slots, Hq]
+ * floats) and one merge wave per (request, head) combines them.
+ *   - Without a plan the grid is the static (request, split) rectangle: slot0[b] = b * num_splits,
+ *     num_splits = ceil(max_seq_len / chunk), max_slots is ignored (= batch_size * num_splits).
+ *   - With a `plan` (sp_decode_plan: [count, chunk, slot0[bs], (b, c) x count], built once per step from
+ *     the same seq_lens and shared by all layers - the counterpart of flashinfer's begin_forward()/plan,
+ *     flashinfer_backend.py:623-670, and of TritonAttnBackend.init_forward_metadata,
+ *     triton_backend.py:48-68) the launch covers `max_slots` work items, the kernels read the split size
+ *     FROM THE PLAN (device memory) and slot0[b] is the exclusive scan of the requests' split counts.  So the
+ *     launch geometry - what a HIP graph captures - is a function of (batch_size, heads, max_slots) only:
+ *     one captured launch follows whatever split size each step's plan was built with, and the workspace is
+ *     bounded by sum(seq_lens) / chunk + batch_size slots (sp_decode_plan_slots), not by the context
+ *     length (the reference's static attn_logits buffer is [bs, heads, max_context_len],
+ *     triton_backend.py:70-80).  `chunk` is then the SMALLEST split size the plan may carry (it only decides
+ *     whether the merge launch is needed).  Items are listed longest first (XCD load balance on ragged
+ *     batches); a plan never changes the result, only which workgroup computes which split.
+ * workspace: sp_decode_attention_workspace_bytes(max_slots, ...); plan: sp_decode_plan_bytes().
  *
  * `kv_dtype` = `dtype`, or SP_FP8_E5M2 for a uint8 pool written by sp_kv_store_fp8 (16-bit q
  * only; kv_buffer_stride then counts bytes): the kernels widen e5m2 to half exactly and compute
@@ -138,27 +156,19 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  *
  * `k_scale`, `v_scale` (> 0; 1.0 = none): the layer's KV scales, the same values the store divided
  * by (flashinfer_backend.py:470-482 passes layer.k_scale / layer.v_scale to both): the pool holds
- * k / k_scale and v / v_scale, so logits are multiplied by k_scale and the output by v_scale.
- * A device-side seq_lens[b] above num_splits * chunk is clamped to it (the bound the plan and
- * the workspace were sized for), never followed past them.
- *
- * `plan` (optional, may be NULL): the list of non-empty (request, split) items built by
- * sp_decode_plan() from the same seq_lens / chunk, once per step, shared by all layers - the
- * counterpart of flashinfer's begin_forward()/plan (flashinfer_backend.py:623-670) and of
- * TritonAttnBackend.init_forward_metadata (triton_backend.py:48-68).  It changes only which
- * workgroup does which split (XCD load balance on ragged batches), never the result.             */
-SP_API size_t sp_decode_attention_workspace_bytes(int batch_size, int num_q_heads, int v_head_dim,
-                                           int64_t max_seq_len, int chunk);
-SP_API size_t sp_decode_plan_bytes(int batch_size, int64_t max_seq_len, int chunk);
+ * k / k_scale and v / v_scale, so logits are multiplied by k_scale and the output by v_scale.    */
+SP_API int64_t sp_decode_plan_slots(int batch_size, int64_t kv_tokens, int64_t max_seq_len, int chunk);
+SP_API size_t sp_decode_attention_workspace_bytes(int64_t max_slots, int num_q_heads, int v_head_dim);
+SP_API size_t sp_decode_plan_bytes(int batch_size, int64_t max_slots);
 SP_API int sp_decode_plan(int32_t* plan, size_t plan_bytes, const void* seq_lens, int idx64,
-                   int batch_size, int64_t max_seq_len, int chunk, void* stream);
+                   int batch_size, int64_t max_seq_len, int chunk, int64_t max_slots, void* stream);
 SP_API int sp_decode_attention(void* out, const void* q, const void* k_buffer, const void* v_buffer,
                         const int32_t* req_to_token, int64_t req_to_token_stride,
                         const void* req_pool_indices, const void* seq_lens, const void* kv_start,
                         int idx64, int batch_size, int num_q_heads, int num_kv_heads,
                         int head_dim, int64_t q_stride, int64_t out_stride,
                         int64_t kv_buffer_stride, float sm_scale, float logit_cap, float k_scale,
-                        float v_scale, int64_t max_seq_len, int chunk, void* workspace,
+                        float v_scale, int64_t max_seq_len, int chunk, int64_t max_slots, void* workspace,
                         size_t workspace_bytes, const int32_t* plan, int dtype, int kv_dtype,
                         void* stream);
 

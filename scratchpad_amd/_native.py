@@ -47,11 +47,12 @@ SIGNATURES = {
     "sp_write_req_to_token": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "sp_compute_position": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp]),
     "sp_clamp_position": (_i32, [_vp, _vp, _i32, _i32, _vp]),
-    "sp_decode_attention_workspace_bytes": (_sz, [_i32, _i32, _i32, _i64, _i32]),
-    "sp_decode_plan_bytes": (_sz, [_i32, _i64, _i32]),
-    "sp_decode_plan": (_i32, [_vp, _sz, _vp, _i32, _i32, _i64, _i32, _vp]),
+    "sp_decode_plan_slots": (_i64, [_i32, _i64, _i64, _i32]),
+    "sp_decode_attention_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "sp_decode_plan_bytes": (_sz, [_i32, _i64]),
+    "sp_decode_plan": (_i32, [_vp, _sz, _vp, _i32, _i32, _i64, _i32, _i64, _vp]),
     "sp_decode_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32,
-                                   _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _i64, _i32,
+                                   _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _i64, _i32, _i64,
                                    _vp, _sz, _vp, _i32, _i32, _vp]),
     "sp_extend_attention_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32]),
     "sp_extend_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp,
@@ -312,23 +313,40 @@ def _idx_pair(req_pool_indices: torch.Tensor, seq_lens: torch.Tensor):
     return req_pool_indices.contiguous(), seq_lens.contiguous(), int(seq_lens.dtype == torch.int64)
 
 
-def decode_workspace_bytes(bs: int, Hq: int, Dv: int, max_seq_len: int, chunk: int) -> int:
-    return int(load().sp_decode_attention_workspace_bytes(bs, Hq, Dv, max_seq_len, chunk))
+def decode_plan_slots(bs: int, max_seq_len: int, chunk: int, kv_tokens: Optional[int] = None) -> int:
+    """Partial slots (= work items) a decode step can need: min(bs * ceil(max_seq_len / chunk),
+    kv_tokens // chunk + bs), kv_tokens = a bound on sum(seq_lens) (None: the first bound alone)."""
+    return int(load().sp_decode_plan_slots(bs, -1 if kv_tokens is None else int(kv_tokens), max_seq_len, chunk))
 
 
-def decode_plan_bytes(bs: int, max_seq_len: int, chunk: int) -> int:
-    return int(load().sp_decode_plan_bytes(bs, max_seq_len, chunk))
+def decode_workspace_bytes(bs: int, Hq: int, Dv: int, max_seq_len: int, chunk: int,
+                           max_slots: Optional[int] = None) -> int:
+    """Split workspace for `max_slots` partial slots (default: the static bound bs * ceil(max_seq_len / chunk))."""
+    if max_slots is None:
+        max_slots = decode_plan_slots(bs, max_seq_len, chunk)
+    return int(load().sp_decode_attention_workspace_bytes(max_slots, Hq, Dv))
 
 
-def decode_plan(plan: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int, chunk: int) -> None:
-    """Fill `plan` (int32) with the non-empty (request, split) items of this step."""
+def decode_plan_bytes(bs: int, max_seq_len: int, chunk: int, max_slots: Optional[int] = None) -> int:
+    if max_slots is None:
+        max_slots = decode_plan_slots(bs, max_seq_len, chunk)
+    return int(load().sp_decode_plan_bytes(bs, max_slots))
+
+
+def decode_plan(plan: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int, chunk: int,
+                max_slots: Optional[int] = None) -> None:
+    """Fill `plan` (int32: [count, chunk, slot0[bs], (request, split) x count]) for this step's lengths.
+    `max_slots`: the item / partial-slot capacity the launches using this plan are given (default: the static
+    bound bs * ceil(max_seq_len / chunk))."""
     _gpu(plan, seq_lens)
     if plan.dtype != torch.int32 or seq_lens.dtype not in (torch.int32, torch.int64):
         raise RuntimeError("decode_plan: plan must be int32, seq_lens int32/int64")
     seq_lens = seq_lens.contiguous()
+    if max_slots is None:
+        max_slots = decode_plan_slots(seq_lens.shape[0], max_seq_len, chunk)
     _check(load().sp_decode_plan(plan.data_ptr(), plan.numel() * 4, seq_lens.data_ptr(),
                                  int(seq_lens.dtype == torch.int64), seq_lens.shape[0], max_seq_len,
-                                 chunk, _stream()), "sp_decode_plan")
+                                 chunk, max_slots, _stream()), "sp_decode_plan")
 
 
 def decode_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
@@ -337,9 +355,10 @@ def decode_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
                      logit_cap: float, max_seq_len: int, chunk: int, workspace: torch.Tensor,
                      kv_start: Optional[torch.Tensor] = None,
                      plan: Optional[torch.Tensor] = None, k_scale: Optional[float] = None,
-                     v_scale: Optional[float] = None) -> None:
+                     v_scale: Optional[float] = None, max_slots: Optional[int] = None) -> None:
     """q, out: [bs, Hq, D] (row stride free); buffers [P+1, Hkv, D].  k_scale / v_scale: the
-    scales the store divided by (None = 1)."""
+    scales the store divided by (None = 1).  With a plan: `max_slots` = the capacity the plan was built
+    for, `chunk` = the smallest split size the plan may carry (the kernels read the actual one from it)."""
     _gpu(out, q, k_buffer, v_buffer, req_to_token, req_pool_indices, seq_lens, workspace, kv_start, plan)
     bs, Hq, D = q.shape
     if q.stride(2) != 1 or q.stride(1) != D or out.stride(2) != 1 or out.stride(1) != D:
@@ -350,12 +369,14 @@ def decode_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
     req, seq, idx64 = _idx_pair(req_pool_indices, seq_lens)
     if kv_start is not None:
         kv_start = kv_start.to(seq.dtype).contiguous()
+    if max_slots is None:
+        max_slots = decode_plan_slots(bs, max_seq_len, chunk)
     _check(load().sp_decode_attention(
         out.data_ptr(), q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), req_to_token.data_ptr(),
         req_to_token.stride(0), req.data_ptr(), seq.data_ptr(), _ptr(kv_start), idx64, bs, Hq,
         k_buffer.shape[1], D, q.stride(0), out.stride(0), k_buffer.stride(0), sm_scale, logit_cap,
         1.0 if k_scale is None else float(k_scale), 1.0 if v_scale is None else float(v_scale),
-        max_seq_len, chunk, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+        max_seq_len, chunk, max_slots, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
         _ptr(plan), _dt(q), kv_dt, _stream()), "sp_decode_attention")
 
 

@@ -110,6 +110,11 @@ class HipAttnBackend(AttentionBackend):
     # over more tiles - e.g. bs 32 x 1024: chunk 256 (256 items) 28.5 us vs chunk 64 (1024) 34.1 us
     TARGET_ITEMS = 256
     MIN_CHUNK, MAX_CHUNK = 64, 512
+    # graph replay: work items / partial slots a captured launch of bucket bs covers (the launch geometry is
+    # a function of this number only; the split size travels in the step's plan).  max(1024, 8 bs) + bs keeps
+    # 512-key splits up to a mean context of 4096 per request and lets the splits grow beyond that, so the
+    # scratch does not scale with the model's context length (131072-token contexts: the same 38 MB)
+    GRAPH_SLOTS_FLOOR, GRAPH_SLOTS_PER_REQ = 1024, 8
     # LlamaAttention may hand rotary + KV store to the backend as one kernel (sp_rotary_embedding
     # with pool arguments); set False to keep the reference's two-step order
     fused_rope_kv_store = True
@@ -127,6 +132,7 @@ class HipAttnBackend(AttentionBackend):
         self.kv_dtype = model_runner.token_to_kv_pool.dtype
         self.is_encoder_decoder = bool(getattr(cfg, "is_encoder_decoder", False))
         self.forward_metadata = None
+        self.pool_tokens = int(getattr(model_runner, "max_total_num_tokens", 0)) or None   # bounds sum(seq_lens)
         self._workspace = torch.empty(0, dtype=torch.uint8, device=self.device)
         self._plans = [torch.empty(0, dtype=torch.int32, device=self.device) for _ in range(3)]
         # Gemma-2 style models: some layers see only the last `sliding_window_size` keys + themselves
@@ -135,7 +141,8 @@ class HipAttnBackend(AttentionBackend):
         self.sliding_window_size = sw if sw not in (None, -1) else None
         self._window = None            # (lens, kv_start) of the windowed layers, this step
         self._graph_window = None
-        self._graph_state = {}         # bs bucket -> (chunk, workspace, plan buffers) of its captured graph
+        self._graph_ws = None          # graph replay: ONE partials workspace / plan-buffer triple for all buckets
+        self._graph_plans = None
         self._extend_plan = None       # int32 work list of the current extend step (sp_extend_plan)
 
     # ---------------------------------------------------------------- launch planning
@@ -157,22 +164,55 @@ class HipAttnBackend(AttentionBackend):
             self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._workspace
 
-    def _build_plans(self, plans, bs, seq_lens, encoder_lens, max_len, chunk):
-        """One split plan per kv window (self-attention lens; encoder lens for cross-attention -
-        the reference keeps two flashinfer wrappers for the same reason, flashinfer_backend.py:
-        121-131).  Built once per step, read by every layer's launch."""
-        need = _native.decode_plan_bytes(bs, max_len, chunk) // 4
-        out = []
-        window_lens = None if self._window is None else self._window[0]
-        for i, lens in enumerate((seq_lens, encoder_lens, window_lens)):
+    def _graph_slots(self, bs: int) -> int:
+        by_len = bs * -(-self.max_context_len // self.MIN_CHUNK)
+        return min(by_len, max(self.GRAPH_SLOTS_FLOOR, self.GRAPH_SLOTS_PER_REQ * bs) + bs)
+
+    def _fit_chunk(self, chunk: int, bs: int, kv_tokens: int, max_len: int, max_slots: int) -> int:
+        """the split size doubles until the step's items fit the slots the launch covers"""
+        while _native.decode_plan_slots(bs, max_len, chunk, kv_tokens) > max_slots:
+            chunk *= 2
+        return chunk
+
+    def _build_plans(self, plans, bs, windows, max_len, max_slots=None):
+        """One split plan per kv window (self-attention lens; encoder lens for cross-attention - the
+        reference keeps two flashinfer wrappers for the same reason, flashinfer_backend.py:121-131; the
+        sliding-window layers' lens).  windows: per plan (lens tensor or None, host bound on their sum).
+        Built once per step, read by every layer's launch.  Each plan carries its own split size; returns
+        per plan (tensor, max_slots, smallest chunk) and the largest max_slots (what the workspace must hold)."""
+        out, need_slots = [], 1
+        for i, (lens, kv_tokens) in enumerate(windows):
             if lens is None:
                 out.append(None)
                 continue
+            chunk = self._plan_chunk(kv_tokens, self.kv_dtype)
+            if max_slots is None:          # eager: exactly what this step can need
+                slots = max(1, _native.decode_plan_slots(bs, max_len, chunk, kv_tokens))
+            else:                          # graph replay: the captured launch's capacity is fixed
+                slots = max_slots
+                chunk = self._fit_chunk(chunk, bs, kv_tokens, max_len, slots)
+            need = _native.decode_plan_bytes(bs, max_len, chunk, slots) // 4
             if plans[i].numel() < need:
                 plans[i] = torch.empty(need, dtype=torch.int32, device=self.device)
-            _native.decode_plan(plans[i], lens, max_len, chunk)
-            out.append(plans[i])
-        return tuple(out)
+            _native.decode_plan(plans[i], lens, max_len, chunk, slots)
+            # third field: the smallest split size this plan buffer may carry when the launch runs - the
+            # step's own chunk (eager), MIN_CHUNK under graph replay (a later step's plan may use any size)
+            out.append((plans[i], slots, chunk if max_slots is None else self.MIN_CHUNK))
+            need_slots = max(need_slots, slots)
+        return tuple(out), need_slots
+
+    def _windows(self, bs, seq_lens, seq_lens_sum, encoder_lens, encoder_sum):
+        """(lens, bound on their sum) of the three kv windows of a decode step"""
+        cap = bs * self.max_context_len if self.pool_tokens is None else min(bs * self.max_context_len,
+                                                                             self.pool_tokens)
+        seq_sum = max(1, min(int(seq_lens_sum), cap))
+        enc = (None, 0)
+        if encoder_lens is not None:
+            enc = (encoder_lens, max(1, cap if encoder_sum is None else min(int(encoder_sum), cap)))
+        win = (None, 0)
+        if self._window is not None:
+            win = (self._window[0], max(1, min(seq_sum, bs * (self.sliding_window_size + 1))))
+        return (seq_lens, seq_sum), enc, win
 
     # ---------------------------------------------------------------- metadata hooks
     def init_forward_metadata(self, forward_batch: "ForwardBatch"):
@@ -189,13 +229,14 @@ class HipAttnBackend(AttentionBackend):
             else:
                 max_len = min(self.max_context_len, forward_batch.seq_lens_sum - (bs - 1))
             max_len = max(max_len, enc_max, 1)
-            chunk = self._plan_chunk(forward_batch.seq_lens_sum, pool_dtype)
-            ws = self._ensure_workspace(_native.decode_workspace_bytes(
-                bs, self.num_head, self.v_head_dim, max_len, chunk))
             enc = forward_batch.encoder_lens if self.is_encoder_decoder else None
+            enc_sum = sum(forward_batch.encoder_lens_cpu) if forward_batch.encoder_lens_cpu else None
             self._window = self._window_of(forward_batch.seq_lens)
-            plans = self._build_plans(self._plans, bs, forward_batch.seq_lens, enc, max_len, chunk)
-            self.forward_metadata = (chunk, max_len, ws, plans)
+            plans, slots = self._build_plans(self._plans, bs, self._windows(
+                bs, forward_batch.seq_lens, forward_batch.seq_lens_sum, enc, enc_sum), max_len)
+            ws = self._ensure_workspace(_native.decode_workspace_bytes(bs, self.num_head, self.v_head_dim, max_len,
+                                                                       self.MIN_CHUNK, slots))
+            self.forward_metadata = (self.MIN_CHUNK, max_len, ws, plans)
         else:
             max_extend = max(forward_batch.extend_seq_lens_cpu)
             if forward_batch.seq_lens_cpu is not None:
@@ -215,44 +256,52 @@ class HipAttnBackend(AttentionBackend):
             self.forward_metadata = (max_extend, max_len, ws)
 
     def init_cuda_graph_state(self, max_bs: int):
-        """Static split geometry + workspace for graph replay (triton_backend.py:70-80 allocates
-        static attn_logits the same way)."""
+        """Static buffers for graph replay (triton_backend.py:70-80 allocates its static attn_logits the same
+        way - but as [max_bs, heads, max_context_len]).  ONE partials workspace and ONE triple of plan buffers
+        serve every batch-size bucket: a bucket's captured launches cover _graph_slots(bs) work items, and the
+        split size is not part of the capture (it travels in the plan), so the scratch is bounded by the slots
+        of the largest bucket whatever the model's context length is."""
         self.cuda_graph_max_seq_len = self.max_context_len
-        # split geometry is part of the captured launches, so it is chosen per batch-size bucket at
-        # capture time (a bs-1 graph wants 64-key splits, a bs-256 graph 512-key ones)
-        self._graph_state = {}
+        slots = self._graph_slots(max_bs)
+        self._graph_ws = torch.empty(_native.decode_workspace_bytes(max_bs, self.num_head, self.v_head_dim,
+                                                                    self.cuda_graph_max_seq_len, self.MIN_CHUNK, slots),
+                                     dtype=torch.uint8, device=self.device)
+        n = _native.decode_plan_bytes(max_bs, self.cuda_graph_max_seq_len, self.MIN_CHUNK, slots) // 4
+        self._graph_plans = [torch.empty(n, dtype=torch.int32, device=self.device) for _ in range(3)]
+        self._graph_max_bs = max_bs
         if self.sliding_window_size is not None:
             self._graph_window = tuple(torch.ones(max_bs, dtype=torch.int32, device=self.device)
                                        for _ in range(2))
+
+    def graph_scratch_bytes(self) -> int:
+        """attention scratch held for graph replay (workspace + plan buffers), all buckets together"""
+        return self._graph_ws.numel() + sum(p.numel() * 4 for p in self._graph_plans)
+
+    def _graph_metadata(self, bs, seq_lens, seq_lens_sum, encoder_lens):
+        assert bs <= self._graph_max_bs
+        plans, _ = self._build_plans(self._graph_plans, bs, self._windows(bs, seq_lens, seq_lens_sum, encoder_lens,
+                                                                          None),
+                                     self.cuda_graph_max_seq_len, self._graph_slots(bs))
+        # MIN_CHUNK: the smallest split size a replayed plan may carry (the merge launch is always captured)
+        self.forward_metadata = (self.MIN_CHUNK, self.cuda_graph_max_seq_len, self._graph_ws, plans)
 
     def init_forward_metadata_capture_cuda_graph(self, bs, num_tokens, req_pool_indices, seq_lens,
                                                  encoder_lens, forward_mode, spec_info=None):
         assert forward_mode.is_decode(), "only decode is captured"
         assert spec_info is None, "speculative decoding is out of scope"
-        chunk = self._plan_chunk(bs * self.max_context_len // 2, self.kv_dtype)
-        ws = torch.empty(_native.decode_workspace_bytes(bs, self.num_head, self.v_head_dim,
-                                                        self.cuda_graph_max_seq_len, chunk),
-                         dtype=torch.uint8, device=self.device)
-        n = _native.decode_plan_bytes(bs, self.cuda_graph_max_seq_len, chunk) // 4
-        plan_bufs = [torch.empty(n, dtype=torch.int32, device=self.device) for _ in range(3)]
-        self._graph_state[bs] = (chunk, ws, plan_bufs)
         self._window = self._window_of(seq_lens, self._graph_window, bs)
-        plans = self._build_plans(plan_bufs, bs, seq_lens, encoder_lens, self.cuda_graph_max_seq_len, chunk)
-        self.forward_metadata = (chunk, self.cuda_graph_max_seq_len, ws, plans)
+        self._graph_metadata(bs, seq_lens, bs * self.get_cuda_graph_seq_len_fill_value(), encoder_lens)
 
     def init_forward_metadata_replay_cuda_graph(self, bs, req_pool_indices, seq_lens, seq_lens_sum,
                                                 encoder_lens, forward_mode, spec_info=None,
                                                 seq_lens_cpu=None):
-        # geometry is static and the kernels read seq_lens / req_pool_indices from the graph's
-        # static input buffers; only the split plan (static buffer, fixed address) is rebuilt for
-        # this step's lengths, ahead of the replay - where the reference recomputes start_loc /
-        # kv_indices (triton_backend.py:103-113, flashinfer_backend.py:330-373)
-        chunk, ws, plan_bufs = self._graph_state[bs]
+        # the launches are static and read seq_lens / req_pool_indices from the graph's static input
+        # buffers; only the split plans (static buffers, fixed addresses) are rebuilt for this step's
+        # lengths, ahead of the replay - where the reference recomputes start_loc / kv_indices
+        # (triton_backend.py:103-113, flashinfer_backend.py:330-373).  The split size is chosen HERE, per
+        # step, from seq_lens_sum (it is plan data, not launch geometry).
         self._window = self._window_of(seq_lens[:bs], self._graph_window, bs)
-        plans = self._build_plans(plan_bufs, bs, seq_lens[:bs],
-                                  None if encoder_lens is None else encoder_lens[:bs],
-                                  self.cuda_graph_max_seq_len, chunk)
-        self.forward_metadata = (chunk, self.cuda_graph_max_seq_len, ws, plans)
+        self._graph_metadata(bs, seq_lens[:bs], seq_lens_sum, None if encoder_lens is None else encoder_lens[:bs])
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1  # padded rows attend to the dummy slot 0 only (triton_backend.py:115-116)
@@ -364,12 +413,13 @@ class HipAttnBackend(AttentionBackend):
         chunk, max_len, ws, plans = self.forward_metadata
         k_scale, v_scale = self._kv_scales(layer)
         seq_lens, kv_start = self._kv_window(layer, forward_batch)
-        plan = plans[2] if self._is_windowed(layer) else (plans[1] if layer.is_cross_attention else plans[0])
+        entry = plans[2] if self._is_windowed(layer) else (plans[1] if layer.is_cross_attention else plans[0])
+        plan, slots, chunk = entry if entry is not None else (None, None, chunk)
         kb, vb = forward_batch.token_to_kv_pool.get_kv_buffer(layer.layer_id)
         _native.decode_attention(
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), kb, vb,
             forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices, seq_lens,
             layer.scaling, layer.logit_cap, max_len, chunk, ws, kv_start, plan,
-            k_scale=k_scale, v_scale=v_scale)
+            k_scale=k_scale, v_scale=v_scale, max_slots=slots)
         return o

@@ -19,13 +19,35 @@ struct DecodeArgs {
   int64_t q_stride, o_stride, kv_stride;  // elements
   float sm_scale, logit_cap;
   float out_scale;  // multiplies the normalised output (the pool's v_scale; 1 = none)
-  int max_len;      // num_splits * chunk: device-side seq_lens are clamped to it
-  int chunk, num_splits, hh_shift, head_groups;
-  float* part_o;    // [bs, Hq, num_splits, D]
-  float* part_lse;  // [bs, Hq, num_splits]  (log2 domain)
+  int max_len;      // host-side bound of a request's kv length: device-side seq_lens are clamped to it
+  int chunk, num_splits, hh_shift, head_groups;   // chunk / num_splits: the plan-less geometry (plan: plan[1])
+  int max_slots;    // partial slots the workspace holds; work items the launch covers when planned
+  float* part_o;    // [max_slots, Hq, D]   slot of (request b, split c): split_slot0() + c
+  float* part_lse;  // [max_slots, Hq]      (log2 domain)
   int kv8;              // 1: the pool holds fp8 e5m2 bytes (kv_stride in bytes); 16-bit q/out only
-  const int32_t* plan;  // optional: [count, chunk, (b, c) x count] from sp_decode_plan
+  // optional, from sp_decode_plan: [count, chunk, slot0[bs], (b, c) x count].  The CHUNK is part of the
+  // plan (device memory), so a captured launch follows whatever split size the step's plan was built
+  // with; slot0[b] = first partial slot of request b (exclusive scan of its split count).
+  const int32_t* plan;
 };
+
+// (request, split) of work item `item`, the split size, and the request's first partial slot
+__device__ __forceinline__ bool decode_item(const DecodeArgs& a, int item, int& b, int& c, int& chunk, int& slot0) {
+  if (a.plan) {
+    if (item >= a.plan[0]) return false;
+    chunk = a.plan[1];
+    const int32_t* items = a.plan + 2 + a.bs;
+    b = items[2 * item];
+    c = items[2 * item + 1];
+    slot0 = a.plan[2 + b];
+  } else {
+    chunk = a.chunk;
+    c = item % a.num_splits;
+    b = item / a.num_splits;
+    slot0 = b * a.num_splits;
+  }
+  return true;
+}
 
 // decode_attention.hip: launch the split-KV decode kernel (+ merge when num_splits > 1)
 int run_decode(const DecodeArgs& a, int head_dim, int group, int dtype, hipStream_t st);

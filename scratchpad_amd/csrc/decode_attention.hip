@@ -111,21 +111,14 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeArgs a) {
   // ragged batches (measured on U[128,4096] contexts: 0.74x the fixed-length rate).
   const int hg = blockIdx.x % a.head_groups;
   const int item = blockIdx.x / a.head_groups;
-  int b, c;
-  if (a.plan) {
-    if (item >= a.plan[0]) return;
-    b = a.plan[2 + 2 * item];
-    c = a.plan[3 + 2 * item];
-  } else {
-    c = item % a.num_splits;
-    b = item / a.num_splits;
-  }
+  int b, c, chunk, slot0;
+  if (!decode_item(a, item, b, c, chunk, slot0)) return;
 
   const int seq = min((int)load_idx(a.seq_lens, b, a.idx64), a.max_len);
-  const int cs = c * a.chunk;
-  if (cs >= seq) return;  // (also covers seq == 0) uniform for the whole workgroup
-  const int ce = min(cs + a.chunk, seq);
-  const int nsplit = (seq + a.chunk - 1) / a.chunk;
+  const int cs = c * chunk;
+  if (cs >= seq || slot0 + c >= a.max_slots) return;  // (also covers seq == 0) uniform for the whole workgroup
+  const int ce = min(cs + chunk, seq);
+  const int nsplit = (seq + chunk - 1) / chunk;
   const int64_t req = load_idx(a.req_idx, b, a.idx64);
   const int64_t kv0 = a.kv_start ? load_idx(a.kv_start, b, a.idx64) : 0;
   const int32_t* idx_row = a.r2t + req * a.r2t_stride + kv0;
@@ -287,7 +280,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeArgs a) {
     if (nsplit == 1) {
       E::store(a.out, (int64_t)b * a.o_stride + (int64_t)h * D + d, o * a.out_scale);
     } else {
-      const int64_t pi = ((int64_t)b * a.Hq + h) * a.num_splits + c;
+      const int64_t pi = (int64_t)(slot0 + c) * a.Hq + h;
       a.part_o[pi * D + d] = o;
       if (d == 0) a.part_lse[pi] = M + __builtin_amdgcn_logf(L);  // v_log_f32 = log2
     }
@@ -306,10 +299,16 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
   const int lane = threadIdx.x & 63;
   const int b = pair / a.Hq, h = pair - b * a.Hq;
   const int seq = min((int)load_idx(a.seq_lens, b, a.idx64), a.max_len);
-  const int nsplit = (seq + a.chunk - 1) / a.chunk;
+  const int chunk = a.plan ? a.plan[1] : a.chunk;
+  const int slot0 = a.plan ? a.plan[2 + b] : b * a.num_splits;
+  int nsplit = (seq + chunk - 1) / chunk;
   if (nsplit <= 1) return;  // written directly by the attention kernel (or empty row)
-  const float* lse = a.part_lse + (int64_t)pair * a.num_splits;
-  const float* po = a.part_o + (int64_t)pair * a.num_splits * D;
+  nsplit = min(nsplit, a.max_slots - slot0);   // never past the workspace (a plan cut short by a broken bound)
+  if (nsplit < 1) return;
+  // split c of this (request, head): slot slot0 + c, partials laid out [slot][Hq][D]
+  const int64_t sstride = a.Hq;                // slots are Hq rows apart
+  const float* lse = a.part_lse + (int64_t)slot0 * a.Hq + h;
+  const float* po = a.part_o + ((int64_t)slot0 * a.Hq + h) * D;
   constexpr int PER = D / 64;
   constexpr int GRP = 16;
   float o[PER], W = 0.f, M = kNegBig;
@@ -321,9 +320,9 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
     for (int c = 0; c < GRP; ++c) {
       const bool live = c0 + c < nsplit;
       const int cc = live ? c0 + c : c0;               // clamped: the load stays in bounds
-      ls[c] = live ? lse[cc] : kNegBig;
+      ls[c] = live ? lse[(int64_t)cc * sstride] : kNegBig;
 #pragma unroll
-      for (int e = 0; e < PER; ++e) pv[c][e] = po[(int64_t)cc * D + e * 64 + lane];
+      for (int e = 0; e < PER; ++e) pv[c][e] = po[(int64_t)cc * sstride * D + e * 64 + lane];
     }
     float Mg = M;
 #pragma unroll
@@ -346,30 +345,39 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
     E::store(a.out, (int64_t)b * a.o_stride + (int64_t)h * D + e * 64 + lane, o[e] / W * a.out_scale);
 }
 
-// Build the list of non-empty (request, split) items: plan[0] = count, plan[2+2i], plan[3+2i] =
-// (b, c).  One workgroup; requests in tiles of 256 with a running offset.  Items are emitted
-// longest-first: all full splits, then the ragged last splits in four length classes (longest
-// quarter first), so the launch ends on its shortest items.
+// Build the step's split plan: plan[0] = number of non-empty (request, split) items, plan[1] = chunk,
+// plan[2 + b] = first partial slot of request b (exclusive scan of its split count), then the items
+// (b, c) from plan[2 + bs].  One workgroup; requests in tiles of 256 with a running offset.  Items are
+// emitted longest-first: all full splits, then the ragged last splits in four length classes (longest
+// quarter first), so the launch ends on its shortest items.  The chunk travels IN the plan: the
+// attention and merge kernels read it from there, so one captured launch serves any split size.
 __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ plan,
                                                            const void* __restrict__ seq_lens,
-                                                           int idx64, int bs, int chunk, int max_len) {
+                                                           int idx64, int bs, int chunk, int max_len,
+                                                           int max_items) {
   __shared__ int s_scan[256];
   __shared__ int s_base;
-  if (threadIdx.x == 0) s_base = 0;
-  __syncthreads();
-  for (int pass = 0; pass < 5; ++pass) {
+  int32_t* items = plan + 2 + bs;
+  // pass -1: slot0[b]; pass 0: full splits; passes 1..4: ragged tails by length class
+  for (int pass = -1; pass < 5; ++pass) {
+    if (pass <= 0) {
+      __syncthreads();
+      if (threadIdx.x == 0 && pass == -1) s_base = 0;
+      if (threadIdx.x == 0 && pass == 0) s_base = 0;
+      __syncthreads();
+    }
     for (int t0 = 0; t0 < bs; t0 += 256) {
       const int b = t0 + threadIdx.x;
-      int nfull = 0, tail = 0;
+      int nfull = 0, tail = 0, rem = 0;
       if (b < bs) {
         // a length beyond the host-supplied bound would index past the plan and the partials
         const int seq = min((int)load_idx(seq_lens, b, idx64), max_len);
         nfull = seq > 0 ? seq / chunk : 0;
-        const int rem = seq > 0 ? seq % chunk : 0;
+        rem = seq > 0 ? seq % chunk : 0;
         // tail class 3 = longest quarter of the chunk ... 0 = shortest; pass 1 takes class 3
         tail = rem > 0 && (4 - pass) == (int)(((int64_t)rem * 4 - 1) / chunk) ? 1 : 0;
       }
-      const int mine = pass == 0 ? nfull : tail;
+      const int mine = pass == -1 ? nfull + (rem > 0 ? 1 : 0) : (pass == 0 ? nfull : tail);
       s_scan[threadIdx.x] = mine;
       __syncthreads();
       for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan
@@ -379,9 +387,16 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ 
         __syncthreads();
       }
       const int base = s_base + s_scan[threadIdx.x] - mine;
-      for (int i = 0; i < mine; ++i) {
-        plan[2 + 2 * (base + i)] = b;
-        plan[3 + 2 * (base + i)] = pass == 0 ? i : nfull;
+      if (pass == -1) {
+        if (b < bs) plan[2 + b] = base;
+      } else {
+        // (the host sizes max_items from its own bound on sum(seq_lens); lengths that break that bound
+        // lose their surplus items here, and the kernels skip slots >= max_items, instead of writing past
+        // the plan and the partials)
+        for (int i = 0; i < mine && base + i < max_items; ++i) {
+          items[2 * (base + i)] = b;
+          items[2 * (base + i) + 1] = pass == 0 ? i : nfull;
+        }
       }
       __syncthreads();
       if (threadIdx.x == 255) s_base += s_scan[255];
@@ -389,7 +404,7 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ 
     }
   }
   if (threadIdx.x == 0) {
-    plan[0] = s_base;
+    plan[0] = min(s_base, max_items);
     plan[1] = chunk;
   }
 }
@@ -398,7 +413,7 @@ template <typename Tag, int D, int G>
 static int launch_decode(const DecodeArgs& a, hipStream_t st) {
   typedef DecodeCfg<Tag, D, G> C;
   const size_t lds = (size_t)C::kLdsFloats * sizeof(float);
-  const unsigned grid = (unsigned)a.bs * a.num_splits * a.head_groups;
+  const unsigned grid = (unsigned)((a.plan ? (int64_t)a.max_slots : (int64_t)a.bs * a.num_splits) * a.head_groups);
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set && lds > 64 * 1024) {
     (void)hipFuncSetAttribute((const void*)decode_attn_kernel<Tag, D, G>,
@@ -519,13 +534,21 @@ static inline int64_t num_splits_for(int64_t max_seq_len, int chunk) {
   return s < 1 ? 1 : s;
 }
 
-extern "C" size_t sp_decode_attention_workspace_bytes(int batch_size, int num_q_heads,
-                                                      int v_head_dim, int64_t max_seq_len,
-                                                      int chunk) {
-  if (batch_size <= 0 || num_q_heads <= 0 || v_head_dim <= 0 || chunk <= 0) return 0;
-  const int64_t s = num_splits_for(max_seq_len, chunk);
-  if (s <= 1) return 16;
-  return (size_t)batch_size * num_q_heads * s * (v_head_dim + 1) * sizeof(float) + 16;
+// Partial slots (= work items) a step can need: every request has ceil(seq / chunk) splits, so the sum is
+// at most bs * ceil(max_seq_len / chunk) AND at most kv_tokens / chunk + bs, where kv_tokens bounds
+// sum(seq_lens) (the step's seq_lens_sum, or the KV pool size).  The second bound is what keeps the split
+// workspace independent of the model's context length.
+extern "C" int64_t sp_decode_plan_slots(int batch_size, int64_t kv_tokens, int64_t max_seq_len, int chunk) {
+  if (batch_size <= 0 || chunk <= 0) return 0;
+  const int64_t by_len = (int64_t)batch_size * num_splits_for(max_seq_len, chunk);
+  if (kv_tokens < 0) return by_len;
+  const int64_t by_sum = kv_tokens / chunk + batch_size;
+  return by_len < by_sum ? by_len : by_sum;
+}
+
+extern "C" size_t sp_decode_attention_workspace_bytes(int64_t max_slots, int num_q_heads, int v_head_dim) {
+  if (max_slots <= 0 || num_q_heads <= 0 || v_head_dim <= 0) return 16;
+  return (size_t)max_slots * num_q_heads * (v_head_dim + 1) * sizeof(float) + 16;
 }
 
 // diagnostic (not part of the forward path): resident workgroups per CU the runtime reports for the
@@ -534,19 +557,19 @@ extern "C" SP_API int sp_debug_decode_occupancy(int head_dim, int group, int dty
   return decode_occupancy(head_dim, group, dtype);
 }
 
-extern "C" size_t sp_decode_plan_bytes(int batch_size, int64_t max_seq_len, int chunk) {
-  if (batch_size <= 0 || chunk <= 0) return 16;
-  return (size_t)(2 + 2 * (int64_t)batch_size * num_splits_for(max_seq_len, chunk)) * sizeof(int32_t);
+extern "C" size_t sp_decode_plan_bytes(int batch_size, int64_t max_slots) {
+  if (batch_size <= 0 || max_slots <= 0) return 16;
+  return (size_t)(2 + (int64_t)batch_size + 2 * max_slots) * sizeof(int32_t);
 }
 
 extern "C" int sp_decode_plan(int32_t* plan, size_t plan_bytes, const void* seq_lens, int idx64,
-                              int batch_size, int64_t max_seq_len, int chunk, void* stream) {
+                              int batch_size, int64_t max_seq_len, int chunk, int64_t max_slots,
+                              void* stream) {
   SP_CHECK_ARG(plan && seq_lens && batch_size >= 0 && chunk >= 4 && chunk % 4 == 0);
-  if (plan_bytes < sp_decode_plan_bytes(batch_size, max_seq_len, chunk)) return SP_ERR_WORKSPACE;
-  const int64_t max_len = num_splits_for(max_seq_len, chunk) * chunk;
-  if (max_len > 0x7fffffffLL) return SP_ERR_INVALID_ARG;
+  SP_CHECK_ARG(max_seq_len >= 0 && max_seq_len <= 0x7fffffffLL && max_slots > 0 && max_slots <= 0x3fffffffLL);
+  if (plan_bytes < sp_decode_plan_bytes(batch_size, max_slots)) return SP_ERR_WORKSPACE;
   decode_plan_kernel<<<dim3(1), 256, 0, (hipStream_t)stream>>>(plan, seq_lens, idx64, batch_size,
-                                                               chunk, (int)max_len);
+                                                               chunk, (int)max_seq_len, (int)max_slots);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
@@ -558,7 +581,7 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
                                    int batch_size, int num_q_heads, int num_kv_heads, int head_dim,
                                    int64_t q_stride, int64_t out_stride, int64_t kv_buffer_stride,
                                    float sm_scale, float logit_cap, float k_scale, float v_scale,
-                                   int64_t max_seq_len, int chunk, void* workspace,
+                                   int64_t max_seq_len, int chunk, int64_t max_slots, void* workspace,
                                    size_t workspace_bytes, const int32_t* plan, int dtype,
                                    int kv_dtype, void* stream) {
   SP_CHECK_ARG(out && q && k_buffer && v_buffer && req_to_token && req_pool_indices && seq_lens);
@@ -584,7 +607,12 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
   const int Gk = G;
   if (head_dim != 64 && head_dim != 128) return SP_ERR_UNSUPPORTED;
 
+  // `chunk`: the split size of the plan-less grid; with a plan, the SMALLEST split size the plan may carry
+  // (the kernels read the actual one from the plan; the host value only decides whether a merge can be needed)
   const int64_t S = num_splits_for(max_seq_len, chunk);
+  if (max_seq_len > 0x7fffffffLL) return SP_ERR_INVALID_ARG;
+  if (!plan) max_slots = (int64_t)batch_size * S;        // static (request, split) grid
+  SP_CHECK_ARG(max_slots > 0 && max_slots <= 0x3fffffffLL);
   DecodeArgs a;
   a.out = out; a.q = q; a.kbuf = (const char*)k_buffer; a.vbuf = (const char*)v_buffer;
   a.r2t = req_to_token; a.r2t_stride = req_to_token_stride; a.req_idx = req_pool_indices;
@@ -594,19 +622,17 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
   // with k_scale, which joins the softmax scale; the output scales with v_scale
   a.kv_stride = kv_buffer_stride; a.sm_scale = sm_scale * k_scale; a.logit_cap = logit_cap;
   a.out_scale = v_scale;
-  if (S * chunk > 0x7fffffffLL) return SP_ERR_INVALID_ARG;
-  a.max_len = (int)(S * chunk);
-  a.chunk = chunk; a.num_splits = (int)S; a.plan = plan; a.kv8 = kv8 ? 1 : 0;
+  a.max_len = (int)max_seq_len;
+  a.chunk = chunk; a.num_splits = (int)S; a.max_slots = (int)max_slots; a.plan = plan; a.kv8 = kv8 ? 1 : 0;
   a.hh_shift = decode_heads_per_load_shift(num_kv_heads, head_dim, dtype, &a.head_groups);
   a.part_o = nullptr; a.part_lse = nullptr;
   if (S > 1) {
-    const size_t need = sp_decode_attention_workspace_bytes(batch_size, num_q_heads, head_dim,
-                                                            max_seq_len, chunk);
+    const size_t need = sp_decode_attention_workspace_bytes(max_slots, num_q_heads, head_dim);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) return SP_ERR_WORKSPACE;
     a.part_o = (float*)workspace;
-    a.part_lse = a.part_o + (size_t)batch_size * num_q_heads * S * head_dim;
+    a.part_lse = a.part_o + (size_t)max_slots * num_q_heads * head_dim;
   }
-  if ((int64_t)batch_size * S * a.head_groups > 0x7fffffffLL) return SP_ERR_INVALID_ARG;
+  if (max_slots * a.head_groups > 0x7fffffffLL) return SP_ERR_INVALID_ARG;
   if (dtype != SP_F32 && dtype != SP_F16 && dtype != SP_BF16) return SP_ERR_UNSUPPORTED;
   return run_decode(a, head_dim, Gk, dtype, (hipStream_t)stream);
 }

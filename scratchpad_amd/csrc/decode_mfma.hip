@@ -136,20 +136,13 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
   const int hgroups = HPW ? a.Hkv / 4 : a.Hkv;
   const int hk = HPW ? (blockIdx.x % hgroups) * 4 + wave : blockIdx.x % hgroups;
   const int item = blockIdx.x / hgroups;
-  int b, c;
-  if (a.plan) {
-    if (item >= a.plan[0]) return;
-    b = a.plan[2 + 2 * item];
-    c = a.plan[3 + 2 * item];
-  } else {
-    c = item % a.num_splits;
-    b = item / a.num_splits;
-  }
+  int b, c, chunk, slot0;
+  if (!decode_item(a, item, b, c, chunk, slot0)) return;
   const int seq = min((int)load_idx(a.seq_lens, b, a.idx64), a.max_len);
-  const int cs = c * a.chunk;
-  if (cs >= seq) return;
-  const int ce = min(cs + a.chunk, seq);
-  const int nsplit = (seq + a.chunk - 1) / a.chunk;
+  const int cs = c * chunk;
+  if (cs >= seq || slot0 + c >= a.max_slots) return;
+  const int ce = min(cs + chunk, seq);
+  const int nsplit = (seq + chunk - 1) / chunk;
   const int64_t req = load_idx(a.req_idx, b, a.idx64);
   const int64_t kv0 = a.kv_start ? load_idx(a.kv_start, b, a.idx64) : 0;
   const int32_t* idx_row = a.r2t + req * a.r2t_stride + kv0;
@@ -345,7 +338,7 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
           *(u32x2*)(op + db * 32) = w;
         }
       } else {
-        const int64_t pi = ((int64_t)b * a.Hq + h) * a.num_splits + c;
+        const int64_t pi = (int64_t)(slot0 + c) * a.Hq + h;
         float* pp = a.part_o + pi * D + 4 * kq;
 #pragma unroll
         for (int db = 0; db < DBLK; ++db)
@@ -388,7 +381,7 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
     if (nsplit == 1) {
       E::store(a.out, (int64_t)b * a.o_stride + (int64_t)h * D + d, o * a.out_scale);
     } else {
-      const int64_t pi = ((int64_t)b * a.Hq + h) * a.num_splits + c;
+      const int64_t pi = (int64_t)(slot0 + c) * a.Hq + h;
       a.part_o[pi * D + d] = o;
       if (d == 0) a.part_lse[pi] = M + __builtin_amdgcn_logf(L);
     }
@@ -398,11 +391,14 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
 template <typename Tag, int D, bool KV8>
 static int launch_dm_kv(const DecodeArgs& a, hipStream_t st) {
   typedef DmCfg<D> C;
+  // planned: one workgroup per (plan item, head group), the launch covers max_slots items (the surplus
+  // exits at once); plan-less: the static (request, split) grid
+  const int64_t items = a.plan ? (int64_t)a.max_slots : (int64_t)a.bs * a.num_splits;
   if (a.Hkv % 4 == 0 && a.o_stride % 4 == 0) {
-    const unsigned grid = (unsigned)a.bs * a.num_splits * (a.Hkv / 4);
+    const unsigned grid = (unsigned)(items * (a.Hkv / 4));
     decode_mfma_kernel<Tag, D, true, KV8><<<dim3(grid), 256, C::kLdsBytes, st>>>(a);
   } else {
-    const unsigned grid = (unsigned)a.bs * a.num_splits * a.Hkv;
+    const unsigned grid = (unsigned)(items * a.Hkv);
     decode_mfma_kernel<Tag, D, false, KV8><<<dim3(grid), 256, C::kLdsBytes, st>>>(a);
   }
   SP_LAUNCH_CHECK();
@@ -419,7 +415,7 @@ static int launch_dm(const DecodeArgs& a, hipStream_t st) {
 int run_decode_mfma(const DecodeArgs& a, int head_dim, int dtype, hipStream_t st) {
   const int G = a.Hq / a.Hkv;
   if (G > 16 || (dtype != SP_BF16 && dtype != SP_F16)) return SP_ERR_UNSUPPORTED;
-  if ((int64_t)a.bs * a.num_splits * a.Hkv > 0x7fffffffLL) return SP_ERR_INVALID_ARG;
+  if ((a.plan ? (int64_t)a.max_slots : (int64_t)a.bs * a.num_splits) * a.Hkv > 0x7fffffffLL) return SP_ERR_INVALID_ARG;
   if (head_dim == 128)
     return dtype == SP_BF16 ? launch_dm<bf16_tag, 128>(a, st) : launch_dm<f16_tag, 128>(a, st);
   if (head_dim == 64)

@@ -219,7 +219,7 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
   // one split per row: every row-stream is reduced inside one workgroup, no partials
   int64_t chunk = ((max_seq_len > 0 ? max_seq_len : 1) + 3) / 4 * 4;
   if (chunk > 0x7ffffff0LL) return SP_ERR_INVALID_ARG;
-  a.chunk = (int)chunk; a.num_splits = 1; a.max_len = (int)chunk;
+  a.chunk = (int)chunk; a.num_splits = 1; a.max_len = (int)chunk; a.max_slots = (int)num_tokens;
   a.hh_shift = decode_heads_per_load_shift(num_kv_heads, head_dim, dtype, &a.head_groups);
   a.part_o = nullptr; a.part_lse = nullptr; a.plan = nullptr; a.kv8 = 0;
   return run_decode(a, head_dim, G, dtype, st);

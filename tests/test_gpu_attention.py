@@ -207,9 +207,12 @@ def test_decode_plan_is_exact_and_changes_nothing(nat):
     for cls in (3, 2, 1, 0):
         want_tail += [(b, l // chunk) for b, l in enumerate(lens)
                       if l % chunk and ((l % chunk) * 4 - 1) // chunk == cls]
-    n = pl[0]
+    n, nb = pl[0], len(lens)
     assert n == len(want_full) + len(want_tail) and pl[1] == chunk
-    got = [(pl[2 + 2 * i], pl[3 + 2 * i]) for i in range(n)]
+    # slot0[b] = first partial slot of request b: the exclusive scan of the requests' split counts
+    nsplit = [-(-l // chunk) for l in lens]
+    assert pl[2:2 + nb] == [sum(nsplit[:b]) for b in range(nb)]
+    got = [(pl[2 + nb + 2 * i], pl[3 + nb + 2 * i]) for i in range(n)]
     assert got == want_full + want_tail
     # 700 requests: the scan crosses several 256-request tiles
     gen = torch.Generator().manual_seed(17)
@@ -218,7 +221,8 @@ def test_decode_plan_is_exact_and_changes_nothing(nat):
     nat.decode_plan(plan, seq.to(DEV), 900, 128)
     pl = plan.cpu()
     assert int(pl[0]) == int(((seq + 127) // 128).sum())
-    items = pl[2:2 + 2 * int(pl[0])].view(-1, 2)
+    assert torch.equal(pl[2:702].long(), torch.cumsum((seq + 127) // 128, 0) - (seq + 127) // 128)
+    items = pl[702:702 + 2 * int(pl[0])].view(-1, 2)
     key = items[:, 0].long() * 100 + items[:, 1].long()
     want = torch.cat([b * 100 + torch.arange((int(l) + 127) // 128) for b, l in enumerate(seq.tolist())])
     assert torch.equal(torch.sort(key).values, torch.sort(want).values), "every item exactly once"
@@ -226,6 +230,48 @@ def test_decode_plan_is_exact_and_changes_nothing(nat):
     b = run_decode(nat, p, 0.1, chunk=chunk, use_plan=False)
     keep = [i for i, l in enumerate(lens) if l > 0]
     assert torch.equal(a[keep], b[keep])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_decode_split_size_travels_in_the_plan(nat, dtype):
+    """ABI 4: with a plan the kernels read the split size from the plan, partials go to compact slots
+    (slot0[b] + c) and the launch covers `max_slots` items.  One launch geometry (host chunk 64, a slot budget
+    from sum(seq_lens)) must give the same bits whatever split size the plan was built with - what graph replay
+    relies on when it rebuilds only the plan - and the slot budget is the one derived from sum(seq_lens), far
+    below batch x context."""
+    lens = [700, 64, 1, 130, 513, 2048, 33]
+    bs, Hq, Hkv, D = len(lens), 8, 2, 128
+    p = paged_problem(31, bs, Hq, Hkv, D, lens, dtype, DEV)
+    q, seq, req = p["q"], p["seq_lens"], p["req_pool_indices"]
+    ctx = 131072                                   # the model's context length: the bound the kernels clamp to
+    ref = run_decode(nat, p, 0.11, chunk=64, use_plan=False)
+    check_decode(ref, p, 0.11, dtype, "static grid")
+    static_slots = nat.decode_plan_slots(bs, ctx, 64)
+    for chunk in (64, 128, 512, 4096):
+        slots = nat.decode_plan_slots(bs, ctx, chunk, kv_tokens=sum(lens))
+        assert slots == sum(lens) // chunk + bs and slots * 100 < static_slots
+        ws = torch.empty(nat.decode_workspace_bytes(bs, Hq, D, ctx, 64, slots), dtype=torch.uint8, device=DEV)
+        plan = torch.empty(nat.decode_plan_bytes(bs, ctx, 64, slots) // 4, dtype=torch.int32, device=DEV)
+        nat.decode_plan(plan, seq, ctx, chunk, slots)
+        assert int(plan[0]) == sum(-(-l // chunk) for l in lens) <= slots and int(plan[1]) == chunk
+        o = torch.full_like(q, float("nan"))
+        nat.decode_attention(o, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], req, seq, 0.11, 0.0,
+                             ctx, 64, ws, None, plan, max_slots=slots)
+        check_decode(o, p, 0.11, dtype, f"plan chunk {chunk}")
+        if chunk == 64:
+            assert torch.equal(o, ref), "same split size: same bits as the static grid"
+    # a slot budget the lengths do not fit (a broken host bound): items beyond it are dropped by the plan and
+    # the kernels never touch a slot past the workspace - no fault, the affected rows are simply incomplete
+    slots = 8
+    ws = torch.full((nat.decode_workspace_bytes(bs, Hq, D, ctx, 64, slots) + 4096,), 0x7f, dtype=torch.uint8, device=DEV)
+    plan = torch.empty(nat.decode_plan_bytes(bs, ctx, 64, slots) // 4, dtype=torch.int32, device=DEV)
+    nat.decode_plan(plan, seq, ctx, 64, slots)
+    assert int(plan[0]) == slots
+    o = torch.zeros_like(q)
+    nat.decode_attention(o, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], req, seq, 0.11, 0.0,
+                         ctx, 64, ws[:nat.decode_workspace_bytes(bs, Hq, D, ctx, 64, slots)], None, plan, max_slots=slots)
+    torch.cuda.synchronize()
+    assert bool((ws[-4096:] == 0x7f).all()), "nothing written past the workspace"
 
 
 def test_decode_rejects_bad_arguments(nat):
