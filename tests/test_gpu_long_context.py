@@ -27,7 +27,6 @@ def test_graph_scratch_is_bounded_and_a_100k_token_decode_step_matches_the_oracl
     pool = sum(lens) + 4 * BS + 64
     args = ServerArgs(max_total_tokens=pool, max_running_requests=256)       # default bucket list, up to bs 256
     mr = ModelRunner(cfg, args, dtype=torch.float16, seed=3)
-    free0 = torch.cuda.mem_get_info()[0]
     mr.init_cuda_graphs()
     backend = mr.attn_backend
     scratch = backend.graph_scratch_bytes()
@@ -37,8 +36,7 @@ def test_graph_scratch_is_bounded_and_a_100k_token_decode_step_matches_the_oracl
     static_8b = _native.decode_workspace_bytes(256, 32, 128, CTX, 512)       # round 2: bs x ceil(ctx / 512) splits
     print(f"graph attention scratch at context_len {CTX}: {scratch / 2**20:.1f} MiB for this model, "
           f"{scratch_8b / 2**20:.1f} MiB at Llama-3-8B head counts ({slots} slots); the bs-256 bucket alone under "
-          f"the round-2 static geometry: {static_8b / 2**20:.0f} MiB; device memory taken by init_cuda_graphs(): "
-          f"{(free0 - torch.cuda.mem_get_info()[0]) / 2**20:.0f} MiB")
+          f"the round-2 static geometry: {static_8b / 2**20:.0f} MiB")
     assert scratch < 1.5e9 and scratch_8b < 1.5e9 and scratch_8b * 20 < static_8b
     assert len(mr.graph_runner.capture_bs) >= 30 and max(mr.graph_runner.capture_bs) == 256
 

@@ -58,12 +58,21 @@ def test_host_side_argument_validation_needs_no_gpu(lib):
                                                       ctypes.c_int64, ctypes.c_float, ctypes.c_int,
                                                       ctypes.c_void_p]
     assert lib.sp_rmsnorm(None, None, None, 4, 64, 64, 64, 1e-5, 2, None) == -1
+    # split geometry (ABI 4): slots = min(bs * ceil(max_seq_len / chunk), kv_tokens / chunk + bs); the workspace
+    # holds [slots, Hq, D + 1] floats - bounded by the step's tokens, not by batch x context
+    lib.sp_decode_plan_slots.restype = ctypes.c_int64
+    lib.sp_decode_plan_slots.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]
+    assert lib.sp_decode_plan_slots(256, -1, 4096, 512) == 256 * 8
+    assert lib.sp_decode_plan_slots(256, 547000, 4096, 512) == 547000 // 512 + 256
+    assert lib.sp_decode_plan_slots(8, 800000, 131072, 1024) == 800000 // 1024 + 8
+    assert lib.sp_decode_plan_slots(4, 10 ** 9, 100, 512) == 4
     lib.sp_decode_attention_workspace_bytes.restype = ctypes.c_size_t
-    lib.sp_decode_attention_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                                        ctypes.c_int64, ctypes.c_int]
-    assert lib.sp_decode_attention_workspace_bytes(256, 32, 128, 4096, 512) == \
-        256 * 32 * 8 * 129 * 4 + 16
-    assert lib.sp_decode_attention_workspace_bytes(4, 8, 64, 100, 512) == 16
+    lib.sp_decode_attention_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+    assert lib.sp_decode_attention_workspace_bytes(256 * 8, 32, 128) == 256 * 32 * 8 * 129 * 4 + 16
+    assert lib.sp_decode_attention_workspace_bytes(0, 8, 64) == 16
+    lib.sp_decode_plan_bytes.restype = ctypes.c_size_t
+    lib.sp_decode_plan_bytes.argtypes = [ctypes.c_int, ctypes.c_int64]
+    assert lib.sp_decode_plan_bytes(256, 2304) == (2 + 256 + 2 * 2304) * 4
 
 
 def test_ops_refuse_host_tensors():
