@@ -672,15 +672,18 @@ def pmc_traffic(alg_bytes, args):
     (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; tools/pmc_decode_bf16.sh): the measured
     traffic / algorithmic ratio of the same kernel SOURCES and workload, else None - a ratio recorded for
     other kernel sources says nothing about this build."""
-    path = os.path.join(ROOT, "profiles", "r02_decode_attn_pmc.json")
-    if not os.path.exists(path) or args.model != "llama3-8b" or args.kv_cache_dtype != "auto" \
-            or args.bs != 256 or args.ctx != "uniform":
+    if args.model != "llama3-8b" or args.kv_cache_dtype != "auto" or args.bs != 256 or args.ctx != "uniform":
         return None, "no PMC pass for this workload"
-    rec = json.load(open(path))
-    if rec.get("kernel_source_sha1") != decode_kernel_sources_sha1():
-        return None, "profiles/r02_decode_attn_pmc.json was recorded for other kernel sources (stale): not used"
-    return int(alg_bytes * rec["traffic_over_algorithmic"]), \
-        "profiles/r02_decode_attn_pmc.json (PMC ratio x algorithmic, same kernel sources)"
+    import glob
+    sha = decode_kernel_sources_sha1()
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_decode_attn_pmc.json")), reverse=True)
+    for path in paths:                   # newest round first: the pass recorded for THESE kernel sources
+        rec = json.load(open(path))
+        if rec.get("kernel_source_sha1") == sha:
+            name = os.path.relpath(path, ROOT)
+            return int(alg_bytes * rec["traffic_over_algorithmic"]), \
+                f"{name} (PMC ratio x algorithmic, same kernel sources)"
+    return None, "the PMC passes under profiles/ were recorded for other kernel sources (stale): not used"
 
 
 def decode_kernel_sources_sha1() -> str:
