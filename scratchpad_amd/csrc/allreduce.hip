@@ -428,11 +428,15 @@ extern "C" int sp_custom_all_reduce(void* out, const void* in, int64_t num_elems
   return SP_OK;
 }
 
+static int g_fused_blocks = 0;     // sp_debug_set("ar_fused_blocks", n): tuning knob, 0 = default
+namespace sp { void set_ar_fused_blocks(int n) { g_fused_blocks = n < 0 ? 0 : (n > kArMaxBlocks ? kArMaxBlocks : n); } }
+
 template <typename Tag>
 static int launch_fused(const ArFusedArgs& a, bool two_shot, hipStream_t st) {
   constexpr int MAXIT = (Elem<Tag>::kBytes == 4) ? 8 : 4;
   // one workgroup per row until the flag rows run out; a short batch still gets one workgroup per row
-  const int blocks = a.T < kArMaxBlocks ? a.T : kArMaxBlocks;
+  const int cap = g_fused_blocks > 0 ? g_fused_blocks : kArMaxBlocks;
+  const int blocks = a.T < cap ? a.T : cap;
   if (two_shot)
     all_reduce_add_rmsnorm_kernel<Tag, true, MAXIT><<<dim3(blocks), kFusedThreads, 0, st>>>(a);
   else
