@@ -51,6 +51,7 @@ constexpr int kArMaxBlocks = 128;      // flag rows per region; a launch uses th
 constexpr int kArBlocks = 32;          // workgroups of the plain all-reduce (each syncs with its twin on the peers)
 constexpr int kArThreads = 512;
 constexpr int kFusedThreads = 256;     // one row per workgroup pass, the mapping of rmsnorm_vec_kernel
+constexpr int kFusedBlocks = 64;       // default workgroup cap of the fused kernel (see launch_fused)
 // words of a region's flag area: [kArMaxBlocks][kArMaxRanks] arrival flags, then one epoch counter per
 // workgroup, then the status word
 constexpr int kArEpochWord0 = kArMaxBlocks * kArMaxRanks;
@@ -434,8 +435,11 @@ namespace sp { void set_ar_fused_blocks(int n) { g_fused_blocks = n < 0 ? 0 : (n
 template <typename Tag>
 static int launch_fused(const ArFusedArgs& a, bool two_shot, hipStream_t st) {
   constexpr int MAXIT = (Elem<Tag>::kBytes == 4) ? 8 : 4;
-  // one workgroup per row until the flag rows run out; a short batch still gets one workgroup per row
-  const int cap = g_fused_blocks > 0 ? g_fused_blocks : kArMaxBlocks;
+  // one workgroup per row up to kFusedBlocks, then several rows per workgroup.  Measured with the ranks of ONE
+  // GPU (tools/bench_allreduce.py, [128, 8192] bf16, 2 / 4 ranks, us per call): 128 workgroups 73 / 207,
+  // 64: 37, 32: 39 / 95, 16: 55 - every barrier is a system-scope fence per workgroup, and those serialise;
+  // all-reduce + norm as two launches: 33 / 122
+  const int cap = g_fused_blocks > 0 ? g_fused_blocks : kFusedBlocks;
   const int blocks = a.T < cap ? a.T : cap;
   if (two_shot)
     all_reduce_add_rmsnorm_kernel<Tag, true, MAXIT><<<dim3(blocks), kFusedThreads, 0, st>>>(a);
