@@ -193,9 +193,12 @@ SP_API size_t sp_extend_attention_workspace_bytes(int64_t num_tokens, int batch_
  * per forward by sp_extend_plan() from the same extend_seq_lens / seq_lens / head counts / causal flag
  * and shared by every layer (the counterpart of flashinfer's begin_forward() for the prefill wrappers,
  * flashinfer_backend.py:400-444, 672-830).  It only decides which workgroup computes which rows (no
- * empty workgroups on ragged batches, longest rows first); results do not depend on it.  A plan built
- * for other head counts is ignored by the kernel's workgroups (nothing is written): build it with the
- * layer's own num_q_heads / num_kv_heads.  sp_extend_plan_bytes() sizes the int32 buffer.          */
+ * empty workgroups on ragged batches, longest rows first); results do not depend on it.  The plan carries
+ * a header (block size, head counts, num_tokens, batch size): a launch whose own values differ - a stale
+ * plan of another step, a plan built for other head counts - does not use its items and derives each
+ * workgroup's rows by walking the requests instead, so a wrong plan costs order, never rows.
+ * sp_extend_plan_bytes() sizes the int32 buffer; `plan_bytes` (sp_extend_attention) must cover it, else
+ * SP_ERR_WORKSPACE.  `causal` of sp_extend_plan is reserved (the item list does not depend on it).    */
 SP_API size_t sp_extend_plan_bytes(int64_t num_tokens, int batch_size, int num_q_heads, int num_kv_heads);
 SP_API int sp_extend_plan(int32_t* plan, size_t plan_bytes, const int32_t* extend_seq_lens, const void* seq_lens,
                    int idx64, int batch_size, int64_t num_tokens, int num_q_heads, int num_kv_heads,
@@ -210,7 +213,7 @@ SP_API int sp_extend_attention(void* out, const void* q, const void* k_buffer, c
                         float logit_cap, float k_scale, float v_scale, int causal,
                         int window_left, int max_extend_len,
                         int64_t max_seq_len, void* workspace, size_t workspace_bytes,
-                        const int32_t* plan, int dtype, int kv_dtype, void* stream);
+                        const int32_t* plan, size_t plan_bytes, int dtype, int kv_dtype, void* stream);
 
 /* ---- Sampler.  Replaces nn/layers/sampler.py:63-75 (torch.argmax; logits.div_(T) + softmax),
  *      sampler.py:195-232 (top_k_top_p_min_p_sampling_from_probs_torch, top_p_normalize_probs_torch)

@@ -57,7 +57,7 @@ SIGNATURES = {
     "sp_extend_attention_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32]),
     "sp_extend_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp,
                                    _i32, _i64, _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32, _f32, _f32,
-                                   _i32, _i32, _i32, _i64, _vp, _sz, _vp, _i32, _i32, _vp]),
+                                   _i32, _i32, _i32, _i64, _vp, _sz, _vp, _sz, _i32, _i32, _vp]),
     "sp_extend_plan_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "sp_extend_plan": (_i32, [_vp, _sz, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _i32, _vp]),
     "sp_kv_store_fp8": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _f32,
@@ -417,7 +417,8 @@ def extend_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
         seq.shape[0], T, Hq, k_buffer.shape[1], D, q.stride(0), out.stride(0), k_buffer.stride(0),
         sm_scale, logit_cap, 1.0 if k_scale is None else float(k_scale),
         1.0 if v_scale is None else float(v_scale), int(causal), int(window_left), max_extend_len, max_seq_len, workspace.data_ptr(),
-        workspace.numel() * workspace.element_size(), _ptr(plan), _dt(q), kv_dt, _stream()), "sp_extend_attention")
+        workspace.numel() * workspace.element_size(), _ptr(plan), 0 if plan is None else plan.numel() * 4,
+        _dt(q), kv_dt, _stream()), "sp_extend_attention")
 
 
 def extend_plan(extend_seq_lens: torch.Tensor, seq_lens: torch.Tensor, num_tokens: int, Hq: int, Hkv: int,

@@ -8,6 +8,9 @@
 
 namespace sp {
 
+// words of an extend plan's header: [count, block rows, Hq, Hkv, num_tokens, bs, 0, 0]; the items follow
+constexpr int kExtPlanHeader = 8;
+
 // extend_mfma.hip: MFMA tile kernel for 16-bit ragged extend; SP_ERR_UNSUPPORTED -> use row-streams
 int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* v_buffer,
                     const int32_t* req_to_token, int64_t req_to_token_stride,
@@ -16,7 +19,7 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
                     int batch_size, int num_q_heads, int num_kv_heads, int head_dim, int64_t q_stride,
                     int64_t out_stride, int64_t kv_buffer_stride, float sm_scale, float logit_cap,
                     float out_scale, int causal, int window_left, int max_extend_len, const int32_t* plan,
-                    int plan_items, int dtype, int kv8, hipStream_t st);
+                    int plan_items, int num_tokens, int dtype, int kv8, hipStream_t st);
 
 // test / tuning hooks behind sp_debug_set
 void set_extend_defer_x10(int tenths);

@@ -53,7 +53,8 @@ constexpr int kPlanThreads = 1024;
 constexpr int kPlanBins = 4096;         // requests above 262k keys share the top class
 __global__ __launch_bounds__(kPlanThreads) void extend_plan_kernel(
     int32_t* __restrict__ plan, int max_items, const int32_t* __restrict__ extend_seq_lens,
-    const void* __restrict__ seq_lens, int idx64, int bs, int block_rows, int causal) {
+    const void* __restrict__ seq_lens, int idx64, int bs, int block_rows, int num_q_heads, int num_kv_heads,
+    int num_tokens) {
   __shared__ int s_bin[kPlanBins];
   __shared__ int s_total;
   for (int i = threadIdx.x; i < kPlanBins; i += kPlanThreads) s_bin[i] = 0;
@@ -83,16 +84,21 @@ __global__ __launch_bounds__(kPlanThreads) void extend_plan_kernel(
     const int pos = atomicAdd(&s_bin[min((max(L, 0) + 63) / 64, kPlanBins - 1)], nblk);
     for (int i = 0; i < nblk; ++i) {
       if (pos + i < max_items) {
-        plan[2 + 2 * (pos + i)] = b;
-        plan[3 + 2 * (pos + i)] = nblk - 1 - i;      // the request's last rows (most keys) first
+        plan[kExtPlanHeader + 2 * (pos + i)] = b;
+        plan[kExtPlanHeader + 1 + 2 * (pos + i)] = nblk - 1 - i;      // the request's last rows (most keys) first
       }
     }
   }
   if (threadIdx.x == 0) {
+    // header: what the plan was built for (the attention kernel checks it against its own launch)
     plan[0] = min(s_total, max_items);
     plan[1] = block_rows;
+    plan[2] = num_q_heads;
+    plan[3] = num_kv_heads;
+    plan[4] = num_tokens;
+    plan[5] = bs;
+    plan[6] = plan[7] = 0;
   }
-  (void)causal;
 }
 
 int extend_block_rows(int num_q_heads, int num_kv_heads);   // extend_mfma.hip
@@ -110,7 +116,7 @@ static inline int64_t extend_plan_items(int64_t num_tokens, int batch_size, int 
 extern "C" size_t sp_extend_plan_bytes(int64_t num_tokens, int batch_size, int num_q_heads, int num_kv_heads) {
   if (num_tokens <= 0 || batch_size <= 0 || num_q_heads <= 0 || num_kv_heads <= 0) return 16;
   const int bm = extend_block_rows(num_q_heads, num_kv_heads);
-  return (size_t)(2 + 2 * extend_plan_items(num_tokens, batch_size, bm)) * sizeof(int32_t);
+  return (size_t)(kExtPlanHeader + 2 * extend_plan_items(num_tokens, batch_size, bm)) * sizeof(int32_t);
 }
 
 extern "C" int sp_extend_plan(int32_t* plan, size_t plan_bytes, const int32_t* extend_seq_lens,
@@ -121,9 +127,11 @@ extern "C" int sp_extend_plan(int32_t* plan, size_t plan_bytes, const int32_t* e
   if (plan_bytes < sp_extend_plan_bytes(num_tokens, batch_size, num_q_heads, num_kv_heads)) return SP_ERR_WORKSPACE;
   const int bm = extend_block_rows(num_q_heads, num_kv_heads);
   const int64_t items = extend_plan_items(num_tokens, batch_size, bm);
-  if (items > 0x3fffffffLL) return SP_ERR_INVALID_ARG;
+  if (items > 0x3fffffffLL || num_tokens > 0x7fffffffLL) return SP_ERR_INVALID_ARG;
+  (void)causal;   // reserved: the item list does not depend on it (kept so that callers state what they plan for)
   extend_plan_kernel<<<dim3(1), kPlanThreads, 0, (hipStream_t)stream>>>(plan, (int)items, extend_seq_lens, seq_lens,
-                                                                      idx64, batch_size, bm, causal);
+                                                                      idx64, batch_size, bm, num_q_heads,
+                                                                      num_kv_heads, (int)num_tokens);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
@@ -164,7 +172,8 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
                                    float k_scale, float v_scale, int causal, int window_left,
                                    int max_extend_len,
                                    int64_t max_seq_len, void* workspace, size_t workspace_bytes,
-                                   const int32_t* plan, int dtype, int kv_dtype, void* stream) {
+                                   const int32_t* plan, size_t plan_bytes, int dtype, int kv_dtype,
+                                   void* stream) {
   SP_CHECK_ARG(out && q && k_buffer && v_buffer && req_to_token && req_pool_indices && seq_lens);
   SP_CHECK_ARG(extend_seq_lens && extend_start_loc && batch_size >= 0 && num_tokens >= 0);
   SP_CHECK_ARG(num_q_heads > 0 && num_kv_heads > 0 && num_q_heads % num_kv_heads == 0);
@@ -188,6 +197,10 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
       sp_extend_attention_workspace_bytes(num_tokens, batch_size, num_q_heads, head_dim, dtype);
   if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) return SP_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  // a plan must be large enough for every grid row this launch reads an item for (its CONTENT is checked by
+  // the kernel against the launch: block size, head counts, num_tokens, batch size)
+  if (plan && plan_bytes < sp_extend_plan_bytes(num_tokens, batch_size, num_q_heads, num_kv_heads))
+    return SP_ERR_WORKSPACE;
 
   // 16-bit dtypes run on the matrix cores (extend_mfma.hip); fp32 and unsupported shapes take the
   // row-stream path below
@@ -199,7 +212,7 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
                                    causal, window_left, max_extend_len, plan,
                                    (int)std::min<int64_t>(extend_plan_items(num_tokens, batch_size,
                                        extend_block_rows(num_q_heads, num_kv_heads)), 0x7fffffff),
-                                   dtype, kv8 ? 1 : 0, st);
+                                   (int)num_tokens, dtype, kv8 ? 1 : 0, st);
     if (rc != SP_ERR_UNSUPPORTED || kv8) return rc;   // an fp8 pool has no row-stream path
   }
 

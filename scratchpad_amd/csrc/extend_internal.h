@@ -32,8 +32,13 @@ struct ExtendArgs {
   int kv8;      // 1: fp8 e5m2 pool (kv_stride in bytes); tile math in fp16, see decode_mfma.hip
   int window;   // sliding window: a row at kv position p sees keys [p - window, p]; < 0 = unlimited
   float defer;  // the running maximum may trail the true row maximum by this much (log2 units)
-  const int32_t* plan;  // optional work list from sp_extend_plan: [count, BM, (request, row block) x count]
+  // optional work list from sp_extend_plan: header [count, BM, Hq, Hkv, num_tokens, bs, 0, 0], then
+  // (request, row block) x count from word kExtPlanHeader.  A workgroup that finds the header built for
+  // another block size / head counts / step derives its item by walking the requests instead (correct,
+  // merely unordered): a stale or foreign plan can never drop rows.
+  const int32_t* plan;
   int plan_items;       // grid rows when a plan is given (an upper bound of its count)
+  int num_tokens;       // sum of the extend lengths (host-known)
 };
 
 static constexpr float kLog2eX = 1.4426950408889634f;

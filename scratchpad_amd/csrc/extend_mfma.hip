@@ -85,9 +85,25 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
 
   int b, row0;
   if (a.plan) {                                    // planned: items are sorted heaviest first
-    if ((int)blockIdx.y >= a.plan[0] || a.plan[1] != BM) return;   // plan[1]: the block size it was built for
-    b = a.plan[2 + 2 * blockIdx.y];
-    row0 = a.plan[3 + 2 * blockIdx.y] * BM;
+    const bool mine = a.plan[1] == BM && a.plan[2] == a.Hq && a.plan[3] == a.Hkv && a.plan[4] == a.num_tokens &&
+                      a.plan[5] == a.bs;
+    if (mine) {
+      if ((int)blockIdx.y >= a.plan[0]) return;
+      b = a.plan[kExtPlanHeader + 2 * blockIdx.y];
+      row0 = a.plan[kExtPlanHeader + 1 + 2 * blockIdx.y] * BM;
+    } else {
+      // a plan built for another block size, other head counts or another step: walk the requests for
+      // grid row blockIdx.y (the grid has a row for every item of THIS step); same results, no ordering
+      int rem = blockIdx.y, nblk = 0;
+      for (b = 0; b < a.bs; ++b) {
+        const int e = a.ext_lens[b];
+        nblk = e > 0 ? (e + BM - 1) / BM : 0;
+        if (rem < nblk) break;
+        rem -= nblk;
+      }
+      if (b >= a.bs) return;
+      row0 = (nblk - 1 - rem) * BM;
+    }
   } else {
     b = blockIdx.z;
     row0 = ((int)gridDim.y - 1 - (int)blockIdx.y) * BM;    // heaviest row blocks first
@@ -668,7 +684,7 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
                     int batch_size, int num_q_heads, int num_kv_heads, int head_dim, int64_t q_stride,
                     int64_t out_stride, int64_t kv_buffer_stride, float sm_scale, float logit_cap,
                     float out_scale, int causal, int window_left, int max_extend_len, const int32_t* plan,
-                    int plan_items, int dtype, int kv8, hipStream_t st) {
+                    int plan_items, int num_tokens, int dtype, int kv8, hipStream_t st) {
   if (dtype != SP_F16 && dtype != SP_BF16) return SP_ERR_UNSUPPORTED;
   if (head_dim != 64 && head_dim != 128) return SP_ERR_UNSUPPORTED;
   if (batch_size > 65535 || num_q_heads > 65535) return SP_ERR_UNSUPPORTED;   // grid.z, grid.y
@@ -685,7 +701,7 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
   a.window = causal ? window_left : -1;
   a.kv8 = kv8;
   a.defer = g_extend_defer;
-  a.plan = plan; a.plan_items = plan_items;
+  a.plan = plan; a.plan_items = plan_items; a.num_tokens = num_tokens;
   if (plan && (plan_items <= 0 || plan_items > 65535)) a.plan = nullptr;   // grid.y limit: unplanned launch
   const int G = num_q_heads / num_kv_heads;
   if (max_extend_len <= 0) return SP_OK;

@@ -29,10 +29,12 @@ class LogitsProcessorOutput:
     """nn/layers/logits_processor.py LogitsProcessorOutput.  ``next_token_logits`` ([bs, vocab] fp32,
     all-gathered over the TP group, padding columns cut: logits_processor.py:362-369) is what the
     reference's callers read; here the forward leaves only this rank's vocab shard in the model dtype
-    (``shard_logits``) and the full fp32 matrix is built the first time somebody asks for it - the
-    sampler of a non-greedy batch, logprobs, tests.  A greedy batch never does (``greedy_token_ids``):
-    under TP it exchanges one (value, index) pair per row instead of [bs, vocab / tp] logits, and at
-    TP = 1 it skips the fp32 copy of the logits (131 MB at bs 256)."""
+    (``shard_logits``).  A greedy batch never needs more (``greedy_token_ids``): under TP it exchanges one
+    (value, index) pair per row instead of [bs, vocab / tp] logits, and at TP = 1 it skips the fp32 copy of
+    the logits (131 MB at bs 256).  Whoever needs the full matrix - the sampler of a non-greedy batch,
+    logprobs, tests - calls ``gather_full_logits()``: under TP that is a COLLECTIVE, so it is an explicit
+    method that every rank of the group calls at the same point, never a side effect of an attribute read
+    (a rank-0-only log line or a debugger would otherwise deadlock or mis-order the group's collectives)."""
 
     def __init__(self, next_token_logits: Optional[torch.Tensor] = None,
                  hidden_states: Optional[torch.Tensor] = None,
@@ -44,13 +46,27 @@ class LogitsProcessorOutput:
         self.vocab_size = vocab_size
         self.shard_offset = shard_offset
 
-    @property
-    def next_token_logits(self) -> Optional[torch.Tensor]:
-        if self._full is None and self.shard_logits is not None:
+    def gather_full_logits(self) -> torch.Tensor:
+        """[bs, vocab] fp32 (logits_processor.py:362-369).  Collective under TP: call on every rank."""
+        if self._full is None:
+            if self.shard_logits is None:
+                raise RuntimeError("LogitsProcessorOutput holds neither a logits shard nor full logits")
             logits = self.shard_logits
             if get_tensor_model_parallel_world_size() > 1:
                 logits = tensor_model_parallel_all_gather(logits)
             self._full = logits[:, : self.vocab_size].float()
+        return self._full
+
+    @property
+    def next_token_logits(self) -> Optional[torch.Tensor]:
+        """The gathered logits if ``gather_full_logits()`` has run (or they were given); at TP = 1, where no
+        collective is involved, they are built on first read.  Under TP an ungathered read raises instead of
+        starting a collective from an attribute access."""
+        if self._full is None and self.shard_logits is not None:
+            if get_tensor_model_parallel_world_size() > 1:
+                raise RuntimeError("next_token_logits under tensor parallelism: call gather_full_logits() on "
+                                   "EVERY rank first (it is a collective)")
+            return self.gather_full_logits()
         return self._full
 
     @next_token_logits.setter
@@ -58,16 +74,22 @@ class LogitsProcessorOutput:
         self._full = value
 
     def rows(self, n: int) -> "LogitsProcessorOutput":
-        """The first n rows (graph replay hands back the live rows of a padded bucket)."""
+        """The first n rows (graph replay hands back the live rows of a padded bucket).  The object this is
+        called on is the graph runner's PERSISTENT output buffer: a full-logits matrix cached on it would be
+        the previous replay's - it must never have been materialised there."""
+        if self._full is not None:
+            raise RuntimeError("full logits were materialised on a persistent graph output buffer (they would "
+                               "be stale on the next replay): read them from the object rows() returns")
         return LogitsProcessorOutput(
-            None if self._full is None else self._full[:n],
-            None if self.hidden_states is None else self.hidden_states[:n],
+            None, None if self.hidden_states is None else self.hidden_states[:n],
             None if self.shard_logits is None else self.shard_logits[:n], self.vocab_size, self.shard_offset)
 
     def greedy_token_ids(self) -> torch.Tensor:
         """torch.argmax(next_token_logits, -1) (sampler.py:63-65) without materialising it."""
-        if self._full is not None or self.shard_logits is None:
+        if self._full is not None:
             return _native.argmax(self._full)
+        if self.shard_logits is None:
+            raise RuntimeError("LogitsProcessorOutput holds neither a logits shard nor full logits")
         shard = self.shard_logits
         cols = max(0, min(shard.shape[1], self.vocab_size - self.shard_offset))   # padding columns never win
         tp = get_tensor_model_parallel_world_size()

@@ -158,7 +158,9 @@ class Sampler(nn.Module):
             if sampling_info.grammars:
                 self.sync_token_ids_across_tp(ids)
             return ids
-        logits = logits_output.next_token_logits
+        # every rank runs the same sampler on the same batch: the gather is an explicit collective here
+        logits = (logits_output.gather_full_logits() if hasattr(logits_output, "gather_full_logits")
+                  else logits_output.next_token_logits)
         if self.use_nan_detection and torch.any(torch.isnan(logits)):
             logits = torch.where(torch.isnan(logits), torch.full_like(logits, -1e5), logits)
         logprobs = None

@@ -128,8 +128,14 @@ def _sharded_layers(rank, world):
                       extend_seq_lens=torch.tensor([2, 3], dtype=torch.int32))
     out = llama.LogitsProcessor(Cfg())(ids, x, emb, fb)
     want = torch.matmul(x[[1, 4]], full_emb.T)
-    assert out.next_token_logits.shape == (2, vocab) and out.next_token_logits.dtype == torch.float32
-    assert torch.allclose(out.next_token_logits, want, atol=1e-4)
+    import pytest
+    with pytest.raises(RuntimeError, match="gather_full_logits"):
+        out.next_token_logits              # under TP the gather is an explicit collective, never an attribute read
+    full = out.gather_full_logits()        # every rank calls it
+    assert full.shape == (2, vocab) and full.dtype == torch.float32 and out.next_token_logits is full
+    assert torch.allclose(full, want, atol=1e-4)
+    with pytest.raises(RuntimeError, match="persistent graph output buffer"):
+        out.rows(1)                        # a buffer object that cached full logits must not be re-sliced
 
 
 def _kv_head_replication(rank, world):

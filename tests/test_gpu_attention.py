@@ -309,7 +309,8 @@ def test_extend_plan_lists_every_row_block_once_and_changes_nothing(nat, Hq, Hkv
     host = plan.cpu().tolist()
     count, bm = host[0], host[1]
     assert bm == rows
-    items = [(host[2 + 2 * i], host[3 + 2 * i]) for i in range(count)]
+    assert host[2:6] == [Hq, Hkv, sum(ext), len(ext)], "header: what the plan was built for"
+    items = [(host[8 + 2 * i], host[9 + 2 * i]) for i in range(count)]
     want = [(b, rb) for b, e in enumerate(ext) for rb in range((e + bm - 1) // bm)]
     assert sorted(items) == sorted(want) and count == len(want)
     order = []                                   # requests in plan order, each one's blocks contiguous
@@ -326,11 +327,24 @@ def test_extend_plan_lists_every_row_block_once_and_changes_nothing(nat, Hq, Hkv
     o_plain = run_extend(nat, *args)
     o_plan = run_extend(nat, *args, plan=plan)
     assert torch.isfinite(o_plan.float()).all() and torch.equal(o_plan, o_plain)
-    # a plan built for other head counts (another block size) is ignored, never half-applied
-    if rows != 64:
+    # a stale or foreign plan must never drop rows.  The kernel checks the plan's header against its
+    # own launch and, on a mismatch, derives each workgroup's rows by walking the requests: same bits.
+    if rows != 64:                                   # built for other head counts (another block size)
         other = nat.extend_plan(ext_t, p["seq_lens"], sum(ext), 32, 8, True)
-        o_bad = run_extend(nat, *args, plan=other)
-        assert torch.isnan(o_bad.float()).all(), "mismatched plan: no workgroup writes"
+        if other.numel() >= plan.numel():
+            assert torch.equal(run_extend(nat, *args, plan=other), o_plain), "foreign plan: walked, not dropped"
+    # built for ANOTHER STEP with the same head counts: other lengths, same token count -> other items
+    ext2 = list(reversed(ext))
+    ext2_t = torch.tensor(ext2, dtype=torch.int32, device=DEV)
+    seq2 = torch.tensor([a + b for a, b in zip(pre, ext2)], device=DEV)
+    stale = nat.extend_plan(ext2_t, seq2, sum(ext2), Hq, Hkv, True)
+    assert stale.numel() == plan.numel()
+    hdr = stale.clone()
+    hdr[4] += 1                                       # ... and a plan whose recorded token count differs
+    assert torch.equal(run_extend(nat, *args, plan=hdr), o_plain), "plan of another step (header differs)"
+    # a plan buffer too small for the launch's grid is refused on the host
+    with pytest.raises(RuntimeError, match="workspace"):
+        run_extend(nat, *args, plan=plan[:8])
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])

@@ -5,8 +5,9 @@ steps through ScheduleBatch -> ModelRunner -> the HIP kernels, against the CPU o
 32-character text match against HF (tests/e2e/test_engine.py:8-57); BASELINE.json asks for <= 1e-3 logit deviation.
 
 Two cases:
-  * "n002": 2 layers, N(0, 0.02) weights (the bench's initialisation): tiny logits (max |logit| ~ 0.4), so one
-    16-bit rounding of the hidden state is already ~2e-3 of the logit scale.
+  * "n002": 2 layers, N(0, 0.02) weights (the bench's initialisation; max |logit| ~ 6): every projection
+    shrinks its input (std 0.02 * sqrt(K) ~ 1.3 .. 2.4 per unit input, but the residual stream stays at the
+    embedding's 0.02 scale), so the few roundings of the hidden state weigh ~2e-3 of the logit scale in fp16.
   * "fanin": 8 layers, fan-in-scaled weights (std 1/sqrt(K); LM head 3/sqrt(K), embedding N(0, 1)): unit-scale
     activations through every layer and logits of O(10), the regime of a trained model - and deep enough for
     rounding to accumulate over 8 residual updates.
@@ -16,8 +17,9 @@ order cannot show there; here every GEMM has K = 4096 / 14336 of non-trivial ope
 rounding regression in any kernel of the path moves the logits.
 
 Metric: max |logit - ref| / max |ref| per step.  Measured on MI355X (printed by the test, quoted in BASELINE.md):
-  n002  fp16: HIP vs fp32 oracle 1.7e-3 .. 2.1e-3 (torch fp16 vs fp32: 1.9e-3 .. 2.1e-3); bf16: 1.3e-2 .. 1.5e-2 (1.4e-2 .. 1.6e-2)
-  fanin: see MEASURED below (filled from the run that set the bounds)
+  n002  fp16: HIP vs fp32 oracle 1.7e-3 .. 2.1e-3 (torch fp16 vs fp32: 1.9e-3 .. 2.1e-3); bf16: 1.3e-2 .. 1.6e-2 (1.4e-2 .. 1.6e-2)
+  fanin fp16: HIP vs fp32 oracle 1.2e-3 .. 1.4e-3 (torch fp16 vs fp32: 1.2e-3 .. 1.5e-3); bf16: 0.95e-2 .. 1.04e-2 (0.91e-2 .. 1.10e-2)
+        (max |logit| 13.5 .. 14.8; greedy tokens equal to the fp32 oracle's on 100 % of rows in fp16, 88 - 100 % in bf16)
 Asserted: (1) the HIP path is no further from the fp32 oracle than torch's own 16-bit evaluation of the same
 layers + 10 %; (2) absolute bounds at <= 1.15 x the largest measured value.  Where 1e-3 is attainable: at kernel
 level (tests/test_gpu_attention.py: <= 0.87 units of fp16 round-off) and for fp16 logits of O(10) over few layers;
@@ -33,8 +35,8 @@ pytestmark = pytest.mark.gpu
 
 # largest measured max|dlogit| / max|logit| over the steps of a case (MI355X): (vs fp32 oracle, vs same-dtype oracle)
 MEASURED = {
-    ("n002", torch.float16): (2.07e-3, 1.31e-3), ("n002", torch.bfloat16): (1.55e-2, 1.05e-2),
-    ("fanin", torch.float16): (None, None), ("fanin", torch.bfloat16): (None, None),
+    ("n002", torch.float16): (2.07e-3, 1.31e-3), ("n002", torch.bfloat16): (1.56e-2, 1.06e-2),
+    ("fanin", torch.float16): (1.38e-3, 1.59e-3), ("fanin", torch.bfloat16): (1.04e-2, 1.19e-2),
 }
 LOOSE = {torch.float16: (6e-3, 6e-3), torch.bfloat16: (5e-2, 5e-2)}     # used only until a case has been measured
 

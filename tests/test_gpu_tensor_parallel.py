@@ -70,6 +70,9 @@ def _rank_main(rank, world, port, case, q, custom_ar=False):
         ref = ollama.forward(shape, w, okv, mode="extend", input_ids=ids, positions=pos, req_pool_indices=req,
                              seq_lens=torch.tensor(lens), out_cache_loc=loc, extend_seq_lens=ext, extend_start_loc=start)
         rel = lambda a, b: float((a.float().cpu() - b).abs().max() / b.abs().max())
+        with pytest.raises(RuntimeError, match="gather_full_logits"):
+            out.next_token_logits          # a collective never hides behind an attribute read under TP
+        out.gather_full_logits()           # explicit, on every rank
         assert out.next_token_logits.shape == ref.shape
         assert rel(out.next_token_logits, ref) <= 1e-4, ("prefill", rank, rel(out.next_token_logits, ref))
         assert torch.equal(nxt.cpu(), ref.argmax(-1))
@@ -85,6 +88,7 @@ def _rank_main(rank, world, port, case, q, custom_ar=False):
         batch = ModelWorkerBatch(bid=2, forward_mode=ForwardMode.DECODE, input_ids=nxt, req_pool_indices=req.to(dev),
                                  seq_lens=seq2.to(dev), out_cache_loc=loc2.to(dev), seq_lens_sum=13)
         out2, _ = worker.forward_batch_generation(batch)
+        out2.gather_full_logits()
         okv.req_to_token.copy_(table.cpu())
         ref2 = ollama.forward(shape, w, okv, mode="decode", input_ids=nxt.cpu(), positions=ops.clamp_position(seq2),
                               req_pool_indices=req, seq_lens=seq2, out_cache_loc=loc2)
@@ -409,7 +413,7 @@ def _rccl_main(rank, world, port, q, custom_ar):
         ref = ollama.forward(shape, w, okv, mode="extend", input_ids=ids, positions=pos, req_pool_indices=req,
                              seq_lens=torch.tensor(lens), out_cache_loc=loc, extend_seq_lens=ext, extend_start_loc=start)
         rel = lambda a, b: float((a.float().cpu() - b).abs().max() / b.abs().max())
-        assert rel(out.next_token_logits, ref) <= 1e-4, ("prefill over RCCL", rank)
+        assert rel(out.gather_full_logits(), ref) <= 1e-4, ("prefill over RCCL", rank)
         assert torch.equal(nxt.cpu(), ref.argmax(-1))
         loc2 = torch.tensor([20, 21])
         table[0, 7] = 20
@@ -424,11 +428,11 @@ def _rccl_main(rank, world, port, q, custom_ar):
                                   seq_lens=seq2.to(dev), out_cache_loc=loc2.to(dev), seq_lens_sum=13)
             return worker.forward_batch_generation(b2)
         out2, n2 = decode_once()                              # eager
-        assert rel(out2.next_token_logits, ref2) <= 1e-4, ("eager decode over RCCL", rank)
+        assert rel(out2.gather_full_logits(), ref2) <= 1e-4, ("eager decode over RCCL", rank)
         mr.init_cuda_graphs()                                 # collectives captured inside the graph
         for _ in range(3):
             out3, n3 = decode_once()
-            assert rel(out3.next_token_logits, ref2) <= 1e-4, ("graph decode over RCCL", rank)
+            assert rel(out3.gather_full_logits(), ref2) <= 1e-4, ("graph decode over RCCL", rank)
             assert torch.equal(n3, n2)
         ca = d.get_tp_group().ca_comm
         assert (ca is not None) == custom_ar
