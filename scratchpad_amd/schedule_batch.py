@@ -32,6 +32,7 @@ class Req:
     req_pool_idx: Optional[int] = None
     last_node: object = None                         # prefix-cache node the request holds a lock on
     fill_ids_override: Optional[List[int]] = None    # chunked prefill: the tokens of this round
+    extend_input_len_override: Optional[int] = None  # set by mix_with_running (1 for a running request)
     finished_reason: object = None
     sampling_params: object = None                   # sampler.SamplingParams (None = greedy)
     is_retracted: bool = False
@@ -58,6 +59,7 @@ class Req:
         """schedule_batch.py:472-510: look the prompt up in the prefix cache; at least one token
         is always left to compute so the step produces logits."""
         self.fill_ids_override = None
+        self.extend_input_len_override = None
         ids = self.origin_input_ids + self.output_ids
         if tree_cache is not None:
             self.prefix_indices, self.last_node = tree_cache.match_prefix(
@@ -73,7 +75,15 @@ class Req:
 
     @property
     def extend_input_len(self) -> int:
+        """tokens this request contributes to the extend step: fill_ids behind the cached prefix, unless the
+        scheduler has pinned it (mix_with_running sets 1 for a running request, schedule_batch.py:1077-1079)"""
+        if self.extend_input_len_override is not None:
+            return self.extend_input_len_override
         return len(self.fill_ids) - self.prefix_len
+
+    @extend_input_len.setter
+    def extend_input_len(self, n: Optional[int]):
+        self.extend_input_len_override = n
 
     @property
     def prefix_len(self) -> int:
@@ -100,6 +110,13 @@ class ScheduleBatch:
         self.seq_lens_sum = 0
         self.extend_num_tokens = None
         self.prefix_lens = self.extend_lens = None
+        # per-batch flags / per-request logprob requests the reference keeps on the batch
+        # (schedule_batch.py:618-640): carried through merge_batch / mix_with_running as it does
+        self.return_logprob = False
+        self.top_logprobs_nums: Optional[List[int]] = None
+        self.token_ids_logprobs: Optional[List[Optional[List[int]]]] = None
+        self.extend_logprob_start_lens: List[int] = []
+        self.has_stream = self.has_grammar = self.return_hidden_states = False
 
     def batch_size(self):
         return len(self.reqs)
@@ -213,6 +230,7 @@ class ScheduleBatch:
         running_bs = running_batch.batch_size()
         for req in running_batch.reqs:
             req.fill_ids = req.origin_input_ids + req.output_ids
+            req.extend_input_len = 1
         input_ids = torch.cat([self.input_ids, running_batch.input_ids])
         out_cache_loc = torch.cat([self.out_cache_loc, running_batch.out_cache_loc])
         self.merge_batch(running_batch)
@@ -224,6 +242,7 @@ class ScheduleBatch:
                                                for r in running_batch.reqs]
         self.extend_lens = self.extend_lens + [1] * running_bs
         self.extend_num_tokens += running_bs
+        self.extend_logprob_start_lens = list(self.extend_logprob_start_lens) + [0] * running_bs
 
     def prepare_for_decode(self):
         self.forward_mode = ForwardMode.DECODE
@@ -311,9 +330,12 @@ class ScheduleBatch:
         before the two are concatenated (row count must follow the merged request list)."""
         if self.sampling_info is not None or other.sampling_info is not None:
             from .sampler import SamplingBatchInfo
-            vocab = (self.sampling_info or other.sampling_info).vocab_size
-            mine = self.sampling_info or SamplingBatchInfo.from_schedule_batch(self, vocab)
-            theirs = other.sampling_info or SamplingBatchInfo.from_schedule_batch(other, vocab)
+            have = self.sampling_info if self.sampling_info is not None else other.sampling_info
+            vocab = have.vocab_size
+            mine = (self.sampling_info if self.sampling_info is not None
+                    else SamplingBatchInfo.from_schedule_batch(self, vocab))
+            theirs = (other.sampling_info if other.sampling_info is not None
+                      else SamplingBatchInfo.from_schedule_batch(other, vocab))
             mine.merge_batch(theirs)
             self.sampling_info = mine
         if self.is_encoder_decoder:
@@ -323,9 +345,26 @@ class ScheduleBatch:
         self.seq_lens = torch.cat([self.seq_lens, other.seq_lens])
         self.out_cache_loc = None
         self.seq_lens_sum += other.seq_lens_sum
-        if self.output_ids is not None and other.output_ids is not None:
+        if self.output_ids is not None:
+            # as the reference: a side that carries pending output ids needs the other side's, or the rows
+            # would no longer line up with reqs / seq_lens - fail loudly instead of keeping the old length
+            if other.output_ids is None:
+                raise RuntimeError("merge_batch: this batch carries output_ids but the merged one does not")
             self.output_ids = torch.cat([self.output_ids, other.output_ids])
+        if self.return_logprob and other.return_logprob:
+            self.top_logprobs_nums.extend(other.top_logprobs_nums)
+            self.token_ids_logprobs.extend(other.token_ids_logprobs)
+        elif self.return_logprob:
+            self.top_logprobs_nums.extend([0] * len(other.reqs))
+            self.token_ids_logprobs.extend([None] * len(other.reqs))
+        elif other.return_logprob:
+            self.top_logprobs_nums = [0] * len(self.reqs) + list(other.top_logprobs_nums)
+            self.token_ids_logprobs = [None] * len(self.reqs) + list(other.token_ids_logprobs)
         self.reqs = self.reqs + other.reqs
+        self.return_logprob |= other.return_logprob
+        self.has_stream |= other.has_stream
+        self.has_grammar |= other.has_grammar
+        self.return_hidden_states |= other.return_hidden_states
 
     def get_model_worker_batch(self) -> ModelWorkerBatch:
         global _bid

@@ -55,23 +55,24 @@ class TpModelWorkerClient:
 
     @torch.inference_mode()
     def forward_thread_func_(self):
-        batch_pt = 0
-        batch_lists = [None] * 2
-        while True:
-            model_worker_batch, future_token_ids_ct = self.input_queue.get()
-            if not model_worker_batch:
-                break
-            # keep the previous batch's tensors alive while the GPU may still read them (130-133)
-            batch_lists[batch_pt % 2] = model_worker_batch
-            batch_pt += 1
-            copy_done = torch.cuda.Event()
-            resolve_future_token_ids(model_worker_batch.input_ids, self.future_token_ids_map)
-            logits_output, next_token_ids = self.worker.forward_batch_generation(model_worker_batch)
-            bs = len(model_worker_batch.seq_lens)
-            self.future_token_ids_map[future_token_ids_ct + 1:future_token_ids_ct + bs + 1] = next_token_ids
-            next_token_ids = next_token_ids.to("cpu", non_blocking=True)
-            copy_done.record()
-            self.output_queue.put((copy_done, logits_output, next_token_ids))
+        """The forward thread's loop (protocol of tp_worker_client.py:118-168): take a batch, patch the
+        placeholder ids the scheduler put into it, run it, publish this batch's sampled ids for the NEXT
+        batch's placeholders, and hand the results back without waiting for the GPU."""
+        import collections
+        in_flight = collections.deque(maxlen=2)      # the GPU may still be reading the previous batch's tensors
+        for batch, first_slot in iter(self.input_queue.get, (None, None)):
+            in_flight.append(batch)
+            self.output_queue.put(self._run_one(batch, first_slot))
+
+    def _run_one(self, batch: ModelWorkerBatch, first_slot: int):
+        resolve_future_token_ids(batch.input_ids, self.future_token_ids_map)
+        logits_output, ids = self.worker.forward_batch_generation(batch)
+        n = len(batch.seq_lens)
+        self.future_token_ids_map[first_slot + 1:first_slot + 1 + n] = ids       # placeholder -k reads map[k]
+        host_ids = ids.to("cpu", non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()                                 # after the D2H copy on forward_stream
+        return done, logits_output, host_ids
 
     def resolve_last_batch_result(self, launch_done: Optional[threading.Event] = None):
         """tp_worker_client.py:170-190: wait for the previous batch's results (one step later)."""

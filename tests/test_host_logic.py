@@ -325,6 +325,28 @@ def test_mixed_batch_merges_sampling_info_like_the_reference():
     new, run = batches(None, (None, None))
     new.mix_with_running(run)
     assert new.sampling_info is None and len(new.reqs) == 3
+    # the mixed-in running requests are extend rows of length 1 (schedule_batch.py:1077-1079), their
+    # logprob bookkeeping and flags are carried (1361-1397), and pending output ids must line up or fail loudly
+    new, run = batches(None, (None, None))
+    run.return_logprob, run.top_logprobs_nums, run.token_ids_logprobs = True, [2, 0], [None, [3, 4]]
+    run.has_grammar = True
+    new.extend_logprob_start_lens = [0]
+    new.mix_with_running(run)
+    assert [r.extend_input_len for r in new.reqs] == [4, 1, 1]
+    assert new.extend_logprob_start_lens == [0, 0, 0]
+    assert new.return_logprob and new.top_logprobs_nums == [0, 2, 0] and new.token_ids_logprobs == [None, None, [3, 4]]
+    assert new.has_grammar and not new.has_stream
+    new.reqs[1].init_next_round_input()                 # the pin does not outlive the round
+    assert new.reqs[1].extend_input_len == 3
+    new, run = batches(None, (None, None))
+    new.output_ids = torch.tensor([42])
+    run.output_ids = torch.tensor([7, 9])
+    new.mix_with_running(run)
+    assert new.output_ids.tolist() == [42, 7, 9]
+    new, run = batches(None, (None, None))
+    new.output_ids = torch.tensor([42])                 # one side without output ids: rows would not line up
+    with pytest.raises(RuntimeError, match="output_ids"):
+        new.mix_with_running(run)
 
 
 def test_spare_row_views_and_library_row_table():
