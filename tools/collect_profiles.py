@@ -31,7 +31,9 @@ def main(tag):
     open(os.path.join(P, f"{tag}_bench_kernel_stats.txt"), "w").write(hdr + body + tail)
     for src, dst in (("bench_serve.json", "serve_trace.json"), ("bench_serve_prefix.json", "serve_trace_prefix512.json"),
                      ("mllama.log", "mllama11b.txt"), ("gemv.log", "gemv.txt"), ("sampling.log", "sampling.txt"),
-                     ("extend_attn.log", "extend_attn.txt"), ("extend_stamps.log", "extend_stamps_dma.txt")):
+                     ("extend_attn.log", "extend_attn.txt"), ("extend_stamps.log", "extend_stamps_dma.txt"),
+                     ("allreduce.log", "allreduce_rehearsal.txt"), ("parity_lines.txt", "parity_lines.txt"),
+                     ("bench_replicas2_refused.log", "replicas2_refused.txt")):
         p = os.path.join(R, src)
         if os.path.exists(p):
             text = "".join(line for line in open(p) if "amdgpu.ids" not in line)
@@ -39,7 +41,7 @@ def main(tag):
     lines = {}
     for f in ("bench_decode", "bench_prefill", "bench_serve", "bench_serve_prefix", "bench_bs1", "bench_bs8",
               "bench_bs32", "bench_ctx128", "bench_ctx1024", "bench_ctx4096", "bench_fp8kv", "bench_70b_rank",
-              "bench_tp2_rehearsal_gloo", "bench_tp2_rehearsal_direct", "bench_replicas2_rehearsal"):
+              "bench_tp2_rehearsal_gloo", "bench_tp2_rehearsal_direct", "bench_replicas2_rehearsal", "bench_librows_auto"):
         p = os.path.join(R, f + ".json")
         if os.path.exists(p):
             d = last_json(p)
