@@ -295,9 +295,13 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
           s[kb][r] = vis ? s[kb][r] : -INFINITY;
         }
     }
+#ifdef SP_X_NOMAX          // DIAGNOSTIC (wrong results): what the row-maximum tree of a tile costs
+    float mx = fmaxf(s[0][0], s[1][15]);
+#else
     float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
+#endif
     mx = fmaxf(mx, xchg32(mx));
     const float m_cand = mx * sc;               // sc > 0: the maximum commutes with the scale
     if (__any(m_cand > m_run + a.defer)) {      // rare once the row maxima have settled
@@ -315,9 +319,17 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+#if defined(SP_X_NOEXP)   // DIAGNOSTIC (wrong results): what the 32 v_exp of a tile cost
+        const float p = __builtin_fmaf(s[kb][r], sc, -m_run);
+#elif defined(SP_X_NOFMAEXP)   // DIAGNOSTIC (wrong results): neither the fma nor the exp
+        const float p = s[kb][r];
+#else
         const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], sc, -m_run));
+#endif
         s[kb][r] = p;
+#ifndef SP_X_NOADD        // DIAGNOSTIC (wrong results): what the 32 row-sum adds of a tile cost
         psum += p;
+#endif
       }
     l_part += psum;
     // B operands of O^T += V^T . P^T: registers 8s..8s+7 of an S^T block, rounded to the KV dtype
