@@ -68,7 +68,7 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 // PLAIN: no logit cap and no sliding window (both compiled out of the tile loop)
 template <typename Tag, int D, int GK, int NW, bool KV8, bool PLAIN, bool DMA>
 __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
-  static_assert(!DMA || (D == 128 && !KV8 && NW == 8), "the LDS-DMA image is laid out for 256-byte rows and 8 waves");
+  static_assert(!DMA || ((D == 128 || D == 64) && !KV8 && NW == 8), "the LDS-DMA images are laid out for 256- / 128-byte rows and 8 waves");
   constexpr int NT = NW * 64;
   constexpr int NB = 2;                // LDS tile buffers: tile t lives in buffer t & 1
   typedef ExtCfg<D, NT> C;
@@ -228,15 +228,23 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
   // tr-read address pieces: lane i of a 16-lane group supplies row (i>>2), columns 4*(i&3)..+3
   const int i16 = lane & 15, g16 = lane >> 4;
   const int tr_rowq = i16 >> 2, tr_col = ((g16 & 1) * 16 + (i16 & 3) * 4) * 2;  // bytes
-  // LDS-DMA image (DMA): rows of 256 B without padding (a DMA piece is 1 KiB of consecutive LDS = 4 rows),
-  // made conflict-free by the SOURCE address each lane asks for: K row r keeps its 16-byte chunk c at
-  // position c ^ (r & 15) (ds_read_b128 serves 16 lanes = 16 different rows mod 16 at a time), V row r
-  // keeps chunk c at c ^ ((r & 3) << 2) (a transposed read serves 4 rows x 64 B per 32 lanes).  Four
-  // K and four V buffers (128 KiB).
-  constexpr int kDmaTile = 64 * 256;
+  // LDS-DMA image (DMA): rows of ROW_B = 256 B (D = 128) or 128 B (D = 64) without padding (a DMA piece is 1 KiB of
+  // consecutive LDS = 4 or 8 rows), made conflict-free by the SOURCE address each lane asks for, i.e. row r keeps its
+  // 16-byte chunk c at position c ^ f(r):
+  //   D = 128   K: f = r & 15 (a ds_read_b128 serves 16 lanes = 16 different rows mod 16 at a time)
+  //             V: f = (r & 3) << 2 (a transposed read serves 4 rows x 64 B per 32 lanes)
+  //   D = 64    rows r and r + 2 share their banks (256 B wrap), so the row PAIR index drives the swizzle:
+  //             K: f = (r >> 1) & 7 (the 16 lanes of a ds_read_b128 group hold 8 even and 8 odd rows whose pair
+  //                indices are all different), V: f = ((r >> 1) & 1) << 2 (the 4 rows of a transposed read land on
+  //                the four 64-byte quarters of the bank space)
+  // Four K and four V buffers (D = 128: 128 KiB; D = 64: 64 KiB).
+  constexpr int kRowB = 2 * D;                       // bytes of a K / V row in LDS
+  constexpr int kDmaTile = 64 * kRowB;
   constexpr int kDmaBufs = 4;   // tile t is consumed from buffer t % 4 while t+1, t+2 and t+3 are in flight
-  const int k_swz = (c & 15) ^ h;
-
+  constexpr int kCPR = kRowB / 16;                   // 16-byte chunks per row (16 / 8)
+  constexpr int kRPP = 64 / kCPR;                    // rows per DMA piece (4 / 8)
+  constexpr int kPPW = 8 / kRPP;                     // pieces per wave and tile, each for K and for V (2 / 1)
+  const int k_swz = D == 128 ? ((c & 15) ^ h) : (((c >> 1) & 7) ^ h);
   // pipeline: the gathers of tiles t+1 and t+2 fly during compute(t); tile t+1 is written to the other
   // LDS buffer right after compute(t), and one barrier per tile both publishes tile t+1 and retires
   // every wave's reads of the buffer that tile t+2 will overwrite.
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-      const char* kp = DMA ? ldsK + kb * 32 * 256 + c * 256 : ldsK + (kb * 32 + c) * SK + h * 16;
+      const char* kp = DMA ? ldsK + kb * 32 * kRowB + c * kRowB : ldsK + (kb * 32 + c) * SK + h * 16;
       // all fragment reads of the block are issued before its first MFMA (distinct registers), so
       // one LDS latency is exposed per block instead of one per MFMA; the sched_barrier keeps the
       // scheduler from sinking each read next to its MFMA again (it then reuses one register quad
@@ -355,38 +363,54 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
       uint32_t va[DBLK];
       {
         const uint32_t vbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds +
-                               (kDmaBufs + buf) * kDmaTile + (4 * h + tr_rowq) * 256 + tr_col;
+                               (kDmaBufs + buf) * kDmaTile + (4 * h + tr_rowq) * kRowB + tr_col;
+        const int vsw = D == 128 ? tr_rowq : (tr_rowq >> 1);   // 64-byte unit swizzle of this lane's row
 #pragma unroll
-        for (int db = 0; db < DBLK; ++db) va[db] = vbase + ((db ^ tr_rowq) << 6);
+        for (int db = 0; db < DBLK; ++db) va[db] = vbase + ((db ^ vsw) << 6);
       }
       u32x2 lo[2][DBLK], hi[2][DBLK];
 #define SP_TR_ISSUE(SET, STEP)                                                                       \
   _Pragma("unroll") for (int db = 0; db < DBLK; ++db) {                                              \
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[SET][db]) : "v"(va[db]), "n"((STEP) * 16 * 256));          \
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[SET][db]) : "v"(va[db]), "n"((STEP) * 16 * 256 + 2048));   \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[SET][db]) : "v"(va[db]), "n"((STEP) * 16 * kRowB));            \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[SET][db]) : "v"(va[db]), "n"((STEP) * 16 * kRowB + 8 * kRowB)); \
   }
-#define SP_TR_WAIT(SET, N)                                                                           \
-  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                           \
-               : "+v"(lo[SET][0]), "+v"(lo[SET][1]), "+v"(lo[SET][2]), "+v"(lo[SET][3]),             \
-                 "+v"(hi[SET][0]), "+v"(hi[SET][1]), "+v"(hi[SET][2]), "+v"(hi[SET][3]))
+// (the waits name every register of the set they cover; N = reads still allowed in flight = 2 * DBLK of the other set)
+#define SP_TR_WAIT(SET, LATER)                                                                       \
+  do {                                                                                               \
+    if constexpr (DBLK == 4) {                                                                       \
+      if constexpr (LATER)                                                                           \
+        asm volatile("s_waitcnt lgkmcnt(8)"                                                          \
+                     : "+v"(lo[SET][0]), "+v"(lo[SET][1]), "+v"(lo[SET][2]), "+v"(lo[SET][3]),       \
+                       "+v"(hi[SET][0]), "+v"(hi[SET][1]), "+v"(hi[SET][2]), "+v"(hi[SET][3]));      \
+      else                                                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)"                                                          \
+                     : "+v"(lo[SET][0]), "+v"(lo[SET][1]), "+v"(lo[SET][2]), "+v"(lo[SET][3]),       \
+                       "+v"(hi[SET][0]), "+v"(hi[SET][1]), "+v"(hi[SET][2]), "+v"(hi[SET][3]));      \
+    } else {                                                                                         \
+      if constexpr (LATER)                                                                           \
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(lo[SET][0]), "+v"(lo[SET][1]), "+v"(hi[SET][0]), "+v"(hi[SET][1])); \
+      else                                                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[SET][0]), "+v"(lo[SET][1]), "+v"(hi[SET][0]), "+v"(hi[SET][1])); \
+    }                                                                                                \
+  } while (0)
 #define SP_TR_MFMA(SET, STEP)                                                                        \
   _Pragma("unroll") for (int db = 0; db < DBLK; ++db) {                                              \
     u32x4 vf;                                                                                        \
     vf[0] = lo[SET][db][0]; vf[1] = lo[SET][db][1]; vf[2] = hi[SET][db][0]; vf[3] = hi[SET][db][1];  \
     oacc[db] = mfma32<CT>(vf, pf[STEP], oacc[db]);                                                   \
   }
-      static_assert(!DMA || DBLK == 4, "wait lists are written for four d blocks");
+      static_assert(!DMA || DBLK == 4 || DBLK == 2, "wait lists are written for four or two d blocks");
       SP_TR_ISSUE(0, 0)
       SP_TR_ISSUE(1, 1)
-      SP_TR_WAIT(0, 8);
+      SP_TR_WAIT(0, true);
       SP_TR_MFMA(0, 0)
       SP_TR_ISSUE(0, 2)
-      SP_TR_WAIT(1, 8);
+      SP_TR_WAIT(1, true);
       SP_TR_MFMA(1, 1)
       SP_TR_ISSUE(1, 3)
-      SP_TR_WAIT(0, 8);
+      SP_TR_WAIT(0, true);
       SP_TR_MFMA(0, 2)
-      SP_TR_WAIT(1, 0);
+      SP_TR_WAIT(1, false);
       SP_TR_MFMA(1, 3)
 #undef SP_TR_ISSUE
 #undef SP_TR_WAIT
@@ -421,25 +445,27 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
   };
 
   if constexpr (DMA) {
-    const int dR = lane >> 4, dp = lane & 15;
+    const int dR = lane / kCPR, dp = lane % kCPR;     // row within a piece / 16-byte chunk position of this lane
     const int64_t row_off = (int64_t)hk * D * 2;
-    struct Slots { int s[2]; };
+    struct Slots { int s[kPPW]; };
     Slots s0, s1, s2, s3;   // slot indices of tiles x with (x - tbeg) % 4 == 0, 1, 2, 3
     auto load_slots = [&](Slots& r, int tile) __attribute__((always_inline)) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int key = tile * BN + wave * 8 + 4 * j + dR;
+      for (int j = 0; j < kPPW; ++j) {
+        const int key = tile * BN + wave * 8 + kRPP * j + dR;
         r.s[j] = idx_row[max(min(key, kv_len - 1), 0)];   // see fetch_slots
       }
     };
     auto dma = [&](const Slots& r, int buf) __attribute__((always_inline)) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int R = wave * 8 + 4 * j + dR;
+      for (int j = 0; j < kPPW; ++j) {
+        const int R = wave * 8 + kRPP * j + dR;
         const int64_t off = (int64_t)r.s[j] * tok_bytes + row_off;
-        const char* ks = a.kbuf + off + ((dp ^ (R & 15)) << 4);
-        const char* vs = a.vbuf + off + ((dp ^ ((R & 3) << 2)) << 4);
-        char* kd = lds + buf * kDmaTile + (wave * 8 + 4 * j) * 256;
+        const int fk = D == 128 ? (R & 15) : ((R >> 1) & 7);
+        const int fv = D == 128 ? ((R & 3) << 2) : (((R >> 1) & 1) << 2);
+        const char* ks = a.kbuf + off + ((dp ^ fk) << 4);
+        const char* vs = a.vbuf + off + ((dp ^ fv) << 4);
+        char* kd = lds + buf * kDmaTile + (wave * 8 + kRPP * j) * kRowB;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
                                          (__attribute__((address_space(3))) void*)kd, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs,
@@ -447,11 +473,11 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
       }
     };
     // The compiler does not track LDS-DMA arrivals: the waits are placed by hand.  A tile step issues
-    // 2 index loads (tile +5) and the 4 DMA pieces of tile +3; before the barrier that publishes tile +1,
-    // everything up to ITS pieces must have landed, i.e. all but the pieces of tiles +2 and +3.  The count
-    // must not rely on the index loads: hipcc hoists them ahead of the prologue's pieces and deletes
-    // them from the tail steps (unused values), so the wait is "all but the 8 youngest operations",
-    // which leaves at most the pieces of tiles +2 and +3 in flight whatever else was issued between them.
+    // kPPW index loads (tile +5) and the 2 kPPW DMA pieces of tile +3 (D = 128: 2 + 4; D = 64: 1 + 2); before the
+    // barrier that publishes tile +1, everything up to ITS pieces must have landed, i.e. all but the pieces of tiles
+    // +2 and +3.  The count must not rely on the index loads: hipcc hoists them ahead of the prologue's pieces and
+    // deletes them from the tail steps (unused values), so the wait is "all but the 4 kPPW youngest operations"
+    // (8 / 4), which leaves at most the pieces of tiles +2 and +3 in flight whatever else was issued between them.
     // A raw s_barrier: __syncthreads() would drain every DMA in flight (its fence waits vmcnt(0)).
     load_slots(s0, tbeg);
     load_slots(s1, tbeg + 1);
@@ -469,7 +495,8 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
     // (the s_waitcnt builtin, not asm text: hipcc's own wait insertion sees it and learns that the older
     // loads - the Q fragments, the index loads - have landed; an asm wait it cannot see leaves it
     // believing they may still be pending at the loop head and it drains vmcnt(0) in every iteration)
-    __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8): tile tbeg has landed
+    if constexpr (kPPW == 2) __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8): tile tbeg has landed
+    else __builtin_amdgcn_s_waitcnt(0x0F74);                          // vmcnt(4)
     asm volatile("s_barrier" ::: "memory");
     SP_WGSTAMP(wg2);
     auto step = [&](int t, int buf, Slots& refill, const Slots& issue) __attribute__((always_inline)) {
@@ -492,7 +519,8 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_mfma_kernel(ExtendArgs a) {
       stamp_sum[7] += 1;
 #endif
       SP_STAMP(ts4);
-      __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0)
+      if constexpr (kPPW == 2) __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0)
+      else __builtin_amdgcn_s_waitcnt(0x0074);                          // vmcnt(4) lgkmcnt(0)
       SP_STAMP(ts5);
       asm volatile("s_barrier" ::: "memory");
       SP_STAMP(ts6);
@@ -656,7 +684,7 @@ static int launch_extend(const ExtendArgs& a, int max_extend_len, int halves, hi
   const bool plain = !(a.logit_cap > 0.f) && a.window < 0;
 #define SP_EXT_LAUNCH(KV8_, PLAIN_, DMA_)                                                            \
   do {                                                                                               \
-    constexpr int lds_bytes = DMA_ ? 8 * 64 * 256 : kLds;                                            \
+    constexpr int lds_bytes = DMA_ ? 8 * 64 * 2 * D : kLds;                                          \
     static bool attr_set = false; /* benign race: idempotent */                                      \
     if (!attr_set && lds_bytes > 64 * 1024) {                                                        \
       (void)hipFuncSetAttribute((const void*)extend_mfma_kernel<Tag, D, GK, NW, KV8_, PLAIN_, DMA_>, \
@@ -667,10 +695,8 @@ static int launch_extend(const ExtendArgs& a, int max_extend_len, int halves, hi
   } while (0)
   if (a.kv8) {
     if (plain) SP_EXT_LAUNCH(true, true, false); else SP_EXT_LAUNCH(true, false, false);
-  } else if (D == 128 && g_extend_dma) {
-    if constexpr (D == 128) {
-      if (plain) SP_EXT_LAUNCH(false, true, true); else SP_EXT_LAUNCH(false, false, true);
-    }
+  } else if (g_extend_dma) {       // 16-bit pools, D 128 or 64: K/V tiles by LDS-DMA into the swizzled ring
+    if (plain) SP_EXT_LAUNCH(false, true, true); else SP_EXT_LAUNCH(false, false, true);
   } else {
     if (plain) SP_EXT_LAUNCH(false, true, false); else SP_EXT_LAUNCH(false, false, false);
   }

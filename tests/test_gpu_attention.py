@@ -379,14 +379,16 @@ def test_extend_deferred_maximum_agrees_with_exact_running_maximum(nat, dt):
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("causal_window", [(-1, 0.0), (300, 0.0), (-1, 30.0)])
-def test_extend_dma_ring_and_register_staging_give_the_same_bits(nat, dt, causal_window):
-    """D = 128, 16-bit pools: the K/V tiles reach LDS by LDS-DMA into a swizzled four-buffer ring; every
-    other shape (and this one with sp_debug_set("extend_dma", 0)) stages them through registers into
-    padded rows.  Same tile order, same arithmetic: the outputs must be identical, ragged prefixes,
-    sliding window and logit cap included (the ring's hand-counted waits are what this would catch)."""
+@pytest.mark.parametrize("D", [128, 64])
+def test_extend_dma_ring_and_register_staging_give_the_same_bits(nat, dt, causal_window, D):
+    """16-bit pools, D = 128 and (round 3) D = 64: the K/V tiles reach LDS by LDS-DMA into a swizzled four-buffer
+    ring (256-byte rows swizzled by the row, 128-byte rows by the row PAIR); byte pools (and either shape with
+    sp_debug_set("extend_dma", 0)) stage them through registers into padded rows.  Same tile order, same
+    arithmetic: the outputs must be identical, ragged prefixes, sliding window and logit cap included (a wrong
+    swizzle or a miscounted wait is what this would catch)."""
     dtype = DTYPES[dt]
     window, cap = causal_window
-    Hq, Hkv, D = 8, 2, 128
+    Hq, Hkv = 8, 2
     pre, ext = [0, 513, 64, 1], [700, 257, 64, 1]
     p, q, ext_t, start = extend_problem(61, Hq, Hkv, D, pre, ext, dtype)
     args = (q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"], p["seq_lens"], ext_t, start,
