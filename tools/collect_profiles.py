@@ -41,7 +41,7 @@ def main(tag):
     lines = {}
     for f in ("bench_decode", "bench_prefill", "bench_serve", "bench_serve_prefix", "bench_bs1", "bench_bs8",
               "bench_bs32", "bench_ctx128", "bench_ctx1024", "bench_ctx4096", "bench_fp8kv", "bench_70b_rank",
-              "bench_tp2_rehearsal_gloo", "bench_tp2_rehearsal_direct", "bench_replicas2_rehearsal", "bench_librows_auto"):
+              "bench_tp2_rehearsal_gloo", "bench_tp2_rehearsal_direct", "bench_replicas2_rehearsal", "bench_librows_auto", "bench_tp4_70b_full_depth"):
         p = os.path.join(R, f + ".json")
         if os.path.exists(p):
             d = last_json(p)

@@ -40,11 +40,21 @@ SP_LIBRARY_ROWS=auto timeout -k 10 300 python bench.py --no-cpu-baseline --no-tt
 timeout -k 10 280 python tools/bench_allreduce.py --world 2 2>&1 | grep -v "Gloo\|socket.cpp\|amdgpu.ids" > $R/allreduce.log || exit 1
 timeout -k 10 280 python tools/bench_allreduce.py --world 4 --blocks 0 32 2>&1 | grep -v "Gloo\|socket.cpp\|amdgpu.ids" >> $R/allreduce.log || exit 1
 cut -c1-200 $R/bench_tp2_rehearsal_gloo.json
+fi
+if [ "$STAGE" = "all" ] || [ "$STAGE" = "stage3" ]; then
+# (the stamps twin of the library: bash tools/build_stamps.sh on the build host; skipped when it is not there)
+if [ -f scratchpad_amd/lib/libscratchpad_hip_stamps.so ]; then
 timeout -k 10 200 python tools/stamp_extend_attn.py --waves 8 > $R/extend_stamps.log 2>&1 || { tail -5 $R/extend_stamps.log; exit 1; }
+fi
 timeout -k 10 500 python tools/bench_mllama.py > $R/mllama.log 2>&1 || { tail -20 $R/mllama.log; exit 1; }
 grep mllama $R/mllama.log
 timeout -k 10 300 python tools/bench_gemv.py > $R/gemv.log 2>&1 || { tail -20 $R/gemv.log; exit 1; }
 grep "per-layer" $R/gemv.log
+# config 4 at FULL DEPTH as far as one GPU allows: Llama-3-70B, all 80 layers, bs 128, sharded TP = 4 over four ranks that
+# share this GPU (140 GB of weights + the KV pools fit in 288 GB; TP = 8 would need 8 processes on the card, the box allows 6),
+# direct all-reduce + fused norm: a rehearsal of the workload's code path (161 collectives per step), not of xGMI
+SP_CUSTOM_ALLREDUCE=1 timeout -k 10 600 python bench.py --rehearsal --mode tp --gpus 4 --tp 4 --model llama3-70b --steps 6 --warmup 2 2>$R/bench_tp4_70b_full_depth.err | tail -1 > $R/bench_tp4_70b_full_depth.json || { tail -5 $R/bench_tp4_70b_full_depth.err; exit 1; }
+cut -c1-300 $R/bench_tp4_70b_full_depth.json
 fi
 if [ "$STAGE" = "all" ] || [ "$STAGE" = "--profile-only" ]; then
 cd /tmp && export TMPDIR=/tmp
