@@ -439,7 +439,8 @@ static int launch_fused(const ArFusedArgs& a, bool two_shot, hipStream_t st) {
   // GPU (tools/bench_allreduce.py, [128, 8192] bf16, 2 / 4 ranks, us per call): 128 workgroups 73 / 207,
   // 64: 37, 32: 39 / 95, 16: 55 - every barrier is a system-scope fence per workgroup, and those serialise;
   // all-reduce + norm as two launches: 33 / 122
-  const int cap = g_fused_blocks > 0 ? g_fused_blocks : kFusedBlocks;
+  // (4 ranks: 32 workgroups 91 - 95, 64: 140 - the fences of more ranks serialise harder - so the cap halves above 2 ranks)
+  const int cap = g_fused_blocks > 0 ? g_fused_blocks : (a.c.world <= 2 ? kFusedBlocks : kFusedBlocks / 2);
   const int blocks = a.T < cap ? a.T : cap;
   if (two_shot)
     all_reduce_add_rmsnorm_kernel<Tag, true, MAXIT><<<dim3(blocks), kFusedThreads, 0, st>>>(a);
