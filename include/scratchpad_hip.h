@@ -131,7 +131,7 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  * length under graph capture); a device-side seq_lens[b] above it is clamped to it, never followed.
  *
  * Split-KV geometry (ABI 4).  A request is cut into splits of `chunk` keys; split c of request b writes
- * its partial (o, log-sum-exp) to SLOT slot0[b] + c of the workspace ([max_slots, Hq, D] + [max_slots, Hq]
+ * its partial (o, log-sum-exp) to SLOT slot0[b] + c of the workspace ([Hq, max_slots, D] + [Hq, max_slots]
  * floats) and one merge wave per (request, head) combines them.
  *   - Without a plan the grid is the static (request, split) rectangle: slot0[b] = b * num_splits,
  *     num_splits = ceil(max_seq_len / chunk), max_slots is ignored (= batch_size * num_splits).

@@ -22,8 +22,8 @@ struct DecodeArgs {
   int max_len;      // host-side bound of a request's kv length: device-side seq_lens are clamped to it
   int chunk, num_splits, hh_shift, head_groups;   // chunk / num_splits: the plan-less geometry (plan: plan[1])
   int max_slots;    // partial slots the workspace holds; work items the launch covers when planned
-  float* part_o;    // [max_slots, Hq, D]   slot of (request b, split c): split_slot0() + c
-  float* part_lse;  // [max_slots, Hq]      (log2 domain)
+  float* part_o;    // [Hq, max_slots, D]   slot of (request b, split c): slot0[b] + c (a request's splits are adjacent)
+  float* part_lse;  // [Hq, max_slots]      (log2 domain)
   int kv8;              // 1: the pool holds fp8 e5m2 bytes (kv_stride in bytes); 16-bit q/out only
   // optional, from sp_decode_plan: [count, chunk, slot0[bs], (b, c) x count].  The CHUNK is part of the
   // plan (device memory), so a captured launch follows whatever split size the step's plan was built

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeArgs a) {
     if (nsplit == 1) {
       E::store(a.out, (int64_t)b * a.o_stride + (int64_t)h * D + d, o * a.out_scale);
     } else {
-      const int64_t pi = (int64_t)(slot0 + c) * a.Hq + h;
+      const int64_t pi = (int64_t)h * a.max_slots + (slot0 + c);
       a.part_o[pi * D + d] = o;
       if (d == 0) a.part_lse[pi] = M + __builtin_amdgcn_logf(L);  // v_log_f32 = log2
     }
@@ -305,10 +305,12 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
   if (nsplit <= 1) return;  // written directly by the attention kernel (or empty row)
   nsplit = min(nsplit, a.max_slots - slot0);   // never past the workspace (a plan cut short by a broken bound)
   if (nsplit < 1) return;
-  // split c of this (request, head): slot slot0 + c, partials laid out [slot][Hq][D]
-  const int64_t sstride = a.Hq;                // slots are Hq rows apart
-  const float* lse = a.part_lse + (int64_t)slot0 * a.Hq + h;
-  const float* po = a.part_o + ((int64_t)slot0 * a.Hq + h) * D;
+  // split c of this (request, head): slot slot0 + c of head h, partials laid out [Hq][slot][D] - a request's splits are
+  // consecutive slots, so one (request, head)'s partials are one contiguous run (with [slot][Hq][D] the merge read
+  // 512-byte pieces 16 KiB apart and took 10.5 us instead of 6.8 at the headline shape)
+  const int64_t sstride = 1;
+  const float* lse = a.part_lse + (int64_t)h * a.max_slots + slot0;
+  const float* po = a.part_o + ((int64_t)h * a.max_slots + slot0) * D;
   constexpr int PER = D / 64;
   constexpr int GRP = 16;
   float o[PER], W = 0.f, M = kNegBig;

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
           *(u32x2*)(op + db * 32) = w;
         }
       } else {
-        const int64_t pi = (int64_t)(slot0 + c) * a.Hq + h;
+        const int64_t pi = (int64_t)h * a.max_slots + (slot0 + c);
         float* pp = a.part_o + pi * D + 4 * kq;
 #pragma unroll
         for (int db = 0; db < DBLK; ++db)
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
     if (nsplit == 1) {
       E::store(a.out, (int64_t)b * a.o_stride + (int64_t)h * D + d, o * a.out_scale);
     } else {
-      const int64_t pi = (int64_t)(slot0 + c) * a.Hq + h;
+      const int64_t pi = (int64_t)h * a.max_slots + (slot0 + c);
       a.part_o[pi * D + d] = o;
       if (d == 0) a.part_lse[pi] = M + __builtin_amdgcn_logf(L);
     }
