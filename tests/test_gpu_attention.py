@@ -712,3 +712,51 @@ def test_long_context_decode_and_extend(nat):
                     lambda v: ops.extend_attention(q.cpu().float(), c["k_buffer"].float(), v, c["req_to_token"],
                                                    c["req_pool_indices"], c["seq_lens"], ext_t.cpu(), start.cpu(), scale))
     assert pre[0] == 39700
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_decode_plan_fuzz_planned_equals_static_bit_for_bit(nat, seed):
+    """Randomised batches through the round-3 split geometry: up to 700 requests (the plan's scans cross several
+    256-request tiles, slot0 is an exclusive scan over all of them), lengths 0 .. 900 with empty and one-token rows,
+    a tight slot budget (sum / chunk + bs), int32 and int64 index tensors, a kv_start window.  The planned launch
+    (items listed longest first, compact slots) must give the SAME BITS as the static (request, split) grid with the
+    same split size, and the plan's header must agree with a host-side recount."""
+    g = torch.Generator().manual_seed(100 + seed)
+    bs = [37, 300, 700][seed]
+    chunk = [64, 128, 256][seed]
+    Hq, Hkv, D = [(8, 2, 128), (32, 8, 128), (4, 4, 64)][seed]
+    lens = torch.randint(0, 901, (bs,), generator=g)
+    lens[torch.randint(0, bs, (bs // 10,), generator=g)] = 0           # empty rows (left untouched by the kernels)
+    lens[torch.randint(0, bs, (bs // 10,), generator=g)] = 1
+    lens[0] = 900
+    start = torch.randint(0, 5, (bs,), generator=g)                   # a small kv_start window in front of every row
+    p = paged_problem(200 + seed, bs, Hq, Hkv, D, [int(l) + 5 for l in lens], torch.bfloat16, DEV)
+    seq = lens.to(DEV)
+    q, req = p["q"], p["req_pool_indices"]
+    max_len = 900
+    for idx_dtype in (torch.int64, torch.int32):
+        s_, r_, k0 = seq.to(idx_dtype), req.to(idx_dtype), start.to(DEV).to(idx_dtype)
+        ws = torch.empty(nat.decode_workspace_bytes(bs, Hq, D, max_len, chunk), dtype=torch.uint8, device=DEV)
+        o_static = torch.zeros_like(q)
+        nat.decode_attention(o_static, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], r_, s_, 0.09, 0.0,
+                             max_len, chunk, ws, k0, None)
+        slots = nat.decode_plan_slots(bs, max_len, chunk, kv_tokens=int(lens.sum()))
+        plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, slots) // 4, dtype=torch.int32, device=DEV)
+        nat.decode_plan(plan, s_, max_len, chunk, slots)
+        nsplit = (lens + chunk - 1) // chunk
+        host = plan.cpu()
+        assert int(host[0]) == int(nsplit.sum()) <= slots and int(host[1]) == chunk
+        assert torch.equal(host[2:2 + bs].long(), torch.cumsum(nsplit, 0) - nsplit)
+        ws2 = torch.empty(nat.decode_workspace_bytes(bs, Hq, D, max_len, chunk, slots), dtype=torch.uint8, device=DEV)
+        o_plan = torch.zeros_like(q)
+        nat.decode_attention(o_plan, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], r_, s_, 0.09, 0.0,
+                             max_len, chunk, ws2, k0, plan, max_slots=slots)
+        assert torch.isfinite(o_plan.float()).all() and torch.equal(o_plan, o_static), (seed, idx_dtype)
+    # and against the oracle on a handful of rows (the longest, an empty one, a one-token one)
+    rows = [0, int((lens == 0).nonzero()[0]), int((lens == 1).nonzero()[0]), bs - 1]
+    c = cpu(p)
+    ref = ops.decode_attention(c["q"].float(), c["k_buffer"].float(), c["v_buffer"].float(), c["req_to_token"],
+                               c["req_pool_indices"], lens, 0.09, 0.0, start)
+    live = [r for r in rows if int(lens[r]) > 0]
+    assert_close(o_plan[live], ref[live], torch.bfloat16, what=f"decode fuzz seed {seed}")
+    assert float(o_plan[rows[1]].float().abs().max()) == 0.0, "an empty row is left untouched"
