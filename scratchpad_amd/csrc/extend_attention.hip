@@ -103,6 +103,7 @@ __global__ __launch_bounds__(kPlanThreads) void extend_plan_kernel(
 
 int extend_block_rows(int num_q_heads, int num_kv_heads);   // extend_mfma.hip
 void set_ar_fused_blocks(int n);                            // allreduce.hip
+void set_skinny_nt(int v);                                  // gemm_skinny.hip
 
 }  // namespace sp
 
@@ -142,6 +143,7 @@ extern "C" int sp_debug_set(const char* key, int value) {
   if (!strcmp(key, "extend_defer_x10")) { set_extend_defer_x10(value); return SP_OK; }
   if (!strcmp(key, "extend_dma")) { set_extend_dma(value); return SP_OK; }
   if (!strcmp(key, "ar_fused_blocks")) { set_ar_fused_blocks(value); return SP_OK; }
+  if (!strcmp(key, "skinny_nt")) { set_skinny_nt(value); return SP_OK; }
   return SP_ERR_INVALID_ARG;
 }
 

@@ -52,7 +52,12 @@ constexpr int kSkWaves = 8;
 // (gate_up 28672x4096 at 1 row: NB 2 53.9 us vs NB 1 44.1 us; LM head 128256x4096: NB 4 206 us vs
 // NB 1 166 us; same sign at 8 rows) - fewer, fatter workgroups lose more than the x reads cost -
 // so launch_skinny always takes NB = 1; the parameter stays for re-measurement.
-template <typename Tag, int NB, int UNROLL>
+// NT (sp_debug_set("skinny_nt", 1); OFF by default): non-temporal weight loads - the weights are read exactly once by
+// exactly one workgroup (MI355X_MICROARCH.md, 'nt-weights').  Measured on this kernel it LOSES: 1 row qkv 14.5 vs 13.6 us,
+// gate_up 46.5 vs 43.3, LM head 186 vs 166; bench.py --bs 1: 4.13 vs 3.98 ms/step (round 3, tools/bench_gemv.py).
+__device__ __forceinline__ u32x4 ld16_nt(const void* p) { return __builtin_nontemporal_load((const u32x4*)p); }
+
+template <typename Tag, int NB, int UNROLL, bool NT>
 __global__ __launch_bounds__(kSkWaves * 64) void gemm_skinny_kernel(SkinnyArgs a) {
   typedef Elem<Tag> E;
   __shared__ float red[kSkWaves][NB][16 * 17];
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(kSkWaves * 64) void gemm_skinny_kernel(SkinnyArgs a
     for (int u = 0; u < UNROLL; ++u) {
       const int64_t off = (int64_t)(ks + u * kSkWaves) * 64;
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) wf[u][nb] = ld16(wp[nb] + off);
+      for (int nb = 0; nb < NB; ++nb) wf[u][nb] = NT ? ld16_nt(wp[nb] + off) : ld16(wp[nb] + off);
       xf[u] = mrow ? ld16(xp + off) : zero;
     }
 #pragma unroll
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(kSkWaves * 64) void gemm_skinny_kernel(SkinnyArgs a
     const int64_t off = (int64_t)ks * 64;
     const u32x4 xf = mrow ? ld16(xp + off) : zero;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_g<Tag>(ld16(wp[nb] + off), xf, acc[nb]);
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_g<Tag>(NT ? ld16_nt(wp[nb] + off) : ld16(wp[nb] + off), xf, acc[nb]);
   }
   // acc[nb][r] = partial of out[m = r16][n0 + 16 nb + 4q + r]; sum the waves in wave order
 #pragma unroll
@@ -113,10 +118,14 @@ __global__ __launch_bounds__(kSkWaves * 64) void gemm_skinny_kernel(SkinnyArgs a
   }
 }
 
+static int g_skinny_nt = 0;     // sp_debug_set("skinny_nt", 0 / 1): A/B switch of the non-temporal weight loads
+void set_skinny_nt(int v) { g_skinny_nt = v; }
+
 template <typename Tag>
 static void launch_skinny(const SkinnyArgs& a, hipStream_t st) {
   const dim3 block(kSkWaves * 64);
-  gemm_skinny_kernel<Tag, 1, 8><<<dim3((a.N + 15) / 16), block, 0, st>>>(a);
+  if (g_skinny_nt) gemm_skinny_kernel<Tag, 1, 8, true><<<dim3((a.N + 15) / 16), block, 0, st>>>(a);
+  else gemm_skinny_kernel<Tag, 1, 8, false><<<dim3((a.N + 15) / 16), block, 0, st>>>(a);
 }
 
 }  // namespace sp
