@@ -50,8 +50,9 @@ def forward(shape: LlamaShape, w: Dict[str, torch.Tensor], kv: OracleKV, *, mode
             seq_lens: torch.Tensor, out_cache_loc: torch.Tensor,
             extend_seq_lens: Optional[torch.Tensor] = None,
             extend_start_loc: Optional[torch.Tensor] = None,
-            cos_sin_cache: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """One forward pass; returns next-token logits [bs, vocab] fp32.  ``mode`` is "extend" or
+            cos_sin_cache: Optional[torch.Tensor] = None, all_hidden: bool = False) -> torch.Tensor:
+    """One forward pass; returns next-token logits [bs, vocab] fp32 (``all_hidden``: the final-norm hidden states
+    of EVERY token instead - what the logits processor is handed, llama.py forward -> logits_processor.py:148).  ``mode`` is "extend" or
     "decode".  ``kv.req_to_token`` must already hold this step's slots (the scheduler writes
     them before the forward: schedule_batch.py:1046-1054, 1306-1308)."""
     dtype = w["model.embed_tokens.weight"].dtype
@@ -86,6 +87,8 @@ def forward(shape: LlamaShape, w: Dict[str, torch.Tensor], kv: OracleKV, *, mode
         gu = torch.nn.functional.linear(h, w[p + "mlp.gate_up_proj.weight"])
         h = torch.nn.functional.linear(ops.silu_and_mul(gu), w[p + "mlp.down_proj.weight"])
     h, _ = ops.rmsnorm(h, w["model.norm.weight"], shape.rms_eps, residual)
+    if all_hidden:
+        return h
     if mode == "extend":
         last = torch.cumsum(extend_seq_lens.long(), 0) - 1
         h = h[last]

@@ -2,9 +2,9 @@
 
 Mirrors model_executor/forward_info.py:18-66 (ForwardMode), 69-81 (CaptureHiddenMode), 84-287
 (ForwardBatch + init_new), 400-471 (positions) and scheduler/schedule_batch.py:1481-1543
-(ModelWorkerBatch) for the fields the attention hot path reads.  Fields that only feed
-out-of-scope subsystems (logprobs, DP attention, speculative decoding, toppings, mrope) are
-kept as inert attributes so call sites written against the reference still construct them."""
+(ModelWorkerBatch) for the fields the attention hot path reads, and the log-prob request fields
+the logits processor / sampler read.  Fields that only feed out-of-scope subsystems (DP attention,
+speculative decoding, toppings, mrope) are kept as inert attributes so call sites written against the reference still construct them."""
 import threading
 from dataclasses import dataclass
 from enum import IntEnum, auto
@@ -168,7 +168,9 @@ class ForwardBatch:
             token_to_kv_pool=model_runner.token_to_kv_pool, attn_backend=model_runner.attn_backend,
             spec_algorithm=batch.spec_algorithm, spec_info=batch.spec_info,
             capture_hidden_mode=batch.capture_hidden_mode, input_embeds=batch.input_embeds,
-            encoder_states=batch.encoder_states)
+            encoder_states=batch.encoder_states,
+            extend_input_logprob_token_ids_gpu=(None if batch.extend_input_logprob_token_ids is None else
+                                                batch.extend_input_logprob_token_ids.to(device, non_blocking=True)))
         if ret.forward_mode.is_idle():
             ret.positions = torch.empty((0,), device=device)
             return ret

@@ -45,6 +45,13 @@ class LogitsProcessorOutput:
         self.shard_logits = shard_logits
         self.vocab_size = vocab_size
         self.shard_offset = shard_offset
+        # prefill-only part (logits_processor.py:40-50): logprobs of the INPUT tokens, filled when the batch asks for
+        # them (ForwardBatch.return_logprob with extend_logprob_start_lens short of the extend lengths)
+        self.input_token_logprobs: Optional[torch.Tensor] = None        # [#input tokens]
+        self.input_top_logprobs_val = None                              # per request: [#tokens][k]
+        self.input_top_logprobs_idx = None
+        self.input_token_ids_logprobs_val = None                        # per request: [#tokens][n]
+        self.input_token_ids_logprobs_idx = None
 
     def gather_full_logits(self) -> torch.Tensor:
         """[bs, vocab] fp32 (logits_processor.py:362-369).  Collective under TP: call on every rank."""
@@ -240,24 +247,102 @@ class ParallelLMHead(VocabParallelEmbedding):
 
 
 class LogitsProcessor(nn.Module):
-    """logits_processor.py:140-376 for the greedy/throughput path: keep the last token of every
-    sequence on extend, matmul with the (vocab-sharded) head.  The all-gather / slice / fp32 step of
-    _get_logits (362-369) is deferred to LogitsProcessorOutput (a greedy batch never needs it)."""
+    """logits_processor.py:140-376.  Decode and extend-without-input-logprobs keep only the last token of every
+    sequence, matmul with the (vocab-sharded) head, and defer the all-gather / slice / fp32 step of _get_logits
+    (362-369) to LogitsProcessorOutput (a greedy batch never needs it).  When the batch asks for the logprobs of its
+    INPUT tokens (179-340: return_logprob with extend_logprob_start_lens short of the extend lengths) the hidden states
+    of every position from the request's logprob start on are projected, the full logits are gathered (an explicit
+    collective: the decision depends on host-side batch fields only, so every rank takes it) and the input-token /
+    top-k / requested-id logprobs are cut out exactly as the reference does."""
 
     def __init__(self, config):
         super().__init__()
         self.config = config
         self.do_tensor_parallel_all_gather = get_tensor_model_parallel_world_size() > 1
 
+    @staticmethod
+    def input_logprob_plan(extend_seq_lens_cpu, extend_logprob_start_lens_cpu):
+        """logits_processor.py:206-246 (host side): row ranges of hidden_states to project, the row of each request's
+        SAMPLED token among them, the rows that carry an input logprob, and the pruned lengths."""
+        spans, sample_indices, input_logprob_indices, pruned_lens = [], [], [], []
+        pt, sample_pt, input_pt = 0, -1, 0
+        for start_len, extend_len in zip(extend_logprob_start_lens_cpu, extend_seq_lens_cpu):
+            # chunked prefill may ask for no input logprob of this chunk at all: one token is still sampled
+            first = start_len - 1 if extend_len == start_len else start_len
+            assert extend_len > first
+            spans.append((pt + first, pt + extend_len))
+            pt += extend_len
+            sample_pt += extend_len - first
+            sample_indices.append(sample_pt)
+            input_logprob_indices.extend(input_pt + i for i in range(extend_len - start_len))
+            input_pt += extend_len - first
+            pruned_lens.append(extend_len - start_len)
+        return spans, sample_indices, input_logprob_indices, pruned_lens
+
+    def _full_logits(self, states, lm_head):
+        """_get_logits, logits_processor.py:344-376: matmul, all-gather over the TP group, cut the padding, fp32"""
+        logits = _native.linear(states.to(lm_head.weight.dtype), lm_head.weight)
+        if self.do_tensor_parallel_all_gather:
+            logits = tensor_model_parallel_all_gather(logits)
+        return logits[:, : self.config.vocab_size].float()
+
     def forward(self, input_ids, hidden_states, lm_head, forward_batch: ForwardBatch):
-        if forward_batch.forward_mode.is_decode_or_idle():
-            pruned = hidden_states
+        fb = forward_batch
+        want_input = (fb.forward_mode.is_extend() and fb.return_logprob and fb.extend_logprob_start_lens_cpu is not None
+                      and any(e - s > 0 for e, s in zip(fb.extend_seq_lens_cpu, fb.extend_logprob_start_lens_cpu)))
+        if not want_input:
+            if fb.forward_mode.is_decode_or_idle():
+                pruned = hidden_states
+            else:
+                last_index = torch.cumsum(fb.extend_seq_lens, dim=0) - 1
+                pruned = hidden_states[last_index]
+            logits = _native.linear(pruned.to(lm_head.weight.dtype), lm_head.weight)
+            return LogitsProcessorOutput(shard_logits=logits, vocab_size=self.config.vocab_size,
+                                         shard_offset=getattr(lm_head, "vocab_start_index", 0))
+        spans, sample_idx, input_idx, pruned_lens = self.input_logprob_plan(fb.extend_seq_lens_cpu,
+                                                                            fb.extend_logprob_start_lens_cpu)
+        dev = hidden_states.device
+        pruned = torch.cat([hidden_states[a:b] for a, b in spans])
+        logits = self._full_logits(pruned, lm_head)
+        out = LogitsProcessorOutput(next_token_logits=logits[torch.tensor(sample_idx, device=dev, dtype=torch.int64)],
+                                    vocab_size=self.config.vocab_size)
+        input_logits = logits[torch.tensor(input_idx, device=dev, dtype=torch.int64)]
+        del logits
+        # logits_processor.py:292-306, 432-460: optional temperature scaling / top-p normalisation of the input logprobs
+        info = fb.sampling_info
+        lens = torch.tensor(pruned_lens, device=dev)
+        if getattr(fb, "temp_scaled_logprobs", False) and info is not None:
+            input_logits = input_logits / torch.repeat_interleave(info.temperatures.view(-1), lens).view(-1, 1)
+        if getattr(fb, "top_p_normalized_logprobs", False) and info is not None and bool((info.top_ps != 1.0).any()):
+            from .sampler import top_p_normalize_probs
+            probs = torch.softmax(input_logits, dim=-1)
+            logprobs = torch.log(top_p_normalize_probs(probs, torch.repeat_interleave(info.top_ps, lens)))
         else:
-            last_index = torch.cumsum(forward_batch.extend_seq_lens, dim=0) - 1
-            pruned = hidden_states[last_index]
-        logits = _native.linear(pruned.to(lm_head.weight.dtype), lm_head.weight)
-        return LogitsProcessorOutput(shard_logits=logits, vocab_size=self.config.vocab_size,
-                                     shard_offset=getattr(lm_head, "vocab_start_index", 0))
+            logprobs = torch.nn.functional.log_softmax(input_logits, dim=-1)
+        if fb.top_logprobs_nums and any(k > 0 for k in fb.top_logprobs_nums):
+            # get_top_logprobs, 378-405: one top-k over all rows, cut per request
+            top = logprobs.topk(max(fb.top_logprobs_nums), dim=1)
+            vals, idxs = top.values.tolist(), top.indices.tolist()
+            out.input_top_logprobs_val, out.input_top_logprobs_idx, pt = [], [], 0
+            for k, n in zip(fb.top_logprobs_nums, pruned_lens):
+                out.input_top_logprobs_val.append([vals[pt + j][:k] for j in range(max(n, 0))])
+                out.input_top_logprobs_idx.append([idxs[pt + j][:k] for j in range(max(n, 0))])
+                pt += max(n, 0)
+        if fb.token_ids_logprobs and any(t is not None for t in fb.token_ids_logprobs):
+            # get_token_ids_logprobs, 407-430
+            out.input_token_ids_logprobs_val, out.input_token_ids_logprobs_idx, pt = [], [], 0
+            for ids, n in zip(fb.token_ids_logprobs, pruned_lens):
+                if n <= 0 or ids is None:
+                    out.input_token_ids_logprobs_val.append([])
+                    out.input_token_ids_logprobs_idx.append([])
+                    pt += max(n, 0) if ids is None else 0
+                    continue
+                out.input_token_ids_logprobs_val.append([logprobs[pt + j, ids].tolist() for j in range(n)])
+                out.input_token_ids_logprobs_idx.append([ids for _ in range(n)])
+                pt += n
+        out.input_token_logprobs = logprobs[torch.arange(logprobs.shape[0], device=dev),
+                                            fb.extend_input_logprob_token_ids_gpu]
+        return out
 
 
 # --------------------------------------------------------------------------- decoder

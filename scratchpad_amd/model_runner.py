@@ -257,8 +257,20 @@ class ModelRunner:
         greedy (sampler.py:63-67)."""
         info = forward_batch.sampling_info
         if info is None:
-            return logits_output.greedy_token_ids()
-        return self.sampler(logits_output, info)
+            if not forward_batch.return_logprob:
+                return logits_output.greedy_token_ids()
+            info = _ALL_GREEDY
+        return self.sampler(logits_output, info, forward_batch.return_logprob, forward_batch.top_logprobs_nums,
+                            forward_batch.token_ids_logprobs)
+
+
+class _AllGreedy:
+    """what the sampler reads of a SamplingBatchInfo when no request of the batch carries sampling parameters"""
+    is_all_greedy = True
+    grammars = None
+
+
+_ALL_GREEDY = _AllGreedy()
 
 
 class HipGraphRunner:

@@ -41,6 +41,13 @@ class Req:
     num_image_tokens: Optional[int] = None
     # MultimodalInputs of the request (mm_items with pixel_values / aspect_ratio_id / aspect_ratio_mask)
     multimodal_inputs: object = None
+    # log-prob requests (schedule_batch.py:296-298, 369-387): logprob_start_len is an index into origin_input_ids;
+    # extend_logprob_start_len is the same, relative to this round's extend part (set by prepare_for_extend)
+    return_logprob: bool = False
+    logprob_start_len: int = 0
+    top_logprobs_num: int = 0
+    token_ids_logprob: Optional[List[int]] = None
+    extend_logprob_start_len: int = 0
 
     @property
     def fill_ids(self) -> List[int]:
@@ -62,8 +69,12 @@ class Req:
         self.extend_input_len_override = None
         ids = self.origin_input_ids + self.output_ids
         if tree_cache is not None:
-            self.prefix_indices, self.last_node = tree_cache.match_prefix(
-                rid=self.rid, key=ids[:max(len(ids) - 1, 0)])
+            # adjust_max_prefix_ids, schedule_batch.py:494-510: a cached prefix may not swallow positions whose
+            # input logprobs are asked for (they need this round's hidden states)
+            limit = len(ids) - 1
+            if self.return_logprob:
+                limit = min(limit, self.logprob_start_len)
+            self.prefix_indices, self.last_node = tree_cache.match_prefix(rid=self.rid, key=ids[:max(limit, 0)])
 
     def reset_for_retract(self):
         """schedule_batch.py:573-584"""
@@ -71,6 +82,7 @@ class Req:
         self.last_node = None
         self.fill_ids_override = None
         self.req_pool_idx = None
+        self.extend_logprob_start_len = 0
         self.is_retracted = True
 
     @property
@@ -112,7 +124,8 @@ class ScheduleBatch:
         self.prefix_lens = self.extend_lens = None
         # per-batch flags / per-request logprob requests the reference keeps on the batch
         # (schedule_batch.py:618-640): carried through merge_batch / mix_with_running as it does
-        self.return_logprob = False
+        self.return_logprob = any(r.return_logprob for r in reqs)          # init_new, schedule_batch.py:693
+        self.extend_input_logprob_token_ids: Optional[torch.Tensor] = None
         self.top_logprobs_nums: Optional[List[int]] = None
         self.token_ids_logprobs: Optional[List[Optional[List[int]]]] = None
         self.extend_logprob_start_lens: List[int] = []
@@ -156,11 +169,30 @@ class ScheduleBatch:
         seq_lens_tensor = torch.tensor(seq_lens, dtype=torch.int64).to(dev, non_blocking=True)
         prefix_lens_tensor = torch.tensor(prefix_lens, dtype=torch.int64, device=dev)
         extend_lens_tensor = seq_lens_tensor - prefix_lens_tensor
+        logprob_token_ids: List[int] = []
         for i, req in enumerate(reqs):
             req.req_pool_idx = req_pool_indices[i]
             if prefix_lens[i] > 0:
                 self.req_to_token_pool.write((req.req_pool_idx, slice(0, prefix_lens[i])),
                                              req.prefix_indices.to(torch.int32))
+            # schedule_batch.py:952-998: the request's logprob start relative to this round's extend part, and the
+            # ids whose logprob each kept position is asked for (the NEXT input token; zero-padded past the prompt)
+            if req.logprob_start_len >= prefix_lens[i]:
+                req.extend_logprob_start_len = min(req.logprob_start_len - prefix_lens[i], req.extend_input_len,
+                                                   len(req.origin_input_ids) + len(req.output_ids) - 1)
+            else:
+                req.extend_logprob_start_len = 0
+            if self.return_logprob:
+                first = max(prefix_lens[i], req.logprob_start_len)
+                ids = req.origin_input_ids[first + 1:seq_lens[i] + 1]
+                logprob_token_ids += ids + [0] * (req.extend_input_len - req.extend_logprob_start_len - len(ids))
+        if self.return_logprob:
+            self.top_logprobs_nums = [r.top_logprobs_num for r in reqs]
+            self.token_ids_logprobs = [r.token_ids_logprob for r in reqs]
+            self.extend_input_logprob_token_ids = torch.tensor(logprob_token_ids, dtype=torch.int64)
+        else:
+            self.extend_input_logprob_token_ids = None
+        self.extend_logprob_start_lens = [r.extend_logprob_start_len for r in reqs]
         out_cache_loc = self.alloc_token_slots(extend_num_tokens)
         self.input_ids = input_ids_tensor
         self.req_pool_indices = req_pool_indices_tensor
@@ -321,6 +353,13 @@ class ScheduleBatch:
         self.seq_lens_sum = int(self.seq_lens.sum().item())
         if self.output_ids is not None:
             self.output_ids = self.output_ids[keep]
+        was_logprob = self.return_logprob
+        self.return_logprob = any(r.return_logprob for r in self.reqs)
+        if self.return_logprob and was_logprob:
+            self.top_logprobs_nums = [self.top_logprobs_nums[i] for i in keep_indices]
+            self.token_ids_logprobs = [self.token_ids_logprobs[i] for i in keep_indices]
+        else:
+            self.top_logprobs_nums = self.token_ids_logprobs = None
         if self.sampling_info is not None:
             self.sampling_info.filter_batch(keep_indices, keep)
 
@@ -382,4 +421,8 @@ class ScheduleBatch:
             encoder_cached=self.encoder_cached, encoder_lens=self.encoder_lens,
             encoder_lens_cpu=self.encoder_lens_cpu, encoder_out_cache_loc=self.encoder_out_cache_loc,
             multimodal_inputs=[r.multimodal_inputs for r in self.reqs],
-            sampling_info=self.sampling_info)
+            sampling_info=self.sampling_info, return_logprob=self.return_logprob,
+            top_logprobs_nums=self.top_logprobs_nums, token_ids_logprobs=self.token_ids_logprobs,
+            extend_logprob_start_lens=(None if self.forward_mode.is_decode_or_idle() else self.extend_logprob_start_lens),
+            extend_input_logprob_token_ids=(None if self.forward_mode.is_decode_or_idle()
+                                            else self.extend_input_logprob_token_ids))

@@ -901,11 +901,99 @@ def gen_mllama_vision():
     _save("mllama_vision", **out)
 
 
+def gen_input_logprobs():
+    """The reference's input-logprob path: ScheduleBatch.prepare_for_extend (schedule_batch.py:952-1040: relative
+    logprob start, ids whose logprob is reported) for requests with / without cached prefixes and chunked prompts, then
+    LogitsProcessor.forward (logits_processor.py:148-340) with LogitsMetadata.from_forward_batch on seeded hidden
+    states and an LM head: sampled logits, input token logprobs, top-k and requested-id logprobs."""
+    import types
+    from scratchpad.distributed import init_distributed_environment, initialize_model_parallel
+    from scratchpad.distributed import parallel_state as ps
+    from scratchpad.memory.pool import MHATokenToKVPool, ReqToTokenPool, TokenToKVPoolAllocator
+    from scratchpad.model_executor.forward_info import CaptureHiddenMode, ForwardBatch, ForwardMode
+    from scratchpad.nn.layers.logits_processor import LogitsProcessor
+    from scratchpad.sampling.sampling_params import SamplingParams
+    from scratchpad.scheduler import schedule_batch as SB
+
+    if ps._WORLD is None:
+        init_distributed_environment(world_size=1, rank=0, distributed_init_method="tcp://127.0.0.1:29519",
+                                     local_rank=0, backend="gloo")
+        initialize_model_parallel(1)
+    g = torch.Generator().manual_seed(131)
+    vocab, vocab_padded, hidden = 200, 256, 64
+    head = _grid(torch.randn(vocab_padded, hidden, generator=g) * 0.25, step=256.0)
+    proc = LogitsProcessor(types.SimpleNamespace(vocab_size=vocab))
+    sp = SamplingParams(max_new_tokens=4)
+    # per case: list of (prompt length, cached prefix length, chunk end or None, logprob_start_len (-1: the default
+    # "last token only"), top_logprobs_num, token_ids_logprob)
+    cases = [
+        [(6, 0, None, 0, 2, None), (5, 0, None, 2, 0, [7, 3, 150]), (4, 0, None, -1, 3, None)],
+        [(9, 4, None, 0, 1, None), (7, 2, None, 5, 4, [0, 199]), (3, 0, None, 0, 0, None), (8, 0, 5, 1, 2, [11])],
+        [(5, 0, None, -1, 0, None), (6, 3, None, -1, 2, None)],            # nobody wants input logprobs
+        [(1, 0, None, 0, 5, [4, 5]), (12, 0, 12, 11, 1, None), (10, 6, 8, 2, 3, None)],
+    ]
+    out = {"num_cases": np.int64(len(cases)), "vocab": np.int64(vocab), "head": head}
+    for ci, case in enumerate(cases):
+        kv = MHATokenToKVPool(256, 1, torch.float32, 1, 8, 1, "cpu", False)
+        alloc = TokenToKVPoolAllocator(256, torch.float32, "cpu", kv)
+        r2t = ReqToTokenPool(8, 64, "cpu", False)
+        reqs = []
+        for i, (n, pre, chunk_end, start, k, ids) in enumerate(case):
+            prompt = torch.randint(1, vocab, (n,), generator=g).tolist()
+            r = SB.Req(str(i), "", prompt, sp, return_logprob=True, top_logprobs_num=k, token_ids_logprob=ids)
+            r.logprob_start_len = n - 1 if start < 0 else start
+            r.fill_ids = list(prompt) if chunk_end is None else list(prompt[:chunk_end])
+            r.prefix_indices = alloc.alloc(pre) if pre else []
+            r.extend_input_len = len(r.fill_ids) - len(r.prefix_indices)
+            reqs.append(r)
+            out[f"c{ci}_r{i}_prompt"] = np.array(prompt, np.int64)
+            out[f"c{ci}_r{i}_ids"] = np.array([] if ids is None else ids, np.int64)
+        mc = types.SimpleNamespace(is_encoder_decoder=False, vocab_size=vocab)
+        b = SB.ScheduleBatch.init_new(reqs, r2t, alloc, None, mc, False, None, False)
+        b.prepare_for_extend()
+        ext = list(b.extend_lens)
+        hidden_states = _randn(sum(ext), hidden, generator=g)
+        fb = ForwardBatch(
+            forward_mode=ForwardMode.EXTEND, batch_size=len(reqs), input_ids=b.input_ids,
+            req_pool_indices=b.req_pool_indices, seq_lens=b.seq_lens, out_cache_loc=b.out_cache_loc,
+            seq_lens_sum=b.seq_lens_sum, extend_num_tokens=sum(ext),
+            extend_seq_lens=torch.tensor(ext, dtype=torch.int32), extend_seq_lens_cpu=ext,
+            extend_prefix_lens_cpu=list(b.prefix_lens), return_logprob=True, top_logprobs_nums=b.top_logprobs_nums,
+            token_ids_logprobs=b.token_ids_logprobs, extend_logprob_start_lens_cpu=b.extend_logprob_start_lens,
+            extend_input_logprob_token_ids_gpu=b.extend_input_logprob_token_ids,
+            capture_hidden_mode=CaptureHiddenMode.NULL)
+        res = proc.forward(b.input_ids, hidden_states, types.SimpleNamespace(weight=head), fb)
+        out.update({
+            f"c{ci}_spec": np.array([[n, pre, -1 if ce is None else ce, st, k] for n, pre, ce, st, k, _ in case], np.int64),
+            f"c{ci}_has_ids": np.array([ids is not None for *_, ids in case]),
+            f"c{ci}_extend_lens": np.array(ext, np.int64), f"c{ci}_prefix_lens": np.array(b.prefix_lens, np.int64),
+            f"c{ci}_extend_logprob_start_lens": np.array(b.extend_logprob_start_lens, np.int64),
+            f"c{ci}_extend_input_logprob_token_ids": b.extend_input_logprob_token_ids.to(torch.int64),
+            f"c{ci}_hidden": hidden_states, f"c{ci}_next_token_logits": res.next_token_logits,
+            f"c{ci}_has_input": np.bool_(res.input_token_logprobs is not None),
+        })
+        if res.input_token_logprobs is not None:
+            out[f"c{ci}_input_token_logprobs"] = res.input_token_logprobs
+        for field in ("input_top_logprobs_val", "input_top_logprobs_idx", "input_token_ids_logprobs_val",
+                      "input_token_ids_logprobs_idx"):
+            v = getattr(res, field)
+            out[f"c{ci}_has_{field}"] = np.bool_(v is not None)
+            if v is not None:                       # ragged [request][position][k]: flattened + per-request shape
+                for i, per_req in enumerate(v):
+                    if field.startswith("input_token_ids") and case[i][5] is None:
+                        continue                     # the reference indexes with None there: not a defined output
+                    flat = [x for row in per_req for x in row]
+                    dt = np.int64 if field.endswith("idx") else np.float32
+                    out[f"c{ci}_{field}_r{i}"] = np.array(flat, dt)
+                    out[f"c{ci}_{field}_r{i}_rows"] = np.int64(len(per_req))
+    _save("input_logprobs", **out)
+
+
 GENERATORS = {
     "rmsnorm": gen_rmsnorm, "silu_mul": gen_silu_mul, "rotary": gen_rotary, "kv_pool": gen_kv_pool,
     "positions": gen_positions, "decode_attention": gen_decode, "extend_attention": gen_extend,
     "tiny_llama": gen_tiny_llama, "tiny_mllama": gen_tiny_mllama, "radix_cache": gen_radix_cache,
-    "sampling": gen_sampling, "mllama_vision": gen_mllama_vision,
+    "sampling": gen_sampling, "mllama_vision": gen_mllama_vision, "input_logprobs": gen_input_logprobs,
 }
 
 if __name__ == "__main__":

@@ -136,6 +136,21 @@ def _sharded_layers(rank, world):
     assert torch.allclose(full, want, atol=1e-4)
     with pytest.raises(RuntimeError, match="persistent graph output buffer"):
         out.rows(1)                        # a buffer object that cached full logits must not be re-sliced
+    # prompt logprobs under TP (logits_processor.py:206-340): the projection of every kept position is gathered
+    # across the vocabulary shards inside the processor (the decision depends on host-side batch fields only)
+    from oracle import logprobs as olp
+    fb.extend_seq_lens_cpu, fb.return_logprob = [2, 3], True
+    fb.extend_logprob_start_lens_cpu, fb.top_logprobs_nums, fb.token_ids_logprobs = [0, 1], [2, 0], [None, [3, 70]]
+    fb.extend_input_logprob_token_ids_gpu = torch.tensor([63, 0, 99, 0])
+    out = llama.LogitsProcessor(Cfg())(ids, x, emb, fb)
+    ref = olp.input_logprobs(x, full_emb, vocab, [2, 3], [0, 1], fb.extend_input_logprob_token_ids_gpu, [2, 0],
+                             [None, [3, 70]])
+    assert torch.allclose(out.next_token_logits, want, atol=1e-4)
+    assert torch.allclose(out.input_token_logprobs, ref["input_token_logprobs"], atol=1e-4)
+    assert out.input_top_logprobs_idx == ref["input_top_logprobs_idx"]
+    assert out.input_token_ids_logprobs_idx == [[], [[3, 70], [3, 70]]]
+    assert torch.allclose(torch.tensor(out.input_token_ids_logprobs_val[1]),
+                          torch.tensor(ref["input_token_ids_logprobs_val"][1]), atol=1e-4)
 
 
 def _kv_head_replication(rank, world):
