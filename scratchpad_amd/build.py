@@ -23,7 +23,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hi
 # relies on NaN propagation (masked scores are -inf, never NaN)
 # allreduce.hip: its fused all-reduce + add + RMSNorm kernel reproduces elementwise.hip's norm bit for bit
 PER_FILE_FLAGS = {"elementwise.hip": ["-ffp-contract=off"], "allreduce.hip": ["-ffp-contract=off"],
-                  "extend_mfma.hip": ["-fno-honor-nans"]}
+                  "extend_mfma.hip": ["-fno-honor-nans"],
+                  # extend_w64.hip: every filler of its hand-placed MFMA gaps is a single instruction: no SLP packing
+                  # of adjacent f32 adds / multiplies into v_pk_* (MI355X_MICROARCH.md: an anti-lever beside MFMAs)
+                  # of adjacent f32 adds / multiplies into v_pk_* (MI355X_MICROARCH.md: an anti-lever beside MFMAs); and its
+                  # accumulation registers belong to the assembly text: the compiler must never park a spill there
+                  "extend_w64.hip": ["-fno-honor-nans", "-fno-slp-vectorize", "-std=c++20",
+                                     "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}
 
 
 def _newer(target, deps):

@@ -21,6 +21,12 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
                     float out_scale, int causal, int window_left, int max_extend_len, const int32_t* plan,
                     int plan_items, int num_tokens, int dtype, int kv8, hipStream_t st);
 
+// extend_w64.hip: the 4-wave x 64-row form of the same kernel (16-bit, D = 128, plain attention, query-head group a
+// multiple of 4); returns 1 when it took the launch
+struct ExtendArgs;
+int try_extend_w64(const ExtendArgs& a, int head_dim, int dtype, int max_extend_len, hipStream_t st);
+void set_extend_w64(int v);
+
 // test / tuning hooks behind sp_debug_set
 void set_extend_defer_x10(int tenths);
 void set_extend_dma(int v);   // 0: register-staged K/V tiles for every shape (the LDS-DMA ring is the default where it applies)

@@ -14,12 +14,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def load_native(libfile, tag):
+def load_native(libspec, tag):
+    """libspec: FILE[@key=value[,key=value...]] - the switches go through sp_debug_set after loading.  Two specs of
+    the same FILE share the library's globals (one dlopen handle): give the second one a copy of the file."""
+    libfile, _, switches = libspec.partition("@")
     spec = importlib.util.spec_from_file_location(f"sp_native_{tag}", os.path.join(ROOT, "scratchpad_amd", "_native.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     m._LIB_PATH = os.path.join(ROOT, "scratchpad_amd", "lib", libfile)
     m.load()
+    for kv in filter(None, switches.split(",")):
+        k, v = kv.split("=")
+        m.debug_set(k, int(v))
     return m
 
 
