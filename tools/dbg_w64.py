@@ -42,6 +42,10 @@ def case(nat_a, nat_b, lens, prefix, seed=0):
                              int(seq.max()), ws, plan=plan)
         torch.cuda.synchronize()
         outs.append(o.float())
+    nan_rows = torch.isnan(outs[1]).any(dim=2).any(dim=1).nonzero().flatten().tolist()
+    if nan_rows:
+        nan_heads = torch.isnan(outs[1]).any(dim=2).any(dim=0).nonzero().flatten().tolist()
+        print(f"  NaN in {len(nan_rows)} of {T} rows: {nan_rows[:24]}...; heads {nan_heads[:12]}; total NaN {int(torch.isnan(outs[1]).sum())} of {outs[1].numel()}")
     d = (outs[1] - outs[0]).abs()
     print(f"lens={lens} prefix={prefix}: max diff {d.max().item():.3e} finite={bool(torch.isfinite(outs[1]).all())}", flush=True)
     if d.max() > 2e-2:
