@@ -115,7 +115,8 @@ def _check(status: int, what: str):
 
 
 def debug_set(key: str, value: int) -> None:
-    """Test / tuning switch of the library (sp_debug_set): "decode_kernel", "extend_defer_x10", "extend_dma" (0 = register-staged tiles)."""
+    """Test / tuning switch of the library (sp_debug_set): "decode_kernel", "extend_defer_x10", "extend_dma" (0 = register-staged tiles),
+    "extend_w64" (0 never / 1 where it pays (default) / 2 wherever it applies: the 4-wave x 64-row extend kernel)."""
     _check(load().sp_debug_set(key.encode(), int(value)), f"sp_debug_set({key})")
 
 

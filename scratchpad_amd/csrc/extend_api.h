@@ -18,13 +18,13 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
                     int idx64, const int32_t* extend_seq_lens, const int32_t* extend_start_loc,
                     int batch_size, int num_q_heads, int num_kv_heads, int head_dim, int64_t q_stride,
                     int64_t out_stride, int64_t kv_buffer_stride, float sm_scale, float logit_cap,
-                    float out_scale, int causal, int window_left, int max_extend_len, const int32_t* plan,
-                    int plan_items, int num_tokens, int dtype, int kv8, hipStream_t st);
+                    float out_scale, int causal, int window_left, int max_extend_len, int64_t max_seq_len,
+                    const int32_t* plan, int plan_items, int num_tokens, int dtype, int kv8, hipStream_t st);
 
 // extend_w64.hip: the 4-wave x 64-row form of the same kernel (16-bit, D = 128, plain attention, query-head group a
-// multiple of 4); returns 1 when it took the launch
+// multiple of 4); returns 1 when it took the launch.  set_extend_w64: 0 never, 1 where it pays (default), 2 always.
 struct ExtendArgs;
-int try_extend_w64(const ExtendArgs& a, int head_dim, int dtype, int max_extend_len, hipStream_t st);
+int try_extend_w64(const ExtendArgs& a, int head_dim, int dtype, int max_extend_len, int64_t max_seq_len, hipStream_t st);
 void set_extend_w64(int v);
 
 // test / tuning hooks behind sp_debug_set

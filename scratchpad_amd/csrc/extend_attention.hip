@@ -212,7 +212,7 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
                                    req_pool_indices, seq_lens, kv_start, idx64, extend_seq_lens,
                                    extend_start_loc, batch_size, num_q_heads, num_kv_heads, head_dim,
                                    q_stride, out_stride, kv_buffer_stride, sm_scale, logit_cap, v_scale,
-                                   causal, window_left, max_extend_len, plan,
+                                   causal, window_left, max_extend_len, max_seq_len, plan,
                                    (int)std::min<int64_t>(extend_plan_items(num_tokens, batch_size,
                                        extend_block_rows(num_q_heads, num_kv_heads)), 0x7fffffff),
                                    (int)num_tokens, dtype, kv8 ? 1 : 0, st);

@@ -721,8 +721,8 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
                     int idx64, const int32_t* extend_seq_lens, const int32_t* extend_start_loc,
                     int batch_size, int num_q_heads, int num_kv_heads, int head_dim, int64_t q_stride,
                     int64_t out_stride, int64_t kv_buffer_stride, float sm_scale, float logit_cap,
-                    float out_scale, int causal, int window_left, int max_extend_len, const int32_t* plan,
-                    int plan_items, int num_tokens, int dtype, int kv8, hipStream_t st) {
+                    float out_scale, int causal, int window_left, int max_extend_len, int64_t max_seq_len,
+                    const int32_t* plan, int plan_items, int num_tokens, int dtype, int kv8, hipStream_t st) {
   if (dtype != SP_F16 && dtype != SP_BF16) return SP_ERR_UNSUPPORTED;
   if (head_dim != 64 && head_dim != 128) return SP_ERR_UNSUPPORTED;
   if (batch_size > 65535 || num_q_heads > 65535) return SP_ERR_UNSUPPORTED;   // grid.z, grid.y
@@ -743,7 +743,7 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
   if (plan && (plan_items <= 0 || plan_items > 65535)) a.plan = nullptr;   // grid.y limit: unplanned launch
   const int G = num_q_heads / num_kv_heads;
   if (max_extend_len <= 0) return SP_OK;
-  if (try_extend_w64(a, head_dim, dtype, max_extend_len, st)) {
+  if (try_extend_w64(a, head_dim, dtype, max_extend_len, max_seq_len, st)) {
     SP_LAUNCH_CHECK();
     return SP_OK;
   }

@@ -45,3 +45,73 @@ def test_tile_loop_keeps_its_dma_in_flight(dma_kernel_asm):
     assert len(counted) >= 4, "the hand-counted wait of every tile step survives"
     assert not any("scratch_" in l for l in loop[:len(loop) // 2]), "no spills in the unrolled main loop"
     assert "ds_read_b64_tr_b16" in dma_kernel_asm and "v_mfma_f32_32x32x16_bf16" in dma_kernel_asm
+
+
+# ----------------------------------------------------------------------------------------------- extend_w64.hip
+# The 4 x 64-row kernel keeps O^T and the Q fragments in accumulation registers that only its asm text names.  What the
+# parity tests cannot see until it is too late: the compiler parking a value of its own in one of those registers (it
+# does so as soon as the architectural ones run short), a scratch access in the tile loop (its wait drains the DMA
+# ring), the generated bodies drifting away from their generator.
+W64_FLAGS = ["-fno-honor-nans", "-fno-slp-vectorize", "-std=c++20", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]
+
+
+def test_w64_generated_bodies_are_the_generators_output():
+    r = subprocess.run(["python3", os.path.join(ROOT, "tools", "gen_extend_w64.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_w64_build_flags_are_the_tested_ones():
+    from scratchpad_amd import build
+    assert build.PER_FILE_FLAGS["extend_w64.hip"] == W64_FLAGS
+
+
+@pytest.fixture(scope="module")
+def w64_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "extend_w64.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3"] + W64_FLAGS + [
+        "--cuda-device-only", "-S", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "scratchpad_amd", "csrc"),
+        os.path.join(ROOT, "scratchpad_amd", "csrc", "extend_w64.hip"), "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return open(out).read()
+
+
+@pytest.mark.parametrize("tag", ["8bf16_tag", "7f16_tag"])
+def test_w64_registers_belong_to_whom_they_should(w64_asm, tag):
+    name = f"_ZN2sp17extend_w64_kernelINS_{tag}EEEvNS_10ExtendArgsE"
+    m = re.search(rf"^{name}:[^\n]*\n(.*?)^\.Lfunc_end", w64_asm, re.S | re.M)
+    assert m, "kernel not found"
+    body = m.group(1)
+    meta = re.search(rf"\.name:\s+{name}\n(.*?)\.wavefront_size", w64_asm, re.S)
+    assert meta
+    fields = dict(re.findall(r"\.(\w+):\s+(\d+)", meta.group(1)))
+    agpr = re.search(rf"\.agpr_count:\s+(\d+)(?:(?!\.agpr_count).)*?\.name:\s+{name}\n", w64_asm, re.S)
+    assert agpr and int(agpr.group(1)) == 192, "O^T a[0:127] + Q a[128:191], and not one accumulation register more"
+    assert int(fields["private_segment_fixed_size"]) == 0 and int(fields["vgpr_spill_count"]) == 0
+    assert int(fields["vgpr_count"]) - 192 <= 248, "architectural registers: keep a margin below 256"
+    assert "scratch_" not in body
+    inside, mine = False, []
+    for line in body.splitlines():
+        if "ASMSTART" in line:
+            inside = True
+        elif "ASMEND" in line:
+            inside = False
+        elif not inside and re.search(r"[ ,]a(\[|\d)", line.split(";")[0]):
+            mine.append(line.strip())
+    assert not mine, f"compiler-made instructions touch accumulation registers: {mine[:4]}"
+    lines = [l.strip() for l in body.splitlines()]
+    bars = [i for i, l in enumerate(lines) if l == "s_barrier"]
+    assert len(bars) >= 6
+    hot = lines[bars[1]:bars[4]]                       # three of the four unrolled bodies
+    assert sum(l.startswith("v_mfma_f32_32x32x16") for l in hot) >= 3 * 64
+    # an iteration's pieces go out in its first gaps; a full drain AHEAD of them only meets operations issued most of an
+    # iteration ago (the compiler's wait for the indices), one behind them would wait for the pieces themselves
+    for b in range(1, 4):
+        it = lines[bars[b]:bars[b + 1]]
+        first = next(i for i, l in enumerate(it) if l.startswith("global_load_lds"))
+        assert sum(l.startswith("global_load_lds") for l in it) == 8
+        assert not [l for l in it[first:] if re.match(r"s_waitcnt.*vmcnt\(0\)", l)], "the body drains its own DMA pieces"
+        assert [l for l in it if re.match(r"s_waitcnt vmcnt\(16\)", l)], "the counted wait ahead of the barrier"
+    assert not any(l.startswith("flat_load") for l in hot), "index loads must be global (a flat load counts in lgkmcnt)"
+    assert not any(l.startswith("v_pk_") for l in hot), "packed f32 vector instructions beside the MFMAs"
