@@ -26,10 +26,9 @@ PER_FILE_FLAGS = {"elementwise.hip": ["-ffp-contract=off"], "allreduce.hip": ["-
                   "extend_mfma.hip": ["-fno-honor-nans"],
                   # extend_w64.hip: every filler of its hand-placed MFMA gaps is a single instruction: no SLP packing
                   # of adjacent f32 adds / multiplies into v_pk_* (MI355X_MICROARCH.md: an anti-lever beside MFMAs)
-                  # of adjacent f32 adds / multiplies into v_pk_* (MI355X_MICROARCH.md: an anti-lever beside MFMAs); and its
-                  # accumulation registers belong to the assembly text: the compiler must never park a spill there
-                  "extend_w64.hip": ["-fno-honor-nans", "-fno-slp-vectorize", "-std=c++20",
-                                     "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}
+                  # of adjacent f32 adds / multiplies into v_pk_* (MI355X_MICROARCH.md: an anti-lever beside MFMAs).  Its
+                  # accumulation registers belong to its assembly text alone: see tools/patch_w64_descriptor.py
+                  "extend_w64.hip": ["-fno-honor-nans", "-fno-slp-vectorize", "-std=c++20"]}
 
 
 def _newer(target, deps):
@@ -64,6 +63,9 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    # the extend_w64 kernels own accumulation registers the compiler was never told about: size their allocation
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "patch_w64_descriptor.py"), LIB], check=True,
+                   stdout=None if verbose else subprocess.DEVNULL)
     return LIB
 
 

@@ -26,6 +26,7 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
 struct ExtendArgs;
 int try_extend_w64(const ExtendArgs& a, int head_dim, int dtype, int max_extend_len, int64_t max_seq_len, hipStream_t st);
 void set_extend_w64(int v);
+void set_extend_w64_persist(int v);   // 1 (default): launches with a plan use the persistent workgroups
 
 // test / tuning hooks behind sp_debug_set
 void set_extend_defer_x10(int tenths);

@@ -143,6 +143,7 @@ extern "C" int sp_debug_set(const char* key, int value) {
   if (!strcmp(key, "extend_defer_x10")) { set_extend_defer_x10(value); return SP_OK; }
   if (!strcmp(key, "extend_dma")) { set_extend_dma(value); return SP_OK; }
   if (!strcmp(key, "extend_w64")) { set_extend_w64(value); return SP_OK; }
+  if (!strcmp(key, "extend_w64_persist")) { set_extend_w64_persist(value); return SP_OK; }
   if (!strcmp(key, "ar_fused_blocks")) { set_ar_fused_blocks(value); return SP_OK; }
   if (!strcmp(key, "skinny_nt")) { set_skinny_nt(value); return SP_OK; }
   return SP_ERR_INVALID_ARG;

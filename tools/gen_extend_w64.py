@@ -85,7 +85,7 @@ def gen_static():
         for db in range(4):
             n = (rb * 4 + db) * 16
             txt = " ".join(f'"v_accvgpr_write_b32 a{n + i}, 0\\n"' for i in range(16))
-            m.add(f'asm volatile({txt} ::: {clobbers(n, n + 16)});')
+            m.add(f'asm volatile({txt});')
     out.append(m.render())
     m = Macro("SP_W64_SET_Q(QF)")
     for rb in range(2):
@@ -93,7 +93,7 @@ def gen_static():
             n = 128 + (rb * 8 + ks) * 4
             txt = " ".join(f'"v_accvgpr_write_b32 a{n + i}, %{i}\\n"' for i in range(4))
             ins = ", ".join(f'"v"(QF[{rb}][{ks}][{i}])' for i in range(4))
-            m.add(f'asm volatile({txt} :: {ins} : {clobbers(n, n + 4)});')
+            m.add(f'asm volatile({txt} :: {ins});')
     out.append(m.render())
     m = Macro("SP_W64_GEN_MFMA_S(PAR, KB, KFR)")
     for ks in range(8):
@@ -118,7 +118,7 @@ def gen_static():
                 txt += [f'"v_accvgpr_read_b32 %{i}, a{base + i}\\n"' for i in range(4)]
                 txt += [f'"v_mul_f32 %{i}, %{i}, %4\\n"' for i in range(4)]
                 txt += [f'"v_accvgpr_write_b32 a{base + i}, %{i}\\n"' for i in range(4)]
-            m.add(f'asm volatile({" ".join(txt)} : "=&v"(t0_), "=&v"(t1_), "=&v"(t2_), "=&v"(t3_) : "v"(AL) : {clobbers(n, n + 16)});')
+            m.add(f'asm volatile({" ".join(txt)} : "=&v"(t0_), "=&v"(t1_), "=&v"(t2_), "=&v"(t3_) : "v"(AL));')
         m.add("}")
         out.append(m.render())
     for rb in range(2):
@@ -347,6 +347,7 @@ def bodies():
     for b in range(4):
         out.append(body(f"SP_W64_STEADY_{b}", b))
     out.append(body("SP_W64_STEADYM", 0, mask=True, dyn=True))
+    out.append(body("SP_W64_STEADYD", 0, dyn=True))
     out.append(body("SP_W64_LEAVE", 0, do_nxt=False, dyn=True))
     # the way in: tile 0 is the 'next' tile of an empty iteration in ring position 3
     out.append(body("SP_W64_ENTER", 3, do_cur=False, tnext="0"))

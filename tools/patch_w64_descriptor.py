@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Give the extend_w64 kernels the accumulation registers their assembly text uses.
+
+extend_w64.hip keeps O^T and the Q fragments in a[0:191], named only inside `asm volatile` text.  For the compiler to
+be UNABLE to put anything of its own there (it does, as soon as architectural registers run short, and an AGPR named in
+any asm constraint or clobber makes all of them allocatable), the source never mentions an accumulation register to it
+and is built for a 256-register budget (__launch_bounds__(256, 2)): hipcc then reserves every AGPR and the kernel
+descriptor it writes allocates none.  This script, run on the built library (scratchpad_amd/build.py,
+tools/build_w64_variant.sh), raises GRANULATED_WORKITEM_VGPR_COUNT in compute_pgm_rsrc1 of those kernels'
+descriptors to ACCUM_OFFSET + 256 registers - the unified register file of gfx90a+ places a[i] at register
+ACCUM_OFFSET + i of the wave's allocation (amdhsa kernel descriptor, LLVM AMDGPUUsage 'Kernel Descriptor').
+  python tools/patch_w64_descriptor.py LIB.so [--check]
+"""
+import struct
+import sys
+
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+W64_AGPRS = 256     # a[0:191] O^T and Q; a[192:255]: values the persistent kernel parks across its bodies
+KERNELS = (b"extend_w64_kernel", b"extend_w64p_kernel")
+
+
+def device_elves(data):
+    pos = 0
+    while True:
+        i = data.find(MAGIC, pos)
+        if i < 0:
+            return
+        n = struct.unpack_from("<Q", data, i + 24)[0]
+        off = i + 32
+        for _ in range(n):
+            o, size, tl = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + tl]
+            off += tl
+            if triple.startswith(b"hip") and size:
+                yield i + o, size
+        pos = i + len(MAGIC)
+
+
+def descriptors(data, base):
+    """(name, file offset of the 64-byte kernel descriptor) of the w64 kernels of the ELF at `base`"""
+    assert data[base:base + 4] == b"\x7fELF" and data[base + 4] == 2
+    shoff, = struct.unpack_from("<Q", data, base + 0x28)
+    shentsize, shnum, _ = struct.unpack_from("<HHH", data, base + 0x3A)
+    sections = [struct.unpack_from("<IIQQQQIIQQ", data, base + shoff + k * shentsize) for k in range(shnum)]
+    for sec in sections:
+        if sec[1] not in (2, 11):      # SHT_SYMTAB / SHT_DYNSYM
+            continue
+        strtab = sections[sec[6]]
+        for k in range(sec[5] // 24):
+            name_off, _info, _other, shndx, value, _size = struct.unpack_from("<IBBHQQ", data, base + sec[4] + 24 * k)
+            end = data.index(b"\0", base + strtab[4] + name_off)
+            name = data[base + strtab[4] + name_off:end]
+            if name.endswith(b".kd") and any(kn in name for kn in KERNELS) and 0 < shndx < shnum:
+                s = sections[shndx]
+                yield name.decode(), base + s[4] + (value - s[3])
+
+
+def main():
+    path = sys.argv[1]
+    check = "--check" in sys.argv
+    data = bytearray(open(path, "rb").read())
+    seen, changed = {}, 0
+    for base, _size in device_elves(bytes(data)):
+        for name, off in descriptors(bytes(data), base):
+            rsrc3, rsrc1 = struct.unpack_from("<II", data, off + 44)
+            accum = ((rsrc3 & 0x3F) + 1) * 4
+            want = (accum + W64_AGPRS + 7) // 8 - 1
+            have = rsrc1 & 0x3F
+            state = "ok" if have >= want else "NOT PATCHED"
+            if have < want and not check:
+                struct.pack_into("<I", data, off + 48, (rsrc1 & ~0x3F) | want)
+                changed += 1
+                state = "patched"
+            seen[name] = (accum, have, want, state)
+    if not seen:
+        print(f"{path}: no extend_w64 kernel descriptor found")
+        sys.exit(1)
+    ok = True
+    for name, (accum, have, want, state) in sorted(seen.items()):
+        ok &= state != "NOT PATCHED"
+        print(f"{name}: accum_offset {accum}, register granules {have + 1} -> {max(have, want) + 1} ({(max(have, want) + 1) * 8} registers) {state}")
+    if changed:
+        open(path, "wb").write(data)
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
