@@ -40,7 +40,7 @@ def _newer(target, deps):
 
 def build_native(force: bool = False, verbose: bool = True) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [
+    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(CSRC, "*.inc"))) + [
         os.path.join(ROOT, "include", "scratchpad_hip.h")]
     if not force and _newer(LIB, srcs + hdrs):
         return LIB

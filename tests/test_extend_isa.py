@@ -48,11 +48,14 @@ def test_tile_loop_keeps_its_dma_in_flight(dma_kernel_asm):
 
 
 # ----------------------------------------------------------------------------------------------- extend_w64.hip
-# The 4 x 64-row kernel keeps O^T and the Q fragments in accumulation registers that only its asm text names.  What the
-# parity tests cannot see until it is too late: the compiler parking a value of its own in one of those registers (it
-# does so as soon as the architectural ones run short), a scratch access in the tile loop (its wait drains the DMA
-# ring), the generated bodies drifting away from their generator.
-W64_FLAGS = ["-fno-honor-nans", "-fno-slp-vectorize", "-std=c++20", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]
+# The 4 x 64-row kernel keeps O^T and the Q fragments in accumulation registers that only its asm text names.  For the
+# compiler to be UNABLE to use one of them (it parks values there as soon as architectural registers run short, and an
+# AGPR in any asm constraint or clobber makes all of them allocatable) the source never mentions one to it and is built
+# for a 256-register budget: hipcc then reserves every AGPR - and writes a kernel descriptor without any, which
+# tools/patch_w64_descriptor.py enlarges in the built library.  What the parity tests cannot see until it is too late:
+# that guarantee lost (a constraint someone adds), the descriptor left unpatched, scratch in the tile loop (its wait
+# drains the DMA ring), the generated bodies drifting away from their generator.
+W64_FLAGS = ["-fno-honor-nans", "-fno-slp-vectorize", "-std=c++20"]
 
 
 def test_w64_generated_bodies_are_the_generators_output():
@@ -63,6 +66,14 @@ def test_w64_generated_bodies_are_the_generators_output():
 def test_w64_build_flags_are_the_tested_ones():
     from scratchpad_amd import build
     assert build.PER_FILE_FLAGS["extend_w64.hip"] == W64_FLAGS
+
+
+def test_built_library_gives_the_w64_kernels_their_accumulation_registers():
+    lib = os.path.join(ROOT, "scratchpad_amd", "lib", "libscratchpad_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    r = subprocess.run(["python3", os.path.join(ROOT, "tools", "patch_w64_descriptor.py"), lib, "--check"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.count(" ok") >= 2, r.stdout + r.stderr
 
 
 @pytest.fixture(scope="module")
@@ -87,11 +98,11 @@ def test_w64_registers_belong_to_whom_they_should(w64_asm, tag):
     assert meta
     fields = dict(re.findall(r"\.(\w+):\s+(\d+)", meta.group(1)))
     agpr = re.search(rf"\.agpr_count:\s+(\d+)(?:(?!\.agpr_count).)*?\.name:\s+{name}\n", w64_asm, re.S)
-    assert agpr and int(agpr.group(1)) == 192, "O^T a[0:127] + Q a[128:191], and not one accumulation register more"
+    assert agpr and int(agpr.group(1)) == 0, "the compiler believes the kernel uses no accumulation register: all of them are reserved"
     assert int(fields["private_segment_fixed_size"]) == 0 and int(fields["vgpr_spill_count"]) == 0
-    assert int(fields["vgpr_count"]) - 192 <= 248, "architectural registers: keep a margin below 256"
+    assert int(fields["vgpr_count"]) <= 256 - 8, "architectural registers: a margin below the 256 the build allows"
     assert "scratch_" not in body
-    inside, mine = False, []
+    inside, mine, used = False, [], set()
     for line in body.splitlines():
         if "ASMSTART" in line:
             inside = True
@@ -99,7 +110,12 @@ def test_w64_registers_belong_to_whom_they_should(w64_asm, tag):
             inside = False
         elif not inside and re.search(r"[ ,]a(\[|\d)", line.split(";")[0]):
             mine.append(line.strip())
+        elif inside:
+            for lo, hi in re.findall(r"\ba\[(\d+):(\d+)\]", line):
+                used.update((int(lo), int(hi)))
+            used.update(int(x) for x in re.findall(r"\ba(\d+)\b", line))
     assert not mine, f"compiler-made instructions touch accumulation registers: {mine[:4]}"
+    assert max(used) == 191, "O^T a[0:127] + Q a[128:191]"
     lines = [l.strip() for l in body.splitlines()]
     bars = [i for i, l in enumerate(lines) if l == "s_barrier"]
     assert len(bars) >= 6

@@ -15,7 +15,7 @@ import struct
 import sys
 
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
-W64_AGPRS = 256     # a[0:191] O^T and Q; a[192:255]: values the persistent kernel parks across its bodies
+W64_AGPRS = 256     # a[0:191] O^T and Q; a[192:255]: spare (the persistent experiment parks values there)
 KERNELS = (b"extend_w64_kernel", b"extend_w64p_kernel")
 
 
