@@ -781,6 +781,9 @@ W64_CASES = {
     "long": (8, 2, [0, 3000, 11], [2100, 70, 1500]),
     "every ring position": (4, 1, [0] * 9, [64 * k + 5 for k in range(1, 10)]),
     "group of 8, one kv head": (8, 1, [5, 250], [300, 129]),
+    # enough workgroups to keep every compute unit busy for many rounds: a wait that leaves a piece in flight too long
+    # (a barrier dropped from the way in did) only shows under this kind of memory load
+    "many short prompts": (8, 2, [0] * 1536, [64 + (i * 37) % 90 for i in range(1536)]),
 }
 
 

@@ -316,6 +316,11 @@ def body(name, buf, mask=False, do_cur=True, do_nxt=True, tnext="(t + 1)", dyn=F
                 m.add(f'asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(l_run[{rb}]) : "v"(alpha[{P}][{rb}]), "v"(lsum[{P}][{rb}]));')
         # ---- the ring: pieces of tile t+3 early in the iteration (its buffer was retired by the last barrier; the gaps of
         # phase A carry the fewest fillers), then the index loads of tile t+4, the tile's barrier near the end
+        if do_nxt and not do_cur and g == 57:
+            # the way in starts as soon as Q and tile 0's K have landed; the rest of the prologue's pieces (tile 0's V, tile
+            # 1) must have by now: everything but the 12 youngest operations (tile 2's pieces, tile 3's indices)
+            m.add("__builtin_amdgcn_s_waitcnt(0x007C);")
+            m.add('asm volatile("s_barrier" ::: "memory");')
         if steady and dyn and g == 57:
             # no pieces in this form (tile t+3 lies past the row block's last tile): drain and publish tile t+2
             m.add("__builtin_amdgcn_s_waitcnt(0x0070);")
