@@ -67,4 +67,13 @@ python tools/prof_summary.py --steady $TRACE decode_mfma_kernel decode_merge_ker
 tail -1 $R/prof_bench.json | cut -c1-300 >> $R/kernel_stats.txt
 rm -rf $R/prof
 cat $R/kernel_stats.txt
+# the prefill pass under the same profiler: the extend kernels' own durations (which of the two ran, and how long)
+cd /tmp
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$R/prof2 -o run -- python3 $GRAFT_REPO_ROOT/bench.py --mode prefill --steps 2 --warmup 1 > $GRAFT_REPO_ROOT/$R/prof_prefill.json 2>$GRAFT_REPO_ROOT/$R/prof_prefill.err || { tail -5 $GRAFT_REPO_ROOT/$R/prof_prefill.err; exit 1; }
+cd $GRAFT_REPO_ROOT
+STATS=$(find $R/prof2 -name "*kernel_stats.csv" | head -1)
+python tools/prof_summary.py $STATS 12 > $R/prefill_kernel_stats.txt
+tail -1 $R/prof_prefill.json | cut -c1-400 >> $R/prefill_kernel_stats.txt
+rm -rf $R/prof2
+cat $R/prefill_kernel_stats.txt
 fi
