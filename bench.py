@@ -494,7 +494,8 @@ def prefill_main(args, rank, local_rank, world):
 def prefill_roofline(prof):
     if prof is None:
         return None
-    return {"bound": "mfma", "kernel": "extend_mfma_kernel", "achieved": round(prof["tflops"], 1),
+    return {"bound": "mfma", "kernel": "extend_w64_kernel (long prompts / long prefixes: the launches of this workload) | extend_mfma_kernel",
+            "achieved": round(prof["tflops"], 1),
             "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(prof["tflops"] / MFMA_PEAK_TFLOPS, 4),
             "traffic": None, "avg_launch_ms": round(prof["avg_launch_ms"], 4), "launches": prof["launches"],
             "algorithmic_flops_per_launch": int(prof["flops_per_launch"]),
