@@ -33,7 +33,8 @@ def main(tag):
                      ("mllama.log", "mllama11b.txt"), ("gemv.log", "gemv.txt"), ("sampling.log", "sampling.txt"),
                      ("extend_attn.log", "extend_attn.txt"), ("extend_stamps.log", "extend_stamps_dma.txt"),
                      ("allreduce.log", "allreduce_rehearsal.txt"), ("parity_lines.txt", "parity_lines.txt"),
-                     ("bench_replicas2_refused.log", "replicas2_refused.txt")):
+                     ("bench_replicas2_refused.log", "replicas2_refused.txt"),
+                     ("prefill_kernel_stats.txt", "prefill_kernel_stats.txt")):
         p = os.path.join(R, src)
         if os.path.exists(p):
             text = "".join(line for line in open(p) if "amdgpu.ids" not in line)
