@@ -51,7 +51,10 @@ SP_API const char* sp_status_string(int status);
  * 1 = VALU kernel, 2 = matrix-core kernel), "extend_defer_x10" (how far the extend kernel's running
  * row maximum may trail, in tenths of a log2 unit; < 0 = the shipped value), "extend_dma" (1 = K/V tiles
  * by LDS-DMA into the swizzled ring where it applies - D 128, 16-bit pools - the default; 0 = register-
- * staged tiles for every shape: same bits).  Nothing on the call path reads the environment.  Returns
+ * staged tiles for every shape: same bits), "extend_w64" (the 4-wave x 64-row form of the extend kernel -
+ * D 128, 16-bit pools, plain attention, query-head group a multiple of 4: 1 = where it pays, i.e. mean extend
+ * length >= 768 or a cached prefix >= 1024 tokens, the default; 2 = wherever it applies; 0 = never: same
+ * bits), "ar_fused_blocks", "skinny_nt".  Nothing on the call path reads the environment.  Returns
  * SP_ERR_INVALID_ARG for an unknown key.                                                          */
 SP_API int sp_debug_set(const char* key, int value);
 
