@@ -73,7 +73,10 @@ def test_built_library_gives_the_w64_kernels_their_accumulation_registers():
     if not os.path.exists(lib):
         pytest.skip("library not built")
     r = subprocess.run(["python3", os.path.join(ROOT, "tools", "patch_w64_descriptor.py"), lib, "--check"], capture_output=True, text=True)
-    assert r.returncode == 0 and r.stdout.count(" ok") >= 2, r.stdout + r.stderr
+    assert r.returncode == 0 and r.stdout.count(" ok") >= 2 and "sp_w64_descriptor_patched = 1" in r.stdout, r.stdout + r.stderr
+    # and a library linked WITHOUT that step refuses to launch them: the flag the kernel's host side checks is not 1
+    import ctypes
+    assert ctypes.c_int.in_dll(ctypes.CDLL(lib), "sp_w64_descriptor_patched").value == 1
 
 
 @pytest.fixture(scope="module")
@@ -118,15 +121,18 @@ def test_w64_registers_belong_to_whom_they_should(w64_asm, tag):
     assert max(used) == 191, "O^T a[0:127] + Q a[128:191]"
     lines = [l.strip() for l in body.splitlines()]
     bars = [i for i, l in enumerate(lines) if l == "s_barrier"]
-    assert len(bars) >= 6
-    hot = lines[bars[1]:bars[4]]                       # three of the four unrolled bodies
-    assert sum(l.startswith("v_mfma_f32_32x32x16") for l in hot) >= 3 * 64
+    assert len(bars) >= 8
+    # the pipelined bodies: the stretches between two barriers that issue a tile's 8 pieces
+    bodies = [lines[bars[b]:bars[b + 1]] for b in range(len(bars) - 1)]
+    bodies = [it for it in bodies if sum(l.startswith("global_load_lds") for l in it) == 8]
+    assert len(bodies) >= 6, "four unrolled bodies, the loop's tail, minus the first one (its pieces precede the way in's barrier)"
+    hot = [l for it in bodies for l in it]
     # an iteration's pieces go out in its first gaps; a full drain AHEAD of them only meets operations issued most of an
     # iteration ago (the compiler's wait for the indices), one behind them would wait for the pieces themselves
-    for b in range(1, 4):
-        it = lines[bars[b]:bars[b + 1]]
+    # (a stretch runs from one body's barrier - gap 57 - to the next one's: 64 MFMAs between two bodies of the loop)
+    assert sum(1 for it in bodies if sum(l.startswith("v_mfma_f32_32x32x16") for l in it) == 64) >= 4
+    for it in bodies:
         first = next(i for i, l in enumerate(it) if l.startswith("global_load_lds"))
-        assert sum(l.startswith("global_load_lds") for l in it) == 8
         assert not [l for l in it[first:] if re.match(r"s_waitcnt.*vmcnt\(0\)", l)], "the body drains its own DMA pieces"
         assert [l for l in it if re.match(r"s_waitcnt vmcnt\(16\)", l)], "the counted wait ahead of the barrier"
     assert not any(l.startswith("flat_load") for l in hot), "index loads must be global (a flat load counts in lgkmcnt)"

@@ -15,4 +15,5 @@ for f in scratchpad_amd/csrc/*.hip; do
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scratchpad_amd/lib/libscratchpad_hip_stamps.so build/stamps/*.o
+python3 tools/patch_w64_descriptor.py scratchpad_amd/lib/libscratchpad_hip_stamps.so > /dev/null   # the w64 extend kernels need their descriptors sized (see that script)
 echo built scratchpad_amd/lib/libscratchpad_hip_stamps.so

@@ -9,6 +9,8 @@ descriptor it writes allocates none.  This script, run on the built library (scr
 tools/build_w64_variant.sh), raises GRANULATED_WORKITEM_VGPR_COUNT in compute_pgm_rsrc1 of those kernels'
 descriptors to ACCUM_OFFSET + 256 registers - the unified register file of gfx90a+ places a[i] at register
 ACCUM_OFFSET + i of the wave's allocation (amdhsa kernel descriptor, LLVM AMDGPUUsage 'Kernel Descriptor').
+Once every descriptor is in place the script sets the library's host-side flag `sp_w64_descriptor_patched` to 1;
+extend_w64.hip refuses to launch its kernels while that flag is 0 (a library linked without this step).
   python tools/patch_w64_descriptor.py LIB.so [--check]
 """
 import struct
@@ -56,6 +58,26 @@ def descriptors(data, base):
                 yield name.decode(), base + s[4] + (value - s[3])
 
 
+def host_flag_offset(data):
+    """file offset of the int `sp_w64_descriptor_patched` in the host ELF (the shared library itself)"""
+    assert data[:4] == b"\x7fELF" and data[4] == 2
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, _ = struct.unpack_from("<HHH", data, 0x3A)
+    sections = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + k * shentsize) for k in range(shnum)]
+    for sec in sections:
+        if sec[1] not in (2, 11):
+            continue
+        strtab = sections[sec[6]]
+        for k in range(sec[5] // 24):
+            name_off, _info, _other, shndx, value, _size = struct.unpack_from("<IBBHQQ", data, sec[4] + 24 * k)
+            end = data.index(b"\0", strtab[4] + name_off)
+            if data[strtab[4] + name_off:end] == b"sp_w64_descriptor_patched" and 0 < shndx < shnum:
+                s = sections[shndx]
+                assert s[1] != 8, "the flag must live in .data (initialised), not .bss"
+                return s[4] + (value - s[3])
+    return None
+
+
 def main():
     path = sys.argv[1]
     check = "--check" in sys.argv
@@ -80,6 +102,17 @@ def main():
     for name, (accum, have, want, state) in sorted(seen.items()):
         ok &= state != "NOT PATCHED"
         print(f"{name}: accum_offset {accum}, register granules {have + 1} -> {max(have, want) + 1} ({(max(have, want) + 1) * 8} registers) {state}")
+    flag = host_flag_offset(bytes(data))
+    if flag is None:
+        print(f"{path}: host flag sp_w64_descriptor_patched not found")
+        sys.exit(1)
+    have_flag, = struct.unpack_from("<i", data, flag)
+    if ok and not check and have_flag != 1:
+        struct.pack_into("<i", data, flag, 1)
+        changed += 1
+        have_flag = 1
+    print(f"sp_w64_descriptor_patched = {have_flag}")
+    ok &= have_flag == 1
     if changed:
         open(path, "wb").write(data)
     sys.exit(0 if ok else 1)
