@@ -17,7 +17,7 @@ def main():
     fn.argtypes = [ctypes.c_void_p]
     fn.restype = ctypes.c_int
     Hq, Hkv, D, dt, dev = 32, 8, 128, torch.bfloat16, "cuda"
-    for bs, ln in ((2048, 64), (256, 512), (64, 2048)):
+    for bs, ln in ((2048, 64), (256, 512), (64, 2048), (16, 4096)):
         g = torch.Generator().manual_seed(0)
         P = bs * ln + 64
         kb = torch.empty(P + 1, Hkv, D, dtype=dt, device=dev).normal_(0, 0.5)
@@ -42,6 +42,13 @@ def main():
         run()
         torch.cuda.synchronize()
         v = buf.cpu().tolist()
+        if "persist" in sys.argv:      # the persistent experiment's per-item stamps
+            n = v[17]
+            print(f"bs={bs} len={ln} PERSISTENT: {n} items, {v[18] / n:.1f} tiles each; cycles per item: start -> tiles + Q landed "
+                  f"{v[12] / n:.0f}, way in {v[13] / n:.0f}, hot iterations {v[14] / n:.0f}, last iterations {v[15] / n:.0f}, "
+                  f"seam + output {v[16] / n:.0f}; per workgroup: mean {sum(v[12:17]) / max(v[20], 1):.0f} cycles, slowest {v[19]}", flush=True)
+            assert fn(0) == 0
+            continue
         n = v[16]
         print(f"bs={bs} len={ln}: {n} workgroups, {v[17] / n:.1f} tiles each; cycles: decode item {v[12] / n:.0f}, "
               f"Q + indices + first tiles {v[13] / n:.0f}, tiles {v[14] / n:.0f} ({v[14] / max(v[17], 1):.0f} per tile), "
