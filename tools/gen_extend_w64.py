@@ -323,7 +323,7 @@ def body(name, buf, mask=False, do_cur=True, do_nxt=True, tnext="(t + 1)", dyn=F
             m.add('asm volatile("s_barrier" ::: "memory");')
         if steady and dyn and g == 57:
             # no pieces in this form (tile t+3 lies past the row block's last tile): drain and publish tile t+2
-            m.add("__builtin_amdgcn_s_waitcnt(0x0070);")
+            m.add("SP_W64_COLD_WAIT")
             m.add('asm volatile("s_barrier" ::: "memory");')
         if steady and not dyn:
             if 2 <= g <= 16 and g % 2 == 0:
@@ -338,6 +338,12 @@ def body(name, buf, mask=False, do_cur=True, do_nxt=True, tnext="(t + 1)", dyn=F
                 # this iteration's 8 pieces and 4 index loads; i.e. tile t+2's pieces have landed.  lgkmcnt(0).
                 m.add("__builtin_amdgcn_s_waitcnt(0x4070);")
                 m.add('asm volatile("s_barrier" ::: "memory");')
+        # hooks of the persistent form of the kernel (empty macros elsewhere): work for the NEXT plan item spread over the
+        # gaps of the ways in and out - between two bodies it would sit in front of the next body's first wait
+        if do_nxt and not do_cur:
+            m.add(f"SP_W64_ENTER_HOOK({g})")
+        if do_cur and not do_nxt:
+            m.add(f"SP_W64_LEAVE_HOOK({g})")
         m.add("__builtin_amdgcn_sched_barrier(0);")
     if stamp_at:
         m.add(f"SP_W64_STAMP({STAMP_END}); SP_W64_STAMP_ACC();")
