@@ -25,10 +25,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hi
 PER_FILE_FLAGS = {"elementwise.hip": ["-ffp-contract=off"], "allreduce.hip": ["-ffp-contract=off"],
                   "extend_mfma.hip": ["-fno-honor-nans"],
                   # extend_w64.hip: every filler of its hand-placed MFMA gaps is a single instruction: no SLP packing
-                  # of adjacent f32 adds / multiplies into v_pk_* (MI355X_MICROARCH.md: an anti-lever beside MFMAs)
                   # of adjacent f32 adds / multiplies into v_pk_* (MI355X_MICROARCH.md: an anti-lever beside MFMAs).  Its
-                  # accumulation registers belong to its assembly text alone: see tools/patch_w64_descriptor.py
-                  "extend_w64.hip": ["-fno-honor-nans", "-fno-slp-vectorize", "-std=c++20"]}
+                  # accumulation registers belong to its assembly text alone: see tools/patch_w64_descriptor.py.  The
+                  # atomic optimizer would turn the persistent form's ticket draw into atomic + full wait + broadcast.
+                  "extend_w64.hip": ["-fno-honor-nans", "-fno-slp-vectorize", "-std=c++20", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
 
 
 def _newer(target, deps):

@@ -10,6 +10,10 @@ namespace sp {
 
 // words of an extend plan's header: [count, block rows, Hq, Hkv, num_tokens, bs, 0, 0]; the items follow
 constexpr int kExtPlanHeader = 8;
+// behind a plan's items (at word kExtPlanHeader + 2 * the item bound of sp_extend_plan_bytes): ticket and completion
+// counters of the persistent extend kernel, one pair per kv-head group; zero whenever no launch is using the plan
+constexpr int kExtPlanTicketGroups = 256;
+constexpr int kExtPlanTicketWords = 2 * kExtPlanTicketGroups;
 
 // extend_mfma.hip: MFMA tile kernel for 16-bit ragged extend; SP_ERR_UNSUPPORTED -> use row-streams
 int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* v_buffer,
@@ -26,7 +30,7 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
 struct ExtendArgs;
 int try_extend_w64(const ExtendArgs& a, int head_dim, int dtype, int max_extend_len, int64_t max_seq_len, hipStream_t st);
 void set_extend_w64(int v);
-void set_extend_w64_persist(int v);   // 1 (default): launches with a plan use the persistent workgroups
+void set_extend_w64_persist(int v);   // 0: never, 1 (default): where it pays, 2: every launch with a plan the 4 x 64-row kernel applies to
 
 // test / tuning hooks behind sp_debug_set
 void set_extend_defer_x10(int tenths);

@@ -89,6 +89,8 @@ __global__ __launch_bounds__(kPlanThreads) void extend_plan_kernel(
       }
     }
   }
+  // the persistent kernel's ticket and completion counters (extend_w64.hip): zero between launches
+  for (int i = threadIdx.x; i < kExtPlanTicketWords; i += kPlanThreads) plan[kExtPlanHeader + 2 * max_items + i] = 0;
   if (threadIdx.x == 0) {
     // header: what the plan was built for (the attention kernel checks it against its own launch)
     plan[0] = min(s_total, max_items);
@@ -117,7 +119,7 @@ static inline int64_t extend_plan_items(int64_t num_tokens, int batch_size, int 
 extern "C" size_t sp_extend_plan_bytes(int64_t num_tokens, int batch_size, int num_q_heads, int num_kv_heads) {
   if (num_tokens <= 0 || batch_size <= 0 || num_q_heads <= 0 || num_kv_heads <= 0) return 16;
   const int bm = extend_block_rows(num_q_heads, num_kv_heads);
-  return (size_t)(kExtPlanHeader + 2 * extend_plan_items(num_tokens, batch_size, bm)) * sizeof(int32_t);
+  return (size_t)(kExtPlanHeader + 2 * extend_plan_items(num_tokens, batch_size, bm) + kExtPlanTicketWords) * sizeof(int32_t);
 }
 
 extern "C" int sp_extend_plan(int32_t* plan, size_t plan_bytes, const int32_t* extend_seq_lens,

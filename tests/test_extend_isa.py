@@ -55,7 +55,7 @@ def test_tile_loop_keeps_its_dma_in_flight(dma_kernel_asm):
 # tools/patch_w64_descriptor.py enlarges in the built library.  What the parity tests cannot see until it is too late:
 # that guarantee lost (a constraint someone adds), the descriptor left unpatched, scratch in the tile loop (its wait
 # drains the DMA ring), the generated bodies drifting away from their generator.
-W64_FLAGS = ["-fno-honor-nans", "-fno-slp-vectorize", "-std=c++20"]
+W64_FLAGS = ["-fno-honor-nans", "-fno-slp-vectorize", "-std=c++20", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 
 def test_w64_generated_bodies_are_the_generators_output():
@@ -137,3 +137,46 @@ def test_w64_registers_belong_to_whom_they_should(w64_asm, tag):
         assert [l for l in it if re.match(r"s_waitcnt vmcnt\(16\)", l)], "the counted wait ahead of the barrier"
     assert not any(l.startswith("flat_load") for l in hot), "index loads must be global (a flat load counts in lgkmcnt)"
     assert not any(l.startswith("v_pk_") for l in hot), "packed f32 vector instructions beside the MFMAs"
+
+
+@pytest.mark.parametrize("tag", ["8bf16_tag", "7f16_tag"])
+def test_w64_persistent_form_keeps_to_its_registers(w64_asm, tag):
+    """The persistent form of the kernel (extend_w64p_kernel): the same ownership rules, more accumulation registers in
+    its asm text - the next item's kv slots in a[192:203], the second half of its Q rows in a[204:235] - and not one
+    spilled value (a reload is a s_waitcnt vmcnt(0): a drained DMA ring in the middle of an item)."""
+    name = f"_ZN2sp18extend_w64p_kernelINS_{tag}EEEvNS_10ExtendArgsE"
+    m = re.search(rf"^{name}:[^\n]*\n(.*?)^\.Lfunc_end", w64_asm, re.S | re.M)
+    assert m, "kernel not found"
+    body = m.group(1)
+    meta = re.search(rf"\.name:\s+{name}\n(.*?)\.wavefront_size", w64_asm, re.S)
+    assert meta
+    fields = dict(re.findall(r"\.(\w+):\s+(\d+)", meta.group(1)))
+    agpr = re.search(rf"\.agpr_count:\s+(\d+)(?:(?!\.agpr_count).)*?\.name:\s+{name}\n", w64_asm, re.S)
+    assert agpr and int(agpr.group(1)) == 0, "the compiler believes the kernel uses no accumulation register: all of them are reserved"
+    assert int(fields["private_segment_fixed_size"]) == 0 and int(fields["vgpr_spill_count"]) == 0
+    assert int(fields["vgpr_count"]) <= 256
+    assert "scratch_" not in body
+    inside, mine, used = False, [], set()
+    for line in body.splitlines():
+        if "ASMSTART" in line:
+            inside = True
+        elif "ASMEND" in line:
+            inside = False
+        elif not inside and re.search(r"[ ,]a(\[|\d)", line.split(";")[0]):
+            mine.append(line.strip())
+        elif inside:
+            for lo, hi in re.findall(r"\ba\[(\d+):(\d+)\]", line):
+                used.update((int(lo), int(hi)))
+            used.update(int(x) for x in re.findall(r"\ba(\d+)\b", line))
+    assert not mine, f"compiler-made instructions touch accumulation registers: {mine[:4]}"
+    assert max(used) == 235, "O^T a[0:127], Q a[128:191], next kv slots a[192:203], next Q rows a[204:235]"
+    # the ticket draw stays an atomic whose value is waited for where it is read (the atomic optimizer's form waits -
+    # a full round trip - right behind it)
+    lines = [l.strip() for l in body.splitlines()]
+    draws = [i for i, l in enumerate(lines) if l.startswith("global_atomic_add") and "sc0" in l]
+    waited = []
+    for i in draws:
+        nxt = [l for l in lines[i + 1:i + 8] if l and not l.startswith((";", "."))]
+        waited.append(any(re.match(r"s_waitcnt.*vmcnt\(0\)", l) for l in nxt[:3]))
+    # (the two completion counts at the kernel's ends are read at once; the draws inside the item loop are not)
+    assert len(draws) >= 3 and waited.count(False) >= 2, "the ticket is waited for on the spot"

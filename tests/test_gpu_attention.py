@@ -766,11 +766,14 @@ def test_decode_plan_fuzz_planned_equals_static_bit_for_bit(nat, seed):
 @pytest.fixture
 def w64(nat):
     """sp_debug_set("extend_w64", 2): the one-wave-per-SIMD kernel wherever it applies (D = 128, 16-bit, plain attention,
-    query-head group a multiple of 4); 0 = never.  The shipped mode 1 picks it for long prompts / long prefixes only."""
-    def set_mode(m):
+    query-head group a multiple of 4); 0 = never.  "extend_w64_persist": its persistent form for launches with a plan
+    (2 = wherever the kernel applies, 0 = never).  The shipped modes (1, 1) pick by launch shape."""
+    def set_mode(m, persist=0):
         nat.debug_set("extend_w64", m)
+        nat.debug_set("extend_w64_persist", persist)
     yield set_mode
     nat.debug_set("extend_w64", 1)
+    nat.debug_set("extend_w64_persist", 1)
 
 
 W64_CASES = {
@@ -784,6 +787,10 @@ W64_CASES = {
     # enough workgroups to keep every compute unit busy for many rounds: a wait that leaves a piece in flight too long
     # (a barrier dropped from the way in did) only shows under this kind of memory load
     "many short prompts": (8, 2, [0] * 1536, [64 + (i * 37) % 90 for i in range(1536)]),
+    # the persistent form's item loop: a dozen items per workgroup with one to nine tiles each, requests without new
+    # tokens in between, prefixes that start the masked tiles early
+    "mixed lengths, many items": (8, 2, [(i * 53) % 300 for i in range(400)], [(i * 97) % 520 if i % 11 else 0 for i in range(400)]),
+    "long and short": (16, 4, [0, 0, 1000, 0, 7] + [0] * 60, [4096, 64, 200, 1300, 2500] + [65 + 3 * i for i in range(60)]),
 }
 
 
@@ -794,19 +801,39 @@ def test_extend_w64_equals_the_eight_wave_kernel_bit_for_bit(nat, w64, dt, case)
     once, O^T accumulation order over the keys): the two kernels must agree to the last bit - and from run to run (a
     miscounted wait, a missing hazard distance or a register the compiler also uses shows up as a difference here).
     The w64 kernel sums a row's probabilities in tile order, the eight-wave kernel in register order: the sums differ
-    in their last fp32 bits, the bf16 / fp16 outputs do not."""
+    in their last fp32 bits, the bf16 / fp16 outputs do not.  One case is allowed to differ: with a 4096-token prompt
+    among short ones, ~20 outputs per million come out a few units in the last place apart (a wave of this kernel votes
+    on the deferred maximum over 64 rows of one head, a wave of the other over its own rows: where the votes differ,
+    P is rounded against another maximum).  The two forms of the w64 kernel share every instruction of the
+    arithmetic: they agree exactly, always."""
     dtype = DTYPES[dt]
     Hq, Hkv, pre, ext = W64_CASES[case]
     p, q, ext_t, start = extend_problem(73, Hq, Hkv, 128, pre, ext, dtype)
     args = (q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"], p["seq_lens"], ext_t, start, 128 ** -0.5)
     plan = nat.extend_plan(ext_t, p["seq_lens"], int(ext_t.sum()), Hq, Hkv, True)
     w64(0)
+    ref8 = run_extend(nat, *args, plan=plan)
+    w64(2, 0)
     ref = run_extend(nat, *args, plan=plan)
-    w64(2)
-    for _ in range(3):
-        got = run_extend(nat, *args, plan=plan)
-        assert torch.equal(got, ref), f"{case} {dt}: max |diff| {float((got.float() - ref.float()).abs().max()):.3e}"
+    if not torch.equal(ref, ref8):
+        # a few elements per 100,000, a few units in the last place of outputs that are small sums of large terms
+        a_, b_ = ref.float(), ref8.float()
+        off = a_ != b_
+        assert case == "long and short" and float(off.float().mean()) < 1e-4 and float((a_ - b_).abs().max()) < 2e-3, \
+            f"{case} {dt}: max |diff| {float((a_ - b_).abs().max()):.3e} on {int(off.sum())} elements"
+    for persist in (0, 2):     # one workgroup per item / persistent workgroups drawing items by ticket
+        w64(2, persist)
+        for _ in range(3):
+            got = run_extend(nat, *args, plan=plan)
+            assert torch.equal(got, ref), f"{case} {dt} persist={persist}: max |diff| {float((got.float() - ref.float()).abs().max()):.3e}"
     assert torch.equal(run_extend(nat, *args), ref), "without a plan (grid over every possible row block)"
+    # the persistent form's counters behind the plan's items are zero again: the next launch starts from ticket 0
+    assert int(plan[-512:].abs().sum()) == 0
+    # a plan of another step (same sizes, header differs): its items are walked, its counters left alone
+    stale = plan.clone()
+    stale[4] += 1
+    stale[-512:] = 7
+    assert torch.equal(run_extend(nat, *args, plan=stale), ref) and int((stale[-512:] != 7).sum()) == 0
 
 
 def test_extend_w64_against_the_oracle_and_non_causal(nat, w64):
@@ -834,6 +861,17 @@ def test_extend_w64_against_the_oracle_and_non_causal(nat, w64):
     got = run_extend(nat, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"], enc, ext_t, start, D ** -0.5,
                      causal=False, kv_start=kv_start)
     assert torch.equal(got, ref)
+    # ... through the persistent form, with a request that has no encoder tokens at all (rows of zeros, no tile)
+    enc0 = torch.tensor([70, 0, 333], dtype=torch.int64, device=DEV)
+    plan = nat.extend_plan(ext_t, enc0, int(ext_t.sum()), Hq, Hkv, False)
+    w64(0)
+    ref = run_extend(nat, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"], enc0, ext_t, start, D ** -0.5,
+                     causal=False, kv_start=kv_start, plan=plan)
+    w64(2, 2)
+    for _ in range(2):
+        got = run_extend(nat, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"], enc0, ext_t, start,
+                         D ** -0.5, causal=False, kv_start=kv_start, plan=plan)
+        assert torch.equal(got, ref)
 
 
 def test_extend_w64_is_selected_for_long_prompts_only(nat, w64):
@@ -844,7 +882,8 @@ def test_extend_w64_is_selected_for_long_prompts_only(nat, w64):
     for pre, ext in (([0, 0], [100, 90]), ([0, 0], [1500, 1200]), ([2000, 1500], [64, 64])):
         p, q, ext_t, start = extend_problem(79, 8, 2, 128, pre, ext, dtype)
         args = (q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"], p["seq_lens"], ext_t, start, 128 ** -0.5)
+        plan = nat.extend_plan(ext_t, p["seq_lens"], int(ext_t.sum()), 8, 2, True)
         w64(0)
         ref = run_extend(nat, *args)
-        w64(1)
-        assert torch.equal(run_extend(nat, *args), ref)
+        w64(1, 1)
+        assert torch.equal(run_extend(nat, *args), ref) and torch.equal(run_extend(nat, *args, plan=plan), ref)

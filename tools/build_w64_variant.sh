@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 NAME=$1; shift
 mkdir -p build/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -fvisibility=hidden -Wno-unused-value -fno-honor-nans \
-  -fno-slp-vectorize "$@" -c scratchpad_amd/csrc/extend_w64.hip -o build/variants/extend_w64_$NAME.o
+  -fno-slp-vectorize -mllvm -amdgpu-atomic-optimizer-strategy=None "$@" -c scratchpad_amd/csrc/extend_w64.hip -o build/variants/extend_w64_$NAME.o
 OBJS=$(ls build/obj/*.o | grep -v extend_w64.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scratchpad_amd/lib/libscratchpad_hip_$NAME.so $OBJS build/variants/extend_w64_$NAME.o
 python3 tools/patch_w64_descriptor.py scratchpad_amd/lib/libscratchpad_hip_$NAME.so

@@ -209,7 +209,7 @@ def body(name, buf, mask=False, do_cur=True, do_nxt=True, tnext="(t + 1)", dyn=F
     if do_nxt and not do_cur:   # nobody read the first fragments ahead
         for f in range(3):
             m.add(kread(f, buf1))
-    stamp_at = dict(STAMP_AT) if steady and not mask else {}
+    stamp_at = dict(STAMP_AT) if steady and mask == STAMP_MASKED else {}
     for g in range(64):
         m.add(f"/* gap {g} */")
         if g in stamp_at:
@@ -323,6 +323,8 @@ def body(name, buf, mask=False, do_cur=True, do_nxt=True, tnext="(t + 1)", dyn=F
             m.add('asm volatile("s_barrier" ::: "memory");')
         if steady and dyn and g == 57:
             # no pieces in this form (tile t+3 lies past the row block's last tile): drain and publish tile t+2
+            if STAMP_WAIT is not None and stamp_at:
+                m.add(f"SP_W64_STAMP({STAMP_WAIT});")
             m.add("SP_W64_COLD_WAIT")
             m.add('asm volatile("s_barrier" ::: "memory");')
         if steady and not dyn:
@@ -393,10 +395,12 @@ def wait_count_v(order, gap, v):
 STAMP_AT = {0: 0, 8: 1, 16: 2, 24: 3, 32: 4, 40: 5, 48: 6, 56: 7, 60: 9}
 STAMP_WAIT = 8
 STAMP_END = 10
+STAMP_MASKED = False      # --stamp-masked: the stamps go into the masked run-time-positioned body instead
 
 
 def generate():
-    global STAMP_AT, STAMP_WAIT, STAMP_END
+    global STAMP_AT, STAMP_WAIT, STAMP_END, STAMP_MASKED
+    STAMP_MASKED = "--stamp-masked" in sys.argv
     for i, arg in enumerate(sys.argv):
         if arg == "--stamp-gaps":
             gaps = [int(x) for x in sys.argv[i + 1].split(",")]

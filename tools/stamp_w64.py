@@ -16,9 +16,9 @@ SEG = ["gaps 0-7 (S^T kb0)", "gaps 8-15", "gaps 16-23 (S^T kb1)", "gaps 24-31", 
 
 def main():
     lib = sys.argv[1] if len(sys.argv) > 1 else "libscratchpad_hip_stamps.so@extend_w64=1"
-    names = sys.argv[2].split(",") if len(sys.argv) > 2 else SEG   # custom --stamp-gaps builds: the gap list
+    names = sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] else SEG   # custom --stamp-gaps builds: the gap list
     nat = load_native(lib, 0)
-    bs, ln, prefix = 128, 128, 8192
+    bs, ln, prefix = (int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (128, 128, 8192)
     Hq, Hkv, D, dt, dev = 32, 8, 128, torch.bfloat16, "cuda"
     g = torch.Generator().manual_seed(0)
     ext = torch.full((bs,), ln)

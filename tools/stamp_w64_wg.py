@@ -45,7 +45,7 @@ def main():
         if "persist" in sys.argv:      # the persistent experiment's per-item stamps
             n = v[17]
             print(f"bs={bs} len={ln} PERSISTENT: {n} items, {v[18] / n:.1f} tiles each; cycles per item: start -> tiles + Q landed "
-                  f"{v[12] / n:.0f}, way in {v[13] / n:.0f}, hot iterations {v[14] / n:.0f}, last iterations {v[15] / n:.0f} (the way out alone {v[21] / n:.0f}), "
+                  f"{v[12] / n:.0f}, way in {v[13] / n:.0f}, hot iterations {v[14] / n:.0f}, last iterations {v[15] / n:.0f} (their start {v[22] / n:.0f}, the way out {v[21] / n:.0f}), "
                   f"seam + output {v[16] / n:.0f}; per workgroup: mean {sum(v[12:17]) / max(v[20], 1):.0f} cycles, slowest {v[19]}", flush=True)
             assert fn(0) == 0
             continue
