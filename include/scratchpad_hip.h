@@ -52,9 +52,12 @@ SP_API const char* sp_status_string(int status);
  * row maximum may trail, in tenths of a log2 unit; < 0 = the shipped value), "extend_dma" (1 = K/V tiles
  * by LDS-DMA into the swizzled ring where it applies - D 128, 16-bit pools - the default; 0 = register-
  * staged tiles for every shape: same bits), "extend_w64" (the 4-wave x 64-row form of the extend kernel -
- * D 128, 16-bit pools, plain attention, query-head group a multiple of 4: 1 = where it pays, i.e. mean extend
- * length >= 768 or a cached prefix >= 1024 tokens, the default; 2 = wherever it applies; 0 = never: same
- * bits), "ar_fused_blocks", "skinny_nt".  Nothing on the call path reads the environment.  Returns
+ * D 128, 16-bit pools, plain attention, query-head group a multiple of 4: 1 = where it pays, the default;
+ * 2 = wherever it applies; 0 = never), "extend_w64_persist" (its persistent form - one workgroup per compute
+ * unit drawing the plan's items by ticket: 1 = where it pays, i.e. a plan with at least three items per
+ * workgroup and row blocks of at most ~32 tiles, the default; 2 = every planned launch the kernel applies to;
+ * 0 = never; without it mode 1 of "extend_w64" means mean extend length >= 768 or a cached prefix >= 1024
+ * tokens; the two forms agree bit for bit), "ar_fused_blocks", "skinny_nt".  Nothing on the call path reads the environment.  Returns
  * SP_ERR_INVALID_ARG for an unknown key.                                                          */
 SP_API int sp_debug_set(const char* key, int value);
 
@@ -201,7 +204,12 @@ SP_API size_t sp_extend_attention_workspace_bytes(int64_t num_tokens, int batch_
  * plan of another step, a plan built for other head counts - does not use its items and derives each
  * workgroup's rows by walking the requests instead, so a wrong plan costs order, never rows.
  * sp_extend_plan_bytes() sizes the int32 buffer; `plan_bytes` (sp_extend_attention) must cover it, else
- * SP_ERR_WORKSPACE.  `causal` of sp_extend_plan is reserved (the item list does not depend on it).    */
+ * SP_ERR_WORKSPACE.  `causal` of sp_extend_plan is reserved (the item list does not depend on it).
+ * The last 2 KiB of the buffer are counters of the attention kernel (the persistent form of the 4 x 64-row
+ * kernel hands its workgroups the items by ticket): written by sp_extend_plan (zeros), counted up during
+ * a launch that owns the plan and zero again when it ends - hence `plan` is not const, and one plan
+ * buffer serves one launch at a time (the layers of a forward, one after the other on a stream: yes;
+ * two streams at once: give each its own copy).  A plan that is not the launch's own is only read.   */
 SP_API size_t sp_extend_plan_bytes(int64_t num_tokens, int batch_size, int num_q_heads, int num_kv_heads);
 SP_API int sp_extend_plan(int32_t* plan, size_t plan_bytes, const int32_t* extend_seq_lens, const void* seq_lens,
                    int idx64, int batch_size, int64_t num_tokens, int num_q_heads, int num_kv_heads,
@@ -216,7 +224,7 @@ SP_API int sp_extend_attention(void* out, const void* q, const void* k_buffer, c
                         float logit_cap, float k_scale, float v_scale, int causal,
                         int window_left, int max_extend_len,
                         int64_t max_seq_len, void* workspace, size_t workspace_bytes,
-                        const int32_t* plan, size_t plan_bytes, int dtype, int kv_dtype, void* stream);
+                        int32_t* plan, size_t plan_bytes, int dtype, int kv_dtype, void* stream);
 
 /* ---- Sampler.  Replaces nn/layers/sampler.py:63-75 (torch.argmax; logits.div_(T) + softmax),
  *      sampler.py:195-232 (top_k_top_p_min_p_sampling_from_probs_torch, top_p_normalize_probs_torch)

@@ -116,7 +116,8 @@ def _check(status: int, what: str):
 
 def debug_set(key: str, value: int) -> None:
     """Test / tuning switch of the library (sp_debug_set): "decode_kernel", "extend_defer_x10", "extend_dma" (0 = register-staged tiles),
-    "extend_w64" (0 never / 1 where it pays (default) / 2 wherever it applies: the 4-wave x 64-row extend kernel)."""
+    "extend_w64" (0 never / 1 where it pays (default) / 2 wherever it applies: the 4-wave x 64-row extend kernel),
+    "extend_w64_persist" (the same three values for its persistent form on launches with a plan)."""
     _check(load().sp_debug_set(key.encode(), int(value)), f"sp_debug_set({key})")
 
 

@@ -178,7 +178,7 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
                                    float k_scale, float v_scale, int causal, int window_left,
                                    int max_extend_len,
                                    int64_t max_seq_len, void* workspace, size_t workspace_bytes,
-                                   const int32_t* plan, size_t plan_bytes, int dtype, int kv_dtype,
+                                   int32_t* plan, size_t plan_bytes, int dtype, int kv_dtype,
                                    void* stream) {
   SP_CHECK_ARG(out && q && k_buffer && v_buffer && req_to_token && req_pool_indices && seq_lens);
   SP_CHECK_ARG(extend_seq_lens && extend_start_loc && batch_size >= 0 && num_tokens >= 0);

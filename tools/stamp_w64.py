@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where a pipelined iteration of the 4 x 64-row extend kernel spends its cycles: runs a -DSP_W64_STAMPS build
-(tools/build_w64_variant.sh stamps -DSP_W64_STAMPS) on a long-prefix launch and prints cycles per segment and wave."""
+(tools/build_w64_variant.sh w64stamps -DSP_W64_STAMPS) on a long-prefix launch and prints cycles per segment and wave."""
 import ctypes
 import os
 import sys
@@ -15,7 +15,7 @@ SEG = ["gaps 0-7 (S^T kb0)", "gaps 8-15", "gaps 16-23 (S^T kb1)", "gaps 24-31", 
 
 
 def main():
-    lib = sys.argv[1] if len(sys.argv) > 1 else "libscratchpad_hip_stamps.so@extend_w64=1"
+    lib = sys.argv[1] if len(sys.argv) > 1 else "libscratchpad_hip_w64stamps.so@extend_w64=2,extend_w64_persist=0"
     names = sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] else SEG   # custom --stamp-gaps builds: the gap list
     nat = load_native(lib, 0)
     bs, ln, prefix = (int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (128, 128, 8192)
