@@ -54,7 +54,7 @@ SP_API const char* sp_status_string(int status);
  * staged tiles for every shape: same bits), "extend_w64" (the 4-wave x 64-row form of the extend kernel -
  * D 128, 16-bit pools, plain attention, query-head group a multiple of 4: 1 = where it pays, the default;
  * 2 = wherever it applies; 0 = never), "extend_w64_persist" (its persistent form - one workgroup per compute
- * unit drawing the plan's items by ticket: 1 = where it pays, i.e. a plan with at least three items per
+ * unit drawing the plan's items by ticket: 1 = where it pays, i.e. a plan with at least 32 items per
  * workgroup and row blocks of at most ~32 tiles, the default; 2 = every planned launch the kernel applies to;
  * 0 = never; without it mode 1 of "extend_w64" means mean extend length >= 768 or a cached prefix >= 1024
  * tokens; the two forms agree bit for bit), "ar_fused_blocks", "skinny_nt".  Nothing on the call path reads the environment.  Returns
