@@ -102,7 +102,7 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.sp_abi_version() != 4:
+    if lib.sp_abi_version() != 5:
         raise RuntimeError("libscratchpad_hip.so ABI version mismatch")
     _lib = lib
     return lib

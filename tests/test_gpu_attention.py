@@ -874,6 +874,42 @@ def test_extend_w64_against_the_oracle_and_non_causal(nat, w64):
         assert torch.equal(got, ref)
 
 
+def test_extend_w64_persistent_form_replays_in_a_graph(nat, w64):
+    """Captured once, replayed: every replay starts from ticket 0 (the last workgroup of a launch zeroes the counters behind
+    the plan's items - no memset node, nothing on the host), and the same plan then serves an eager launch."""
+    dtype = torch.bfloat16
+    Hq, Hkv = 8, 2
+    pre = [(i * 31) % 200 for i in range(300)]
+    ext = [64 + (i * 41) % 200 for i in range(300)]
+    p, q, ext_t, start = extend_problem(83, Hq, Hkv, 128, pre, ext, dtype)
+    plan = nat.extend_plan(ext_t, p["seq_lens"], int(ext_t.sum()), Hq, Hkv, True)
+    ws = torch.empty(nat.extend_workspace_bytes(q.shape[0], len(ext), Hq, 128, dtype), dtype=torch.uint8, device=DEV)
+    args = (q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"], p["seq_lens"], ext_t, start, 128 ** -0.5,
+            0.0, True, max(ext), int(p["seq_lens"].max()), ws)
+    w64(2, 0)
+    ref = torch.full_like(q, float("nan"))
+    nat.extend_attention(ref, *args, plan=plan)
+    w64(2, 2)
+    out = torch.full_like(q, float("nan"))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        nat.extend_attention(out, *args, plan=plan)          # warm (kernel attributes are set outside the capture)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        nat.extend_attention(out, *args, plan=plan)
+    for _ in range(3):
+        out.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+        assert int(plan[-512:].abs().sum()) == 0
+    out.fill_(float("nan"))
+    nat.extend_attention(out, *args, plan=plan)
+    assert torch.equal(out, ref)
+
+
 def test_extend_w64_is_selected_for_long_prompts_only(nat, w64):
     """mode 1 (shipped): long prompts or a long cached prefix take the w64 kernel, short ones the eight-wave kernel -
     observable through the foreign-plan path: both give the same bits, so the selection is checked by timing order

@@ -45,7 +45,7 @@ def test_python_binding_covers_every_symbol():
 
 def test_abi_version_and_status_strings(lib):
     lib.sp_abi_version.restype = ctypes.c_int
-    assert lib.sp_abi_version() == 4
+    assert lib.sp_abi_version() == 5
     lib.sp_status_string.restype = ctypes.c_char_p
     assert lib.sp_status_string(0) == b"ok"
     assert b"unsupported" in lib.sp_status_string(-2)
