@@ -827,6 +827,12 @@ def test_extend_w64_equals_the_eight_wave_kernel_bit_for_bit(nat, w64, dt, case)
             got = run_extend(nat, *args, plan=plan)
             assert torch.equal(got, ref), f"{case} {dt} persist={persist}: max |diff| {float((got.float() - ref.float()).abs().max()):.3e}"
     assert torch.equal(run_extend(nat, *args), ref), "without a plan (grid over every possible row block)"
+    # ... and with 32-bit request indices / sequence lengths (the kernels read them through one switch)
+    if dt == "bf16":
+        a32 = list(args)
+        a32[4], a32[5] = args[4].to(torch.int32), args[5].to(torch.int32)
+        plan32 = nat.extend_plan(ext_t, a32[5], int(ext_t.sum()), Hq, Hkv, True)
+        assert torch.equal(run_extend(nat, *a32, plan=plan32), ref)
     # the persistent form's counters behind the plan's items are zero again: the next launch starts from ticket 0
     assert int(plan[-512:].abs().sum()) == 0
     # a plan of another step (same sizes, header differs): its items are walked, its counters left alone
