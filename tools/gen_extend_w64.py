@@ -350,7 +350,8 @@ def body(name, buf, mask=False, do_cur=True, do_nxt=True, tnext="(t + 1)", dyn=F
     if stamp_at:
         m.add(f"SP_W64_STAMP({STAMP_END}); SP_W64_STAMP_ACC();")
     if steady:   # (on the way in O^T is still zero: nothing to rescale)
-        m.add("if (any_) { SP_W64_MFMA_FENCE(); SP_W64_RESCALE_O_0(alpha[%d][0]); SP_W64_RESCALE_O_1(alpha[%d][1]); SP_W64_ACCWRITE_FENCE(); }" % (Pn, Pn))
+        # (rare - the deferred maximum moves in a row block's first tiles: out of line, the loop's code stays dense)
+        m.add("if (__builtin_expect(any_, 0)) { SP_W64_MFMA_FENCE(); SP_W64_RESCALE_O_0(alpha[%d][0]); SP_W64_RESCALE_O_1(alpha[%d][1]); SP_W64_ACCWRITE_FENCE(); }" % (Pn, Pn))
     m.add("}")
     return m.render()
 
