@@ -15,8 +15,19 @@ accumulation register.  This script writes that text as macros:
   SP_W64_READ_O(RB, DB, x)                  16 accumulators into float x[16] (epilogue)
   SP_W64_STEADY_0..3                        the software-pipelined tile iteration, one per ring buffer, every MFMA gap
                                             filled by the table below, with counted lgkmcnt waits
+  SP_W64_STEADYM / STEADYD / LEAVE          the same with the ring position as a run-time value (`cb_`): the masked and
+                                            the plain form of the last iterations, the way out of the pipeline
+  SP_W64_ENTER / ENTERM                     the way in (tile 0 as the next tile of an empty iteration)
+
+The bodies name three macros the including file defines: SP_W64_ENTER_HOOK(g) / SP_W64_LEAVE_HOOK(g) in every gap g of
+the ways in and out (the persistent form of the kernel puts the next item's loads there; empty otherwise) and
+SP_W64_COLD_WAIT, the vector-memory wait of the run-time-positioned bodies (a full drain, or the persistent form's
+counted one).
 
 Usage: python tools/gen_extend_w64.py [--check]   (--check: exit 1 if the committed file differs)
+       ... --stamp-gaps 30,31,... / --stamp-masked   diagnostic stamps (-DSP_W64_STAMPS builds): other gaps than
+                                                     the default ten segments / in the masked body instead of the
+                                                     pipelined ones; write the file, build the variant, regenerate
 """
 import os
 import sys
