@@ -17,7 +17,7 @@ import struct
 import sys
 
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
-W64_AGPRS = 256     # a[0:191] O^T and Q; a[192:255]: spare (the persistent experiment parks values there)
+W64_AGPRS = 256     # a[0:191] O^T and Q; a[192:235]: the persistent form (the next item's kv slots and half of its Q rows)
 KERNELS = (b"extend_w64_kernel", b"extend_w64p_kernel")
 
 

@@ -42,7 +42,7 @@ def main():
         run()
         torch.cuda.synchronize()
         v = buf.cpu().tolist()
-        if "persist" in sys.argv:      # the persistent experiment's per-item stamps
+        if "persist" in sys.argv:      # the persistent form's per-item stamps
             n = v[17]
             print(f"bs={bs} len={ln} PERSISTENT: {n} items, {v[18] / n:.1f} tiles each; cycles per item: start -> tiles + Q landed "
                   f"{v[12] / n:.0f}, way in {v[13] / n:.0f}, hot iterations {v[14] / n:.0f}, last iterations {v[15] / n:.0f} (their start {v[22] / n:.0f}, the way out {v[21] / n:.0f}), "
