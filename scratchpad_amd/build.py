@@ -42,8 +42,15 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(CSRC, "*.inc"))) + [
         os.path.join(ROOT, "include", "scratchpad_hip.h")]
-    if not force and _newer(LIB, srcs + hdrs):
+    # (the library also has to be made of exactly these sources and flags: a source removed - or a flag changed - leaves
+    # every remaining file older than the library)
+    stamp = LIB + ".sources"
+    made_of = "\n".join([os.path.basename(x) for x in srcs] + [" ".join(FLAGS)] +
+                        [k + " " + " ".join(v) for k, v in sorted(PER_FILE_FLAGS.items())])
+    same = os.path.exists(stamp) and open(stamp).read() == made_of
+    if not force and same and _newer(LIB, srcs + hdrs):
         return LIB
+    force = force or not same
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
 
@@ -66,6 +73,8 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
     # the extend_w64 kernels own accumulation registers the compiler was never told about: size their allocation
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "patch_w64_descriptor.py"), LIB], check=True,
                    stdout=None if verbose else subprocess.DEVNULL)
+    with open(stamp, "w") as f:
+        f.write(made_of)
     return LIB
 
 
