@@ -272,6 +272,33 @@ def extend_attention(q: torch.Tensor, k_buffer: torch.Tensor, v_buffer: torch.Te
     return o.to(q.dtype)
 
 
+def context_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, b_start_loc: torch.Tensor,
+                      b_seq_len: torch.Tensor) -> torch.Tensor:
+    """context_attention_fwd - nn/attention/triton_attn/prefill_attention.py:125-163 (kernel 18-122): cache-less
+    CAUSAL variable-length self-attention.  Sequence b = rows [b_start_loc[b], + b_seq_len[b]) of q / k / v
+    ([tokens, heads, D], GQA by head // group); sm_scale = 1 / sqrt(D) is fixed inside the function (131);
+    probabilities are cast to V's dtype before P.V while the denominator keeps the fp32 sum (98-112).
+    Pinned by tests/golden/prefill_attention.npz (the reference's kernel under the Triton interpreter)."""
+    T, Hq, D = q.shape
+    Hkv = k.shape[1]
+    g = Hq // Hkv
+    o = torch.zeros(T, Hq, v.shape[2], dtype=torch.float32)
+    for b in range(b_seq_len.shape[0]):
+        s0, L = int(b_start_loc[b]), int(b_seq_len[b])
+        if L == 0:
+            continue
+        qb = q[s0:s0 + L].to(torch.float32).view(L, Hkv, g, D)
+        kb = k[s0:s0 + L].to(torch.float32)
+        vb = v[s0:s0 + L].to(torch.float32)
+        s = torch.einsum("ehgd,lhd->hgel", qb, kb) * (1.0 / math.sqrt(D))
+        col = torch.arange(L).view(1, L)
+        row = torch.arange(L).view(L, 1)
+        s = s.masked_fill(col > row, float("-inf"))
+        p, denom = _softmax_parts(s, q.dtype)
+        o[s0:s0 + L] = (torch.einsum("hgel,lhd->hged", p, vb) / denom).permute(2, 0, 1, 3).reshape(L, Hq, -1)
+    return o.to(q.dtype)
+
+
 def merge_state(o1: torch.Tensor, lse1: torch.Tensor, o2: torch.Tensor, lse2: torch.Tensor):
     """flashinfer.cascade.merge_state (v0.2.3, third-party, absent here; call site
     nn/attention/flashinfer_backend.py:437-439): combine two partial attention results over

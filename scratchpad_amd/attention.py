@@ -118,6 +118,12 @@ class HipAttnBackend(AttentionBackend):
     # LlamaAttention may hand rotary + KV store to the backend as one kernel (sp_rotary_embedding
     # with pool arguments); set False to keep the reference's two-step order
     fused_rope_kv_store = True
+    # the decode kernel merges its split partials itself (plans carry arrival counters); False = merge launch
+    fused_split_merge = True
+    # True: every plan's overflow word is read back right after it is built (one device sync per step: tests,
+    # debugging).  False: the 16-byte header is copied to pinned memory asynchronously and checked when the
+    # NEXT plan is built, or by check_plans() - an understated seq_lens_sum raises one step late instead of never
+    strict_plan_check = False
 
     def __init__(self, model_runner):
         super().__init__()
@@ -144,6 +150,9 @@ class HipAttnBackend(AttentionBackend):
         self._graph_ws = None          # graph replay: ONE partials workspace / plan-buffer triple for all buckets
         self._graph_plans = None
         self._extend_plan = None       # int32 work list of the current extend step (sp_extend_plan)
+        self._plan_groups = self.num_kv_head if self.fused_split_merge else 0
+        self._plan_checks = []         # (pinned header copy, event, max_slots) of plans not yet checked
+        self._plan_hosts = []          # pinned buffers + events to reuse
 
     # ---------------------------------------------------------------- launch planning
     def _head_groups(self, dtype: torch.dtype) -> int:
@@ -191,15 +200,47 @@ class HipAttnBackend(AttentionBackend):
             else:                          # graph replay: the captured launch's capacity is fixed
                 slots = max_slots
                 chunk = self._fit_chunk(chunk, bs, kv_tokens, max_len, slots)
-            need = _native.decode_plan_bytes(bs, max_len, chunk, slots) // 4
+            need = _native.decode_plan_bytes(bs, max_len, chunk, slots, self._plan_groups) // 4
             if plans[i].numel() < need:
                 plans[i] = torch.empty(need, dtype=torch.int32, device=self.device)
-            _native.decode_plan(plans[i], lens, max_len, chunk, slots)
+            _native.decode_plan(plans[i], lens, max_len, chunk, slots, self._plan_groups)
+            self._watch_plan(plans[i], slots)
             # third field: the smallest split size this plan buffer may carry when the launch runs - the
             # step's own chunk (eager), MIN_CHUNK under graph replay (a later step's plan may use any size)
             out.append((plans[i], slots, chunk if max_slots is None else self.MIN_CHUNK))
             need_slots = max(need_slots, slots)
         return tuple(out), need_slots
+
+    # ---------------------------------------------------------------- plan overflow (an understated seq_lens_sum)
+    def _watch_plan(self, plan: torch.Tensor, slots: int) -> None:
+        """The plan kernel records how many items the device-side lengths need; more than the launch covers means
+        splits were dropped (wrong logits).  The header comes back through a 16-byte asynchronous copy: earlier
+        plans whose copy has landed are checked here, this one at the next plan or in check_plans()."""
+        self.check_plans(wait=len(self._plan_checks) >= 64)      # (a bound on the copies in flight)
+        host, ev = self._plan_hosts.pop() if self._plan_hosts else (
+            torch.empty(_native.PLAN_HEADER_WORDS, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+        host.copy_(plan[:_native.PLAN_HEADER_WORDS], non_blocking=True)
+        ev.record()
+        self._plan_checks.append((host, ev, slots))
+        if self.strict_plan_check:
+            self.check_plans(wait=True)
+
+    def check_plans(self, wait: bool = True) -> None:
+        """Raise RuntimeError if a decode plan built so far was cut short.  wait=False looks only at header copies
+        that have already completed (no synchronisation)."""
+        pending = []
+        err = None
+        for host, ev, slots in self._plan_checks:
+            if wait:
+                ev.synchronize()
+            elif not ev.query():
+                pending.append((host, ev, slots))
+                continue
+            err = err or _native.decode_plan_overflow(host.tolist(), slots)
+            self._plan_hosts.append((host, ev))
+        self._plan_checks = pending
+        if err:
+            raise RuntimeError(err)
 
     def _windows(self, bs, seq_lens, seq_lens_sum, encoder_lens, encoder_sum):
         """(lens, bound on their sum) of the three kv windows of a decode step"""
@@ -266,7 +307,7 @@ class HipAttnBackend(AttentionBackend):
         self._graph_ws = torch.empty(_native.decode_workspace_bytes(max_bs, self.num_head, self.v_head_dim,
                                                                     self.cuda_graph_max_seq_len, self.MIN_CHUNK, slots),
                                      dtype=torch.uint8, device=self.device)
-        n = _native.decode_plan_bytes(max_bs, self.cuda_graph_max_seq_len, self.MIN_CHUNK, slots) // 4
+        n = _native.decode_plan_bytes(max_bs, self.cuda_graph_max_seq_len, self.MIN_CHUNK, slots, self._plan_groups) // 4
         self._graph_plans = [torch.empty(n, dtype=torch.int32, device=self.device) for _ in range(3)]
         self._graph_max_bs = max_bs
         if self.sliding_window_size is not None:
@@ -421,5 +462,6 @@ class HipAttnBackend(AttentionBackend):
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), kb, vb,
             forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices, seq_lens,
             layer.scaling, layer.logit_cap, max_len, chunk, ws, kv_start, plan,
-            k_scale=k_scale, v_scale=v_scale, max_slots=slots)
+            k_scale=k_scale, v_scale=v_scale, max_slots=slots,
+            plan_fuse_groups=self._plan_groups if layer.tp_k_head_num <= self._plan_groups else 0)
         return o

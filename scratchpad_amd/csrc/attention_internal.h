@@ -25,21 +25,33 @@ struct DecodeArgs {
   float* part_o;    // [Hq, max_slots, D]   slot of (request b, split c): slot0[b] + c (a request's splits are adjacent)
   float* part_lse;  // [Hq, max_slots]      (log2 domain)
   int kv8;              // 1: the pool holds fp8 e5m2 bytes (kv_stride in bytes); 16-bit q/out only
-  // optional, from sp_decode_plan: [count, chunk, slot0[bs], (b, c) x count].  The CHUNK is part of the
-  // plan (device memory), so a captured launch follows whatever split size the step's plan was built
-  // with; slot0[b] = first partial slot of request b (exclusive scan of its split count).
+  // optional, from sp_decode_plan: [count, chunk, needed, 0 | slot0[bs] | (b, c) x max_slots | arrival counters].
+  // The CHUNK is part of the plan (device memory), so a captured launch follows whatever split size the step's
+  // plan was built with; slot0[b] = first partial slot of request b (exclusive scan of its split count);
+  // needed = the item count BEFORE the cut at max_slots (needed > count: the host's bound on sum(seq_lens) was
+  // broken and items were dropped - the host checks this word, see sp_decode_plan).
   const int32_t* plan;
+  // > 0: the plan carries fuse_groups arrival counters per request behind its items (zeroed by sp_decode_plan, reset
+  // by the last arriver): the matrix-core kernel merges a request's splits itself - the workgroup (wave, where a wave
+  // owns its heads) whose partials arrive last combines them - and no merge kernel is launched.  0: separate merge.
+  int fuse_groups;
 };
+
+static constexpr int kPlanHdr = 4;   // int32 words in front of slot0[]
+
+__device__ __forceinline__ int32_t* decode_plan_counters(const DecodeArgs& a) {
+  return const_cast<int32_t*>(a.plan) + kPlanHdr + a.bs + 2 * (int64_t)a.max_slots;
+}
 
 // (request, split) of work item `item`, the split size, and the request's first partial slot
 __device__ __forceinline__ bool decode_item(const DecodeArgs& a, int item, int& b, int& c, int& chunk, int& slot0) {
   if (a.plan) {
     if (item >= a.plan[0]) return false;
     chunk = a.plan[1];
-    const int32_t* items = a.plan + 2 + a.bs;
+    const int32_t* items = a.plan + kPlanHdr + a.bs;
     b = items[2 * item];
     c = items[2 * item + 1];
-    slot0 = a.plan[2 + b];
+    slot0 = a.plan[kPlanHdr + b];
   } else {
     chunk = a.chunk;
     c = item % a.num_splits;
@@ -47,6 +59,70 @@ __device__ __forceinline__ bool decode_item(const DecodeArgs& a, int item, int& 
     slot0 = b * a.num_splits;
   }
   return true;
+}
+
+// Combine the split partials of U (request, q head) pairs by their log2-sum-exp: one wave, lane = output elements
+// lane, lane + 64 (D = 128).  The partials of up to 16 splits (log-sum-exp and the lane's output elements) are
+// loaded in one go - a single memory round trip instead of a max pass followed by a dependent accumulate pass -
+// and merged online across groups of 16.  Shared by decode_merge_kernel and by the fused merge of
+// decode_mfma_kernel, so that both produce the same bits (every product-sum is an explicit fma).
+// Partials are laid out [Hq][slot][D]: a request's splits are consecutive slots, so one (request, head)'s partials
+// are one contiguous run (with [slot][Hq][D] the merge read 512-byte pieces 16 KiB apart: 10.5 us instead of 6.8).
+template <typename Tag, int D, int U>
+__device__ __forceinline__ void decode_merge_rows(const DecodeArgs& a, int b, const int (&h)[U], int lane,
+                                                  int nsplit, int slot0) {
+  typedef Elem<Tag> E;
+  constexpr int PER = D / 64;
+  constexpr int GRP = 16;
+  constexpr float kFloor = -1.0e30f;
+  const float* lse[U];
+  const float* po[U];
+  float o[U][PER], W[U], M[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    lse[u] = a.part_lse + (int64_t)h[u] * a.max_slots + slot0;
+    po[u] = a.part_o + ((int64_t)h[u] * a.max_slots + slot0) * D;
+    W[u] = 0.f;
+    M[u] = kFloor;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) o[u][e] = 0.f;
+  }
+  for (int c0 = 0; c0 < nsplit; c0 += GRP) {
+    float ls[U][GRP], pv[U][GRP][PER];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int c = 0; c < GRP; ++c) {
+        const bool live = c0 + c < nsplit;
+        const int cc = live ? c0 + c : c0;               // clamped: the load stays in bounds
+        ls[u][c] = live ? lse[u][cc] : kFloor;
+#pragma unroll
+        for (int e = 0; e < PER; ++e) pv[u][c][e] = po[u][(int64_t)cc * D + e * 64 + lane];
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float Mg = M[u];
+#pragma unroll
+      for (int c = 0; c < GRP; ++c) Mg = fmaxf(Mg, ls[u][c]);
+      const float rescale = __builtin_amdgcn_exp2f(M[u] - Mg);   // 0 on the first group (M = -1e30)
+      W[u] *= rescale;
+#pragma unroll
+      for (int e = 0; e < PER; ++e) o[u][e] *= rescale;
+#pragma unroll
+      for (int c = 0; c < GRP; ++c) {
+        const float w = c0 + c < nsplit ? __builtin_amdgcn_exp2f(ls[u][c] - Mg) : 0.f;
+        W[u] += w;
+#pragma unroll
+        for (int e = 0; e < PER; ++e) o[u][e] = __builtin_fmaf(w, pv[u][c][e], o[u][e]);
+      }
+      M[u] = Mg;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int e = 0; e < PER; ++e)
+      E::store(a.out, (int64_t)b * a.o_stride + (int64_t)h[u] * D + e * 64 + lane, o[u][e] / W[u] * a.out_scale);
 }
 
 // decode_attention.hip: launch the split-KV decode kernel (+ merge when num_splits > 1)

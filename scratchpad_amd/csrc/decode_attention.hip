@@ -287,79 +287,44 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeArgs a) {
   }
 }
 
-// one wave per (request, q head): combine the split partials by their log2-sum-exp.  The partials of
-// up to 16 splits (log-sum-exp and the lane's output elements) are loaded in one go - a single memory
-// round trip instead of a max pass followed by a dependent accumulate pass - and merged online across
-// groups of 16 (the launch is latency-bound at small batch: 9 us for a few KB).
+// one wave per (request, q head): combine the split partials by their log2-sum-exp (decode_merge_rows).  The launch
+// is latency-bound at small batch (9 us for a few KB); the matrix-core kernel does this itself when the plan
+// carries arrival counters (DecodeArgs::fuse_groups).
 template <typename Tag, int D>
 __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
-  typedef Elem<Tag> E;
   const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pair >= a.bs * a.Hq) return;
   const int lane = threadIdx.x & 63;
   const int b = pair / a.Hq, h = pair - b * a.Hq;
   const int seq = min((int)load_idx(a.seq_lens, b, a.idx64), a.max_len);
   const int chunk = a.plan ? a.plan[1] : a.chunk;
-  const int slot0 = a.plan ? a.plan[2 + b] : b * a.num_splits;
+  const int slot0 = a.plan ? a.plan[kPlanHdr + b] : b * a.num_splits;
   int nsplit = (seq + chunk - 1) / chunk;
   if (nsplit <= 1) return;  // written directly by the attention kernel (or empty row)
   nsplit = min(nsplit, a.max_slots - slot0);   // never past the workspace (a plan cut short by a broken bound)
   if (nsplit < 1) return;
-  // split c of this (request, head): slot slot0 + c of head h, partials laid out [Hq][slot][D] - a request's splits are
-  // consecutive slots, so one (request, head)'s partials are one contiguous run (with [slot][Hq][D] the merge read
-  // 512-byte pieces 16 KiB apart and took 10.5 us instead of 6.8 at the headline shape)
-  const int64_t sstride = 1;
-  const float* lse = a.part_lse + (int64_t)h * a.max_slots + slot0;
-  const float* po = a.part_o + ((int64_t)h * a.max_slots + slot0) * D;
-  constexpr int PER = D / 64;
-  constexpr int GRP = 16;
-  float o[PER], W = 0.f, M = kNegBig;
-#pragma unroll
-  for (int e = 0; e < PER; ++e) o[e] = 0.f;
-  for (int c0 = 0; c0 < nsplit; c0 += GRP) {
-    float ls[GRP], pv[GRP][PER];
-#pragma unroll
-    for (int c = 0; c < GRP; ++c) {
-      const bool live = c0 + c < nsplit;
-      const int cc = live ? c0 + c : c0;               // clamped: the load stays in bounds
-      ls[c] = live ? lse[(int64_t)cc * sstride] : kNegBig;
-#pragma unroll
-      for (int e = 0; e < PER; ++e) pv[c][e] = po[(int64_t)cc * sstride * D + e * 64 + lane];
-    }
-    float Mg = M;
-#pragma unroll
-    for (int c = 0; c < GRP; ++c) Mg = fmaxf(Mg, ls[c]);
-    const float rescale = fast_exp2(M - Mg);           // 0 on the first group (M = -1e30)
-    W *= rescale;
-#pragma unroll
-    for (int e = 0; e < PER; ++e) o[e] *= rescale;
-#pragma unroll
-    for (int c = 0; c < GRP; ++c) {
-      const float w = c0 + c < nsplit ? fast_exp2(ls[c] - Mg) : 0.f;
-      W += w;
-#pragma unroll
-      for (int e = 0; e < PER; ++e) o[e] += w * pv[c][e];
-    }
-    M = Mg;
-  }
-#pragma unroll
-  for (int e = 0; e < PER; ++e)
-    E::store(a.out, (int64_t)b * a.o_stride + (int64_t)h * D + e * 64 + lane, o[e] / W * a.out_scale);
+  const int hs[1] = {h};
+  decode_merge_rows<Tag, D, 1>(a, b, hs, lane, nsplit, slot0);
 }
 
-// Build the step's split plan: plan[0] = number of non-empty (request, split) items, plan[1] = chunk,
-// plan[2 + b] = first partial slot of request b (exclusive scan of its split count), then the items
-// (b, c) from plan[2 + bs].  One workgroup; requests in tiles of 256 with a running offset.  Items are
+// Build the step's split plan: plan[0] = number of non-empty (request, split) items the plan lists, plan[1] = chunk,
+// plan[2] = the number the lengths NEED (> plan[0]: items were cut at max_items because the host's bound on
+// sum(seq_lens) does not hold - an error the host reports, sp_decode_plan), plan[3] = 0,
+// plan[4 + b] = first partial slot of request b (exclusive scan of its split count), the items (b, c) from
+// plan[4 + bs], and behind the max_items item pairs bs x fuse_groups arrival counters, zeroed here, for the
+// attention kernel's own merge of the splits.  One workgroup; requests in tiles of 256 with a running offset.  Items are
 // emitted longest-first: all full splits, then the ragged last splits in four length classes (longest
 // quarter first), so the launch ends on its shortest items.  The chunk travels IN the plan: the
 // attention and merge kernels read it from there, so one captured launch serves any split size.
 __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ plan,
                                                            const void* __restrict__ seq_lens,
                                                            int idx64, int bs, int chunk, int max_len,
-                                                           int max_items) {
+                                                           int max_items, int fuse_groups) {
   __shared__ int s_scan[256];
   __shared__ int s_base;
-  int32_t* items = plan + 2 + bs;
+  int32_t* items = plan + kPlanHdr + bs;
+  int32_t* counters = items + 2 * (int64_t)max_items;
+  for (int i = threadIdx.x; i < bs * fuse_groups; i += 256) counters[i] = 0;
   // pass -1: slot0[b]; pass 0: full splits; passes 1..4: ragged tails by length class
   for (int pass = -1; pass < 5; ++pass) {
     if (pass <= 0) {
@@ -390,7 +355,7 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ 
       }
       const int base = s_base + s_scan[threadIdx.x] - mine;
       if (pass == -1) {
-        if (b < bs) plan[2 + b] = base;
+        if (b < bs) plan[kPlanHdr + b] = base;
       } else {
         // (the host sizes max_items from its own bound on sum(seq_lens); lengths that break that bound
         // lose their surplus items here, and the kernels skip slots >= max_items, instead of writing past
@@ -408,6 +373,8 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ 
   if (threadIdx.x == 0) {
     plan[0] = min(s_base, max_items);
     plan[1] = chunk;
+    plan[2] = s_base;
+    plan[3] = 0;
   }
 }
 
@@ -508,11 +475,11 @@ int run_decode(const DecodeArgs& a, int head_dim, int group, int dtype, hipStrea
   if (a.kv8) {                       // fp8 pool: matrix-core kernel only
     if (a.Hq / a.Hkv > 16) return SP_ERR_UNSUPPORTED;
     const int rc = run_decode_mfma(a, head_dim, dtype, st);
-    return rc == SP_OK ? run_decode_merge(a, head_dim, dtype, st) : rc;
+    return rc == SP_OK && a.fuse_groups == 0 ? run_decode_merge(a, head_dim, dtype, st) : rc;
   }
   if (group > 8 || decode_kernel_choice(a.Hq / a.Hkv, dtype) == 2) {   // groups 9..16: matrix-core kernel only
     const int rc = run_decode_mfma(a, head_dim, dtype, st);
-    if (rc == SP_OK) return run_decode_merge(a, head_dim, dtype, st);
+    if (rc == SP_OK) return a.fuse_groups == 0 ? run_decode_merge(a, head_dim, dtype, st) : SP_OK;   // fused: the kernel merged
     if (rc != SP_ERR_UNSUPPORTED) return rc;
   }
   SP_DISPATCH_DTYPE(dtype, return (dispatch_dim<Tag>(a, head_dim, group, st)));
@@ -559,19 +526,21 @@ extern "C" SP_API int sp_debug_decode_occupancy(int head_dim, int group, int dty
   return decode_occupancy(head_dim, group, dtype);
 }
 
-extern "C" size_t sp_decode_plan_bytes(int batch_size, int64_t max_slots) {
+extern "C" size_t sp_decode_plan_bytes(int batch_size, int64_t max_slots, int fuse_groups) {
   if (batch_size <= 0 || max_slots <= 0) return 16;
-  return (size_t)(2 + (int64_t)batch_size + 2 * max_slots) * sizeof(int32_t);
+  if (fuse_groups < 0) fuse_groups = 0;
+  return (size_t)(kPlanHdr + (int64_t)batch_size + 2 * max_slots + (int64_t)batch_size * fuse_groups) * sizeof(int32_t);
 }
 
 extern "C" int sp_decode_plan(int32_t* plan, size_t plan_bytes, const void* seq_lens, int idx64,
                               int batch_size, int64_t max_seq_len, int chunk, int64_t max_slots,
-                              void* stream) {
+                              int fuse_groups, void* stream) {
   SP_CHECK_ARG(plan && seq_lens && batch_size >= 0 && chunk >= 4 && chunk % 4 == 0);
   SP_CHECK_ARG(max_seq_len >= 0 && max_seq_len <= 0x7fffffffLL && max_slots > 0 && max_slots <= 0x3fffffffLL);
-  if (plan_bytes < sp_decode_plan_bytes(batch_size, max_slots)) return SP_ERR_WORKSPACE;
+  SP_CHECK_ARG(fuse_groups >= 0 && (int64_t)batch_size * fuse_groups <= 0x3fffffffLL);
+  if (plan_bytes < sp_decode_plan_bytes(batch_size, max_slots, fuse_groups)) return SP_ERR_WORKSPACE;
   decode_plan_kernel<<<dim3(1), 256, 0, (hipStream_t)stream>>>(plan, seq_lens, idx64, batch_size,
-                                                               chunk, (int)max_seq_len, (int)max_slots);
+                                                               chunk, (int)max_seq_len, (int)max_slots, fuse_groups);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
@@ -584,7 +553,7 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
                                    int64_t q_stride, int64_t out_stride, int64_t kv_buffer_stride,
                                    float sm_scale, float logit_cap, float k_scale, float v_scale,
                                    int64_t max_seq_len, int chunk, int64_t max_slots, void* workspace,
-                                   size_t workspace_bytes, const int32_t* plan, int dtype,
+                                   size_t workspace_bytes, const int32_t* plan, int plan_fuse_groups, int dtype,
                                    int kv_dtype, void* stream) {
   SP_CHECK_ARG(out && q && k_buffer && v_buffer && req_to_token && req_pool_indices && seq_lens);
   SP_CHECK_ARG(batch_size >= 0 && num_q_heads > 0 && num_kv_heads > 0 && head_dim > 0);
@@ -628,6 +597,12 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
   a.chunk = chunk; a.num_splits = (int)S; a.max_slots = (int)max_slots; a.plan = plan; a.kv8 = kv8 ? 1 : 0;
   a.hh_shift = decode_heads_per_load_shift(num_kv_heads, head_dim, dtype, &a.head_groups);
   a.part_o = nullptr; a.part_lse = nullptr;
+  // the kernel merges the splits itself when the plan carries one arrival counter per (request, kv head) - what
+  // sp_decode_plan was given as fuse_groups; the partials are then addressed through a buffer descriptor (32-bit offsets)
+  SP_CHECK_ARG(plan_fuse_groups >= 0 && (plan_fuse_groups == 0 || (plan && plan_fuse_groups >= num_kv_heads)));
+  a.fuse_groups = plan ? plan_fuse_groups : 0;
+  if (a.fuse_groups > 0 &&
+      sp_decode_attention_workspace_bytes(max_slots, num_q_heads, head_dim) >= 0x7fffffffULL) a.fuse_groups = 0;
   if (S > 1) {
     const size_t need = sp_decode_attention_workspace_bytes(max_slots, num_q_heads, head_dim);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) return SP_ERR_WORKSPACE;

@@ -10,7 +10,7 @@ and the outputs produced by the reference's own code:
     (scratchpad/memory/pool.py),
   * ``compute_position_triton/torch`` (scratchpad/model_executor/forward_info.py),
   * ``write_req_to_token_pool_triton`` (scratchpad/scheduler/schedule_batch.py),
-  * the in-tree Triton kernels ``decode_attention_fwd`` / ``extend_attention_fwd``
+  * the in-tree Triton kernels ``decode_attention_fwd`` / ``extend_attention_fwd`` / ``context_attention_fwd``
     (scratchpad/nn/attention/triton_attn/) executed by the Triton interpreter,
   * the full reference ``LlamaForCausalLM`` (2 layers, tiny) for prefill + decode logits.
 
@@ -332,6 +332,38 @@ def gen_extend():
                     f"c{i}_o": o})
     out["num_cases"] = np.int64(len(cases))
     _save("extend_attention", **out)
+
+
+def gen_prefill_attention():
+    """context_attention_fwd (nn/attention/triton_attn/prefill_attention.py:125-163) under the Triton interpreter:
+    cache-less, CAUSAL, variable-length self-attention - sequence b's queries, keys and values are rows
+    [b_start_loc[b], +b_seq_len[b]) of q / k / v; sm_scale = 1/sqrt(head dim) is fixed inside the function."""
+    from scratchpad.nn.attention.triton_attn.prefill_attention import context_attention_fwd
+
+    g = torch.Generator().manual_seed(131)
+    out = {}
+    cases = [
+        # Hq, Hkv, D, seq_lens
+        (8, 2, 64, [5, 70, 131]),          # GQA group 4, D=64; a sequence longer than the kernel's 128-row block
+        (8, 2, 128, [1, 129, 33]),         # D=128, a one-token sequence, one that crosses a block by 1
+        (8, 1, 128, [200, 3]),             # group 8
+        (4, 4, 64, [64, 17, 128]),         # MHA, exact block multiples
+    ]
+    for i, (Hq, Hkv, D, lens) in enumerate(cases):
+        seq = torch.tensor(lens, dtype=torch.int32)
+        start = torch.zeros(len(lens), dtype=torch.int32)
+        start[1:] = torch.cumsum(seq[:-1], 0)
+        T = int(seq.sum())
+        q = _randn(T, Hq, D, generator=g)
+        k = _randn(T, Hkv, D, generator=g)
+        v = _randn(T, Hkv, D, generator=g)
+        o = torch.zeros(T, Hq, D)
+        context_attention_fwd(q, k, v, o, start, seq, int(seq.max()))
+        out.update({f"c{i}_q": q, f"c{i}_k": k, f"c{i}_v": v, f"c{i}_b_start_loc": start, f"c{i}_b_seq_len": seq,
+                    f"c{i}_o": o})
+        print("prefill case", i, float(o.abs().max()))
+    out["num_cases"] = np.int64(len(cases))
+    _save("prefill_attention", **out)
 
 
 def gen_tiny_llama():
@@ -853,8 +885,10 @@ def gen_mllama_vision():
     shape on CPU, tiny config: 28x28 images, 14x14 patches (4 + class token = 5 patches, padded to 8),
     hidden 32, 2 heads (head size 16), 3 local + 2 global (gated) layers, up to 4 tiles.
     Two batches: all tiles real / some tiles padding, so both branches of the tile mask are recorded.
-    Also a stand-alone VisionAttention call with cu_seqlens (the context_attention_fwd path) computed
-    densely here per sequence, since that Triton kernel is CUDA-only."""
+    (The cache-less varlen kernel behind VisionTritonAttention, context_attention_fwd, does run under the Triton
+    interpreter - but it is causal only, and its vision caller passes an is_causal argument it does not accept
+    (vision.py:315, 361): its own fixture is prefill_attention.npz, the CAUSAL cache-less path; the non-causal
+    form VisionAttention needs has no reference output to record.)"""
     import transformers.models.mllama.configuration_mllama as cm
     import scratchpad.nn.models.llama.mllama as M
     import torch.distributed as dist
@@ -994,6 +1028,7 @@ GENERATORS = {
     "positions": gen_positions, "decode_attention": gen_decode, "extend_attention": gen_extend,
     "tiny_llama": gen_tiny_llama, "tiny_mllama": gen_tiny_mllama, "radix_cache": gen_radix_cache,
     "sampling": gen_sampling, "mllama_vision": gen_mllama_vision, "input_logprobs": gen_input_logprobs,
+    "prefill_attention": gen_prefill_attention,
 }
 
 if __name__ == "__main__":

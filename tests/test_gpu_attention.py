@@ -33,7 +33,9 @@ def decode_kernel(request, nat):
 
 
 def run_decode(nat, p, scale, cap=0.0, chunk=64, max_len=None, kv_start=None, idx_dtype=None,
-               use_plan=True):
+               use_plan=True, fuse=True):
+    """use_plan + fuse (what HipAttnBackend does): the plan carries arrival counters and the matrix-core kernel merges
+    its splits itself; fuse=False or no plan: the separate merge launch"""
     q = p["q"]
     bs, Hq, D = q.shape
     seq, req = p["seq_lens"], p["req_pool_indices"]
@@ -44,11 +46,14 @@ def run_decode(nat, p, scale, cap=0.0, chunk=64, max_len=None, kv_start=None, id
     ws = torch.empty(nat.decode_workspace_bytes(bs, Hq, D, max_len, chunk), dtype=torch.uint8, device=DEV)
     o = torch.full_like(q, float("nan"))
     plan = None
+    groups = p["k_buffer"].shape[1] if (use_plan and fuse) else 0
     if use_plan:   # the per-step split plan the backend builds in init_forward_metadata
-        plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk) // 4, dtype=torch.int32, device=DEV)
-        nat.decode_plan(plan, seq, max_len, chunk)
+        plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, fuse_groups=groups) // 4, dtype=torch.int32, device=DEV)
+        nat.decode_plan(plan, seq, max_len, chunk, fuse_groups=groups)
     nat.decode_attention(o, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], req, seq, scale, cap,
-                         max_len, chunk, ws, kv_start, plan)
+                         max_len, chunk, ws, kv_start, plan, plan_fuse_groups=groups)
+    if groups:   # the last arriver of every (request, kv head) has put its counter back to zero
+        assert int(plan[4 + bs + 2 * nat.decode_plan_slots(bs, max_len, chunk):].abs().sum()) == 0
     return o
 
 
@@ -209,10 +214,11 @@ def test_decode_plan_is_exact_and_changes_nothing(nat):
                       if l % chunk and ((l % chunk) * 4 - 1) // chunk == cls]
     n, nb = pl[0], len(lens)
     assert n == len(want_full) + len(want_tail) and pl[1] == chunk
+    assert pl[2] == n and pl[3] == 0, "word 2: the items the lengths need (= listed: no overflow)"
     # slot0[b] = first partial slot of request b: the exclusive scan of the requests' split counts
     nsplit = [-(-l // chunk) for l in lens]
-    assert pl[2:2 + nb] == [sum(nsplit[:b]) for b in range(nb)]
-    got = [(pl[2 + nb + 2 * i], pl[3 + nb + 2 * i]) for i in range(n)]
+    assert pl[4:4 + nb] == [sum(nsplit[:b]) for b in range(nb)]
+    got = [(pl[4 + nb + 2 * i], pl[5 + nb + 2 * i]) for i in range(n)]
     assert got == want_full + want_tail
     # 700 requests: the scan crosses several 256-request tiles
     gen = torch.Generator().manual_seed(17)
@@ -221,8 +227,8 @@ def test_decode_plan_is_exact_and_changes_nothing(nat):
     nat.decode_plan(plan, seq.to(DEV), 900, 128)
     pl = plan.cpu()
     assert int(pl[0]) == int(((seq + 127) // 128).sum())
-    assert torch.equal(pl[2:702].long(), torch.cumsum((seq + 127) // 128, 0) - (seq + 127) // 128)
-    items = pl[702:702 + 2 * int(pl[0])].view(-1, 2)
+    assert torch.equal(pl[4:704].long(), torch.cumsum((seq + 127) // 128, 0) - (seq + 127) // 128)
+    items = pl[704:704 + 2 * int(pl[0])].view(-1, 2)
     key = items[:, 0].long() * 100 + items[:, 1].long()
     want = torch.cat([b * 100 + torch.arange((int(l) + 127) // 128) for b, l in enumerate(seq.tolist())])
     assert torch.equal(torch.sort(key).values, torch.sort(want).values), "every item exactly once"
@@ -267,6 +273,10 @@ def test_decode_split_size_travels_in_the_plan(nat, dtype):
     plan = torch.empty(nat.decode_plan_bytes(bs, ctx, 64, slots) // 4, dtype=torch.int32, device=DEV)
     nat.decode_plan(plan, seq, ctx, 64, slots)
     assert int(plan[0]) == slots
+    # ... and the plan says so: word 2 is what the lengths need, which the host compares with the capacity
+    assert int(plan[2]) == sum(-(-l // 64) for l in lens) > slots
+    assert "overflow" in nat.decode_plan_overflow(plan[:4].tolist(), slots)
+    assert nat.decode_plan_overflow(plan[:4].tolist(), int(plan[2])) is None
     o = torch.zeros_like(q)
     nat.decode_attention(o, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], req, seq, 0.11, 0.0,
                          ctx, 64, ws[:nat.decode_workspace_bytes(bs, Hq, D, ctx, 64, slots)], None, plan, max_slots=slots)
@@ -741,17 +751,23 @@ def test_decode_plan_fuzz_planned_equals_static_bit_for_bit(nat, seed):
         nat.decode_attention(o_static, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], r_, s_, 0.09, 0.0,
                              max_len, chunk, ws, k0, None)
         slots = nat.decode_plan_slots(bs, max_len, chunk, kv_tokens=int(lens.sum()))
-        plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, slots) // 4, dtype=torch.int32, device=DEV)
-        nat.decode_plan(plan, s_, max_len, chunk, slots)
         nsplit = (lens + chunk - 1) // chunk
-        host = plan.cpu()
-        assert int(host[0]) == int(nsplit.sum()) <= slots and int(host[1]) == chunk
-        assert torch.equal(host[2:2 + bs].long(), torch.cumsum(nsplit, 0) - nsplit)
         ws2 = torch.empty(nat.decode_workspace_bytes(bs, Hq, D, max_len, chunk, slots), dtype=torch.uint8, device=DEV)
-        o_plan = torch.zeros_like(q)
-        nat.decode_attention(o_plan, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], r_, s_, 0.09, 0.0,
-                             max_len, chunk, ws2, k0, plan, max_slots=slots)
-        assert torch.isfinite(o_plan.float()).all() and torch.equal(o_plan, o_static), (seed, idx_dtype)
+        # groups = 0: the merge launch; groups = Hkv: the attention kernel merges (launched three times on one plan:
+        # the arrival counters are put back by the last arriver, as between the layers of a step)
+        for groups in (0, Hkv):
+            plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, slots, groups) // 4, dtype=torch.int32, device=DEV)
+            nat.decode_plan(plan, s_, max_len, chunk, slots, groups)
+            host = plan.cpu()
+            assert int(host[0]) == int(host[2]) == int(nsplit.sum()) <= slots and int(host[1]) == chunk
+            assert torch.equal(host[4:4 + bs].long(), torch.cumsum(nsplit, 0) - nsplit)
+            for rep in range(3 if groups else 1):
+                ws2.fill_(0x7f)                                # stale partials of "another layer"
+                o_plan = torch.zeros_like(q)
+                nat.decode_attention(o_plan, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], r_, s_, 0.09, 0.0,
+                                     max_len, chunk, ws2, k0, plan, max_slots=slots, plan_fuse_groups=groups)
+                assert torch.isfinite(o_plan.float()).all() and torch.equal(o_plan, o_static), (seed, idx_dtype, groups, rep)
+            assert int(plan[4 + bs + 2 * slots:].abs().sum()) == 0, "arrival counters are back at zero"
     # and against the oracle on a handful of rows (the longest, an empty one, a one-token one)
     rows = [0, int((lens == 0).nonzero()[0]), int((lens == 1).nonzero()[0]), bs - 1]
     c = cpu(p)
@@ -760,6 +776,45 @@ def test_decode_plan_fuzz_planned_equals_static_bit_for_bit(nat, seed):
     live = [r for r in rows if int(lens[r]) > 0]
     assert_close(o_plan[live], ref[live], torch.bfloat16, what=f"decode fuzz seed {seed}")
     assert float(o_plan[rows[1]].float().abs().max()) == 0.0, "an empty row is left untouched"
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("Hq,Hkv,D", [(8, 1, 128), (16, 2, 128), (16, 1, 128), (32, 8, 128), (4, 4, 128), (24, 4, 64),
+                                      (6, 2, 64)])
+def test_decode_fused_merge_equals_the_merge_launch_bit_for_bit(nat, dt, Hq, Hkv, D):
+    """ABI 6: with arrival counters in the plan the matrix-core kernel combines a request's split partials itself (the
+    wave - head-per-wave form, Hkv % 4 == 0 - or the workgroup whose partials arrive last).  Same order, same code as
+    the merge launch: the same bits, on ragged batches (uneven load: arrivals out of order), with more than 16 splits
+    per request (the merge's online groups), on a workspace full of another launch's partials, launch after launch
+    on one plan."""
+    dtype = DTYPES[dt]
+    g = torch.Generator().manual_seed(Hq * 131 + Hkv)
+    bs, chunk, max_len = 96, 64, 2600
+    lens = torch.randint(1, 700, (bs,), generator=g)
+    lens[:4] = torch.tensor([2600, 1025, 64, 65])          # 41 and 17 splits; one split; two
+    p = paged_problem(300 + Hq, bs, Hq, Hkv, D, lens.tolist(), dtype, DEV)
+    q, seq, req = p["q"], p["seq_lens"], p["req_pool_indices"]
+    slots = nat.decode_plan_slots(bs, max_len, chunk, kv_tokens=int(lens.sum()))
+    ws = torch.empty(nat.decode_workspace_bytes(bs, Hq, D, max_len, chunk, slots), dtype=torch.uint8, device=DEV)
+    outs = {}
+    for groups in (0, Hkv, Hkv + 3):                         # more counters than kv heads is allowed
+        plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, slots, groups) // 4, dtype=torch.int32, device=DEV)
+        nat.decode_plan(plan, seq, max_len, chunk, slots, groups)
+        for rep in range(4 if groups else 1):
+            ws.fill_(0x7f if rep % 2 else 0)
+            o = torch.full_like(q, float("nan"))
+            nat.decode_attention(o, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], req, seq, D ** -0.5, 0.0,
+                                 max_len, chunk, ws, None, plan, max_slots=slots, plan_fuse_groups=groups)
+            outs[(groups, rep)] = o
+        assert int(plan[4 + bs + 2 * slots:].abs().sum()) == 0
+    base = outs[(0, 0)]
+    assert torch.isfinite(base.float()).all()
+    for key, o in outs.items():
+        assert torch.equal(o, base), key
+    check_decode(base, p, D ** -0.5, dtype, f"fused merge {dt} Hq{Hq} Hkv{Hkv} D{D}")
+    with pytest.raises(RuntimeError, match="invalid"):        # fewer counters than kv heads
+        nat.decode_attention(o, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], req, seq, D ** -0.5, 0.0,
+                             max_len, chunk, ws, None, plan, max_slots=slots, plan_fuse_groups=Hkv - 1 if Hkv > 1 else -1)
 
 
 # ----------------------------------------------------------------------------------- extend, 4 waves x 64 rows

@@ -56,9 +56,10 @@ def run_decode(nat, q, kb, vb, r2t, req, seq, chunk, plan=True):
     o = torch.full_like(q, float("nan"))
     pl = None
     if plan:
-        pl = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk) // 4, dtype=torch.int32, device=DEV)
-        nat.decode_plan(pl, seq, max_len, chunk)
-    nat.decode_attention(o, q, kb, vb, r2t, req, seq, SCALE, 0.0, max_len, chunk, ws, None, pl)
+        pl = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, fuse_groups=kb.shape[1]) // 4, dtype=torch.int32, device=DEV)
+        nat.decode_plan(pl, seq, max_len, chunk, fuse_groups=kb.shape[1])         # as HipAttnBackend: fused split merge
+    nat.decode_attention(o, q, kb, vb, r2t, req, seq, SCALE, 0.0, max_len, chunk, ws, None, pl,
+                         plan_fuse_groups=kb.shape[1] if plan else 0)
     return o
 
 

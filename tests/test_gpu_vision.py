@@ -61,6 +61,27 @@ def test_varlen_attention_matches_dense_softmax(dtype, tol, D):
     assert rel(got, torch.einsum("hij,jhd->ihd", p, v[135:199].float())) <= tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_causal_varlen_attention_matches_the_reference_prefill_kernel(dtype):
+    """varlen_attention(causal=True) - sp_extend_attention with no cached prefix - against the outputs of the
+    reference's own cache-less kernel, context_attention_fwd (nn/attention/triton_attn/prefill_attention.py:125-163,
+    run under the Triton interpreter: tests/golden/prefill_attention.npz).  Inputs are on a grid exact in fp16 and
+    bf16; the bound is one unit of the 16-bit attention error model (helpers.attn_error_units)."""
+    from oracle import ops
+    from scratchpad_amd.vision import varlen_attention
+    from tests.helpers import assert_attn_close
+    g = golden.load("prefill_attention")
+    for i in range(int(g["num_cases"])):
+        q, k, v = (torch.from_numpy(g[f"c{i}_{n}"]) for n in ("q", "k", "v"))
+        lens = g[f"c{i}_b_seq_len"].tolist()
+        assert g[f"c{i}_b_start_loc"].tolist() == [sum(lens[:b]) for b in range(len(lens))]
+        got = varlen_attention(q.to(dtype).cuda(), k.to(dtype).cuda(), v.to(dtype).cuda(), lens,
+                               q.shape[-1] ** -0.5, causal=True)
+        aref = ops.context_attention(q, k, v.abs(), torch.from_numpy(g[f"c{i}_b_start_loc"]),
+                                     torch.from_numpy(g[f"c{i}_b_seq_len"]))
+        assert_attn_close(got, torch.from_numpy(g[f"c{i}_o"]), aref, dtype, what=f"causal varlen c{i} {dtype}")
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 3e-3), (torch.bfloat16, 2.5e-2)])
 def test_vision_attention_layer_padded_heads_mask_and_cu_seqlens(dtype, tol):
     """Head size 80 (Mllama's) zero-padded to 128 in the weights; tile-mask semantics; ragged rows."""

@@ -100,6 +100,24 @@ def test_extend_attention(use_contiguous_kv):
         close(o, g[f"c{i}_o"], atol=3e-6)
 
 
+def test_context_attention():
+    """the cache-less causal varlen path against the reference's context_attention_fwd (Triton interpreter run)"""
+    g = golden.load("prefill_attention")
+    for i in range(int(g["num_cases"])):
+        o = ops.context_attention(T(g[f"c{i}_q"]), T(g[f"c{i}_k"]), T(g[f"c{i}_v"]), T(g[f"c{i}_b_start_loc"]),
+                                  T(g[f"c{i}_b_seq_len"]))
+        close(o, g[f"c{i}_o"], atol=3e-6)
+        # the same numbers from the extend oracle with no cached prefix and an identity req_to_token table: the
+        # form scratchpad_amd.vision.varlen_attention(causal=True) hands to sp_extend_attention
+        lens, start = T(g[f"c{i}_b_seq_len"]), T(g[f"c{i}_b_start_loc"])
+        table = torch.arange(int(lens.max())).view(1, -1) + start.view(-1, 1).long()
+        table = table.clamp_(max=int(lens.sum()) - 1).to(torch.int32)
+        D = g[f"c{i}_q"].shape[-1]
+        o2 = ops.extend_attention(T(g[f"c{i}_q"]), T(g[f"c{i}_k"]), T(g[f"c{i}_v"]), table,
+                                  torch.arange(lens.shape[0]), lens.long(), lens, start, D ** -0.5)
+        close(o2, g[f"c{i}_o"], atol=3e-6)
+
+
 def test_merge_state_matches_joint_softmax():
     # flashinfer merge_state is third-party (absent): pinned by the identity
     # attention(K1 u K2) == merge(attention(K1), attention(K2)), which the reference relies on

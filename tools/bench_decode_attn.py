@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--lib", default="", help="diagnostic library under scratchpad_amd/lib")
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--no-plan", action="store_true")
+    ap.add_argument("--no-fuse", action="store_true", help="separate merge launch (default: the attention kernel merges)")
+    ap.add_argument("--interleave", action="store_true",
+                    help="one [P+1, 2, Hkv, D] arena: a token's K and V rows are adjacent (pool.py's layout)")
     ap.add_argument("--gemm", action="store_true", help="interleave a bf16 GEMM between launches (as in a model)")
     a = ap.parse_args()
     if a.lib:
@@ -39,11 +42,17 @@ def main():
            else torch.full((a.bs,), int(a.ctx)))
     total = int(ctx.sum())
     P = total + 1024
-    kb = torch.empty(P + 1, a.Hkv, a.D, dtype=dt, device=dev).normal_(0, 0.5)
-    vb = torch.empty(P + 1, a.Hkv, a.D, dtype=dt, device=dev).normal_(0, 0.5)
-    if a.kv == "fp8":
-        kb = kb.to(torch.float8_e5m2).view(torch.uint8)
-        vb = vb.to(torch.float8_e5m2).view(torch.uint8)
+    if a.interleave:
+        arena = torch.empty(P + 1, 2, a.Hkv, a.D, dtype=dt, device=dev).normal_(0, 0.5)
+        if a.kv == "fp8":
+            arena = arena.to(torch.float8_e5m2).view(torch.uint8)
+        kb, vb = arena[:, 0], arena[:, 1]
+    else:
+        kb = torch.empty(P + 1, a.Hkv, a.D, dtype=dt, device=dev).normal_(0, 0.5)
+        vb = torch.empty(P + 1, a.Hkv, a.D, dtype=dt, device=dev).normal_(0, 0.5)
+        if a.kv == "fp8":
+            kb = kb.to(torch.float8_e5m2).view(torch.uint8)
+            vb = vb.to(torch.float8_e5m2).view(torch.uint8)
     perm = (torch.randperm(P, generator=g) + 1).to(torch.int32)
     r2t = torch.zeros(a.bs, int(ctx.max()) + 8, dtype=torch.int32)
     off = 0
@@ -65,9 +74,12 @@ def main():
         ws = torch.empty(_native.decode_workspace_bytes(a.bs, a.Hq, a.D, max_len, chunk), dtype=torch.uint8, device=dev)
         plan = None
         if not a.no_plan:
-            plan = torch.empty(_native.decode_plan_bytes(a.bs, max_len, chunk) // 4, dtype=torch.int32, device=dev)
-            _native.decode_plan(plan, seq, max_len, chunk)
-        run = lambda: _native.decode_attention(o, q, kb, vb, r2t, req, seq, a.D ** -0.5, 0.0, max_len, chunk, ws, None, plan)
+            groups = 0 if a.no_fuse else a.Hkv
+            plan = torch.empty(_native.decode_plan_bytes(a.bs, max_len, chunk, fuse_groups=groups) // 4, dtype=torch.int32, device=dev)
+            _native.decode_plan(plan, seq, max_len, chunk, fuse_groups=groups)
+        groups = 0 if (a.no_fuse or a.no_plan) else a.Hkv
+        run = lambda: _native.decode_attention(o, q, kb, vb, r2t, req, seq, a.D ** -0.5, 0.0, max_len, chunk, ws, None, plan,
+                                               plan_fuse_groups=groups)
         for _ in range(a.warmup):
             run()
         torch.cuda.synchronize()
