@@ -7,6 +7,7 @@ it reads ``req_to_token`` directly like the Triton backend (no kv_indices materi
 implements the flashinfer backend's encoder-decoder dispatch (cross-attention reads kv slots
 [0, encoder_len); self-attention reads [encoder_len, encoder_len + seq_len)).
 """
+import os
 from abc import ABC, abstractmethod
 from typing import TYPE_CHECKING, Optional
 
@@ -118,8 +119,15 @@ class HipAttnBackend(AttentionBackend):
     # LlamaAttention may hand rotary + KV store to the backend as one kernel (sp_rotary_embedding
     # with pool arguments); set False to keep the reference's two-step order
     fused_rope_kv_store = True
-    # the decode kernel merges its split partials itself (plans carry arrival counters); False = merge launch
-    fused_split_merge = True
+    # the decode kernel can merge its split partials itself (plans with arrival counters: no merge launch).  Measured
+    # (round 4, tools/bench_decode_attn.py and bench.py): the workgroup that stores a partial has to see its stores
+    # acknowledged and then its arrival count returned before it may leave - two memory round trips with the
+    # workgroup's slot held - which costs MORE than the merge launch it saves on launches of several rounds of
+    # workgroups (headline shape 411 vs 396 us) and about the same on one full round (bs 32: 31.6 vs 28.5 us; 70B rank
+    # shape 36.2 vs 36.0); it wins where the whole launch is a few dozen workgroups (bs 1: 17.0 vs 20.0 us).
+    # "auto": fused for batches of at most FUSE_MAX_BS requests; SP_DECODE_FUSE_MERGE=1 / 0 forces it on / off
+    fused_split_merge = os.environ.get("SP_DECODE_FUSE_MERGE", "auto")
+    FUSE_MAX_BS = 8
     # True: every plan's overflow word is read back right after it is built (one device sync per step: tests,
     # debugging).  False: the 16-byte header is copied to pinned memory asynchronously and checked when the
     # NEXT plan is built, or by check_plans() - an understated seq_lens_sum raises one step late instead of never
@@ -150,7 +158,8 @@ class HipAttnBackend(AttentionBackend):
         self._graph_ws = None          # graph replay: ONE partials workspace / plan-buffer triple for all buckets
         self._graph_plans = None
         self._extend_plan = None       # int32 work list of the current extend step (sp_extend_plan)
-        self._plan_groups = self.num_kv_head if self.fused_split_merge else 0
+        # arrival counters every plan carries (their use is decided per launch: _fuse)
+        self._plan_groups = self.num_kv_head if str(self.fused_split_merge) not in ("0", "False") else 0
         self._plan_checks = []         # (pinned header copy, event, max_slots) of plans not yet checked
         self._plan_hosts = []          # pinned buffers + events to reuse
 
@@ -241,6 +250,12 @@ class HipAttnBackend(AttentionBackend):
         self._plan_checks = pending
         if err:
             raise RuntimeError(err)
+
+    def _fuse(self, bs: int) -> bool:
+        """whether a decode launch of `bs` requests merges its splits inside the attention kernel.  A function of the
+        batch size alone, so that a graph bucket's captured launches and every step's plan agree."""
+        mode = str(self.fused_split_merge)
+        return self._plan_groups > 0 and (mode in ("1", "True") or (mode == "auto" and bs <= self.FUSE_MAX_BS))
 
     def _windows(self, bs, seq_lens, seq_lens_sum, encoder_lens, encoder_sum):
         """(lens, bound on their sum) of the three kv windows of a decode step"""
@@ -463,5 +478,5 @@ class HipAttnBackend(AttentionBackend):
             forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices, seq_lens,
             layer.scaling, layer.logit_cap, max_len, chunk, ws, kv_start, plan,
             k_scale=k_scale, v_scale=v_scale, max_slots=slots,
-            plan_fuse_groups=self._plan_groups if layer.tp_k_head_num <= self._plan_groups else 0)
+            plan_fuse_groups=self._plan_groups if self._fuse(q.shape[0]) and layer.tp_k_head_num <= self._plan_groups else 0)
         return o

@@ -72,7 +72,11 @@ class CustomAllReduce:
         self.failed = False          # a barrier timed out somewhere in the group: every later call raises
         self.calls = 0
         self.fused_calls = 0
-        self.fuse_norm = os.environ.get("SP_CUSTOM_ALLREDUCE_FUSE_NORM", "1") != "0"
+        # the fused all-reduce + add + RMSNorm is a second opt-in (SP_CUSTOM_ALLREDUCE_FUSE_NORM=1): like the direct
+        # all-reduce it has only run with all ranks on one device so far (no multi-GPU box in this pool); it becomes
+        # the default once tests/test_gpu_tensor_parallel.py's one-device-per-rank cases have passed on a TP node
+        self.fuse_norm = os.environ.get("SP_CUSTOM_ALLREDUCE_FUSE_NORM", "0") == "1"
+        self._cast_weights = {}      # (data_ptr, version, dtype) -> the norm weight in the activation dtype
         self.debug = os.environ.get("SP_CUSTOM_ALLREDUCE_DEBUG", "0") == "1"
         torch.distributed.barrier(group=group.cpu_group)
 
@@ -113,8 +117,22 @@ class CustomAllReduce:
             return False
         vec = 16 // x.element_size()
         H = x.shape[1]
+        # (everything a rank could decide differently from its peers is decided HERE, before any rank launches: the
+        # weight's layout too - a weight in another dtype is cast once into a fresh, aligned buffer)
         return (self._eligible(x) and residual.is_cuda and residual.stride(1) == 1 and H % vec == 0 and H <= 8192
-                and residual.stride(0) % vec == 0 and residual.data_ptr() % 16 == 0 and weight.numel() == H)
+                and residual.stride(0) % vec == 0 and residual.data_ptr() % 16 == 0 and weight.numel() == H
+                and weight.is_contiguous() and (weight.dtype != x.dtype or weight.data_ptr() % 16 == 0))
+
+    def _norm_weight(self, weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        if weight.dtype == dtype:
+            return weight
+        key = (weight.data_ptr(), weight._version, dtype)
+        w = self._cast_weights.get(key)
+        if w is None:
+            if len(self._cast_weights) > 1024:
+                self._cast_weights.clear()
+            w = self._cast_weights[key] = weight.to(dtype)
+        return w
 
     def fused_all_reduce_add_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
                                      eps: float) -> bool:
@@ -125,9 +143,7 @@ class CustomAllReduce:
         if not self.should_fuse_norm(x, residual, weight):
             return False
         self._fail_if_failed()
-        w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
-        if w.data_ptr() % 16:
-            return False
+        w = self._norm_weight(weight, x.dtype)
         _native._check(self.lib.sp_fused_allreduce_add_rmsnorm(
             x.data_ptr(), residual.data_ptr(), w.data_ptr(), x.shape[0], x.shape[1], x.stride(0),
             residual.stride(0), float(eps), _native._dt(x), self._regions, self.rank, self.world,

@@ -6,11 +6,12 @@ slot 0 is the reserved dummy slot for padded rows) with the bookkeeping re-desig
 are rings (host ring for request rows, device ring for KV slots) instead of lists that are rebuilt
 on every alloc/free.
 
-MI355X layout: K and V each live in ONE allocation [layers, P+1, Hkv, D] (token-major, NHD);
-``get_key_buffer(l)`` is a view of layer l, so addresses and strides are what the reference's
-per-layer tensors would have, while a 288 GB HBM pool is a single contiguous arena.
+MI355X layout: K and V live in ONE allocation [layers, P+1, 2, Hkv, D] (token-major; a token's K and V rows of
+a layer adjacent); ``get_key_buffer(l)`` / ``get_value_buffer(l)`` are strided views [P+1, Hkv, D] of layer l with
+the reference's shape, and a 288 GB HBM pool is a single contiguous arena.
 """
 import abc
+import os
 from typing import List, Optional, Tuple, Union
 
 import numpy as np
@@ -281,23 +282,42 @@ class MHATokenToKVPool(KVCache):
         self.layer_transfer_counter = None
         self.capture_mode = False
 
+    # One arena [layers, P+1, 2, Hkv, D]: a token's K row and V row of a layer are adjacent (one 4 KiB run at
+    # Llama-3-8B's 8 KV heads, 512 B per rank at 70B / TP 8), k_buffer[l] / v_buffer[l] are its two strided views
+    # with the reference's shape [P+1, Hkv, D] (memory/pool.py:295-318 allocates one tensor per layer and side).  Every
+    # kernel takes the token stride, so nothing else changes; a decode gather then touches one page per token instead
+    # of two far-apart ones.  SP_KV_INTERLEAVE=0: two arenas [layers, P+1, Hkv, D] (rounds 1-3).
+    interleave_kv = os.environ.get("SP_KV_INTERLEAVE", "1") != "0"
+
     def _create_buffers(self):
-        shape = (self.layer_num, self.size + self.page_size, self.head_num, self.head_dim)
-        self._k_arena = torch.zeros(shape, dtype=self.store_dtype, device=self.device)
-        self._v_arena = torch.zeros(shape, dtype=self.store_dtype, device=self.device)
+        rows = self.size + self.page_size
+        if self.interleave_kv:
+            self._kv_arena = torch.zeros((self.layer_num, rows, 2, self.head_num, self.head_dim),
+                                         dtype=self.store_dtype, device=self.device)
+            self._k_arena = self._kv_arena[:, :, 0]
+            self._v_arena = self._kv_arena[:, :, 1]
+        else:
+            shape = (self.layer_num, rows, self.head_num, self.head_dim)
+            self._kv_arena = None
+            self._k_arena = torch.zeros(shape, dtype=self.store_dtype, device=self.device)
+            self._v_arena = torch.zeros(shape, dtype=self.store_dtype, device=self.device)
         self.k_buffer = [self._k_arena[i] for i in range(self.layer_num)]
         self.v_buffer = [self._v_arena[i] for i in range(self.layer_num)]
 
     def _clear_buffers(self):
-        del self.k_buffer, self.v_buffer, self._k_arena, self._v_arena
+        del self.k_buffer, self.v_buffer, self._k_arena, self._v_arena, self._kv_arena
 
     def get_kv_size_bytes(self):
         return (self._k_arena.numel() * self._k_arena.element_size(),
                 self._v_arena.numel() * self._v_arena.element_size())
 
     def get_contiguous_buf_infos(self):
+        """pool.py:329-346: (data pointers, byte lengths, bytes per token) of the K buffers then the V buffers.  With
+        the interleaved arena a buffer is a strided view: its byte length is the span it covers and an item is one
+        token's row at stride 2 x that (the transfer engine upstream copies [ptr + token * item_stride, + item_len))."""
         bufs = self.k_buffer + self.v_buffer
-        return ([b.data_ptr() for b in bufs], [b.nbytes for b in bufs], [b[0].nbytes for b in bufs])
+        span = lambda b: (b.shape[0] - 1) * b.stride(0) * b.element_size() + b[0].nbytes
+        return ([b.data_ptr() for b in bufs], [span(b) for b in bufs], [b[0].nbytes for b in bufs])
 
     def get_flat_data(self, indices):
         return torch.stack([self._k_arena[:, indices], self._v_arena[:, indices]])

@@ -2,7 +2,12 @@
 over gloo (the box has one GPU; RCCL refuses two ranks on one device), each rank holding its
 shard of the heads, of the KV pool and of the linears exactly as on a TP node
 (linear.py:696-760, 1033-1155; model_runner.py:420-429).  Every rank's gathered logits must equal
-the unsharded oracle's for a ragged prefill and a decode step."""
+the unsharded oracle's for a ragged prefill and a decode step.
+
+Every multi-rank test also has ONE-DEVICE-PER-RANK parametrisations at world 2, 4 and 8 (RCCL over xGMI, the direct
+all-reduce across devices, collectives captured in HIP graphs, config 4's real head counts at TP = 8).  They are
+skipped where the box has fewer GPUs than ranks - every box of this pool so far - and run as they are on a TP node
+(distributed/parallel_state.py:256-353, device_communicators/pynccl.py:108-130)."""
 import os
 import socket
 import traceback
@@ -12,6 +17,31 @@ import torch
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
+
+
+def _needs(n):
+    return pytest.mark.skipif(torch.cuda.device_count() < n, reason=f"needs >= {n} GPUs (one device per rank)")
+
+
+# (world, one device per rank): ranks sharing cuda:0 exercise the protocol through IPC within one device; the
+# per-device cases are the real transport (peer mappings over xGMI) and are skipped on a one-GPU box
+PLACEMENTS = [pytest.param(2, False, id="2-ranks-on-one-gpu"), pytest.param(4, False, id="4-ranks-on-one-gpu"),
+              pytest.param(2, True, marks=_needs(2), id="2-gpus"), pytest.param(4, True, marks=_needs(4), id="4-gpus"),
+              pytest.param(8, True, marks=_needs(8), id="8-gpus")]
+
+
+def _run_ranks(target, world, extra, timeout=300):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(extra)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=timeout) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err in results:
+        assert err is None, f"rank {rank}:\n{err}"
 
 
 def _free_port():
@@ -27,6 +57,7 @@ def _rank_main(rank, world, port, case, q, custom_ar=False):
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         os.environ["SP_CUSTOM_ALLREDUCE"] = "1" if custom_ar else "0"
+        os.environ["SP_CUSTOM_ALLREDUCE_FUSE_NORM"] = "1" if custom_ar else "0"     # (a second opt-in)
         from oracle import llama as ollama, ops
         from scratchpad_amd import distributed as d
         from scratchpad_amd.forward_info import ForwardMode, ModelWorkerBatch
@@ -117,15 +148,16 @@ def test_sharded_forward_matches_unsharded_oracle(world, case, custom_ar):
         assert err is None, f"rank {rank}:\n{err}"
 
 
-def _ar_main(rank, world, port, q):
+def _ar_main(rank, world, port, q, per_device=False):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         from scratchpad_amd import distributed as d
         from scratchpad_amd.custom_all_reduce import CustomAllReduce
-        d.init_distributed_environment(world, rank, f"tcp://127.0.0.1:{port}", 0, backend="gloo")
-        d.initialize_model_parallel(world, backend="gloo", local_rank=0)
-        torch.cuda.set_device(0)
+        dev = rank if per_device else 0
+        torch.cuda.set_device(dev)
+        d.init_distributed_environment(world, rank, f"tcp://127.0.0.1:{port}", dev, backend="gloo")
+        d.initialize_model_parallel(world, backend="gloo", local_rank=dev)
         tp = d.get_tp_group()
         ca = CustomAllReduce(tp, max_bytes=4 << 20)
         tp.ca_comm = ca
@@ -181,32 +213,25 @@ def _ar_main(rank, world, port, q):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_direct_all_reduce_through_ipc_regions(world):
-    """csrc/allreduce.hip in the ca_comm seam: one-shot (small) and two-shot (large) sums across ranks
-    that share this GPU (IPC handles within one device).  NOT a test of xGMI transport."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_ar_main, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=240) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    for rank, err in results:
-        assert err is None, f"rank {rank}:\n{err}"
+@pytest.mark.parametrize("world,per_device", PLACEMENTS)
+def test_direct_all_reduce_through_ipc_regions(world, per_device):
+    """csrc/allreduce.hip in the ca_comm seam: one-shot (small) and two-shot (large) sums, eager and replayed from a
+    HIP graph.  Ranks that share this GPU map each other's regions through IPC within one device - NOT a test of
+    xGMI transport; the one-device-per-rank cases are (system-scope flags and data across peer mappings)."""
+    _run_ranks(_ar_main, world, (per_device,), timeout=240)
 
 
-def _fused_main(rank, world, port, q):
+def _fused_main(rank, world, port, q, per_device=False):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
+        os.environ["SP_CUSTOM_ALLREDUCE_FUSE_NORM"] = "1"
         from scratchpad_amd import _native, distributed as d
         from scratchpad_amd.custom_all_reduce import CustomAllReduce
-        d.init_distributed_environment(world, rank, f"tcp://127.0.0.1:{port}", 0, backend="gloo")
-        d.initialize_model_parallel(world, backend="gloo", local_rank=0)
-        torch.cuda.set_device(0)
+        dev = rank if per_device else 0
+        torch.cuda.set_device(dev)
+        d.init_distributed_environment(world, rank, f"tcp://127.0.0.1:{port}", dev, backend="gloo")
+        d.initialize_model_parallel(world, backend="gloo", local_rank=dev)
         tp = d.get_tp_group()
         ca = CustomAllReduce(tp, max_bytes=4 << 20)
         tp.ca_comm = ca
@@ -281,23 +306,13 @@ def _fused_main(rank, world, port, q):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_fused_all_reduce_add_rmsnorm_is_bit_identical_to_the_two_step_form(world):
+@pytest.mark.parametrize("world,per_device", PLACEMENTS)
+def test_fused_all_reduce_add_rmsnorm_is_bit_identical_to_the_two_step_form(world, per_device):
     """sp_fused_allreduce_add_rmsnorm (the TP path of config 4: o_proj / down_proj all-reduce + the next
     RMSNorm(x, residual), linear.py:1148-1149 -> llama.py:216/222) against sp_custom_all_reduce followed by
     sp_fused_add_rmsnorm: bit-identical x and residual, one-shot and two-shot, eager and replayed from a HIP
-    graph.  Ranks share this GPU (IPC within one device): NOT a test of xGMI transport."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_fused_main, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=300) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    for rank, err in results:
-        assert err is None, f"rank {rank}:\n{err}"
+    graph.  Ranks sharing this GPU: IPC within one device, NOT a test of xGMI transport (the per-device cases are)."""
+    _run_ranks(_fused_main, world, (per_device,))
 
 
 def _timeout_main(rank, world, port, q):
@@ -368,76 +383,123 @@ def test_direct_all_reduce_timeout_is_published_to_every_rank():
         assert err is None, f"rank {rank}:\n{err}"
 
 
-def _rccl_main(rank, world, port, q, custom_ar):
+# config 4's attention at its real head counts (Llama-3-70B: 64 query / 8 KV heads of 128, hidden 8192 - per rank
+# at TP = 8: 8 query heads over 1 KV head, the shape of decode_mfma_kernel's split-keys path), two layers, MLP and
+# vocabulary cut down so the unsharded fp32 oracle stays in test time
+WIDE = dict(hidden=8192, inter=2048, layers=2, Hq=64, Hkv=8, vocab=2048)
+
+
+def _wide_weights(seed=9):
+    """fan-in-scaled weights, the same on every rank (full, unsharded state dict; load_full_state_dict shards it)"""
+    g = torch.Generator().manual_seed(seed)
+    H, I, V, D = WIDE["hidden"], WIDE["inter"], WIDE["vocab"], 128
+    rnd = lambda rows, cols, gain=1.0: torch.randn(rows, cols, generator=g) * (gain / cols ** 0.5)
+    w = {"model.embed_tokens.weight": torch.randn(V, H, generator=g), "model.norm.weight": torch.ones(H),
+         "lm_head.weight": rnd(V, H, 3.0)}
+    for l in range(WIDE["layers"]):
+        pre = f"model.layers.{l}."
+        w[pre + "self_attn.qkv_proj.weight"] = rnd((WIDE["Hq"] + 2 * WIDE["Hkv"]) * D, H)
+        w[pre + "self_attn.o_proj.weight"] = rnd(H, WIDE["Hq"] * D)
+        w[pre + "mlp.gate_up_proj.weight"] = rnd(2 * I, H)
+        w[pre + "mlp.down_proj.weight"] = rnd(H, I)
+        w[pre + "input_layernorm.weight"] = torch.ones(H)
+        w[pre + "post_attention_layernorm.weight"] = torch.ones(H)
+    return w
+
+
+def _rccl_main(rank, world, port, q, custom_ar, wide=False, dt="f32", backend="nccl"):
     """TP over RCCL with one GPU per rank: sharded forward vs the unsharded oracle, eager and under
-    HIP-graph replay with the all-reduces captured inside the graph."""
+    HIP-graph replay with the all-reduces captured inside the graph.  wide: config 4's head counts (WIDE).
+    backend "gloo": the same flow with all ranks on cuda:0 (what a one-GPU box can run of it; the graph part only
+    with the direct all-reduce - gloo collectives cannot be captured)."""
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         os.environ["SP_CUSTOM_ALLREDUCE"] = "1" if custom_ar else "0"
+        os.environ["SP_CUSTOM_ALLREDUCE_FUSE_NORM"] = "1" if custom_ar else "0"
         from oracle import llama as ollama, ops
         from scratchpad_amd import distributed as d
         from scratchpad_amd.forward_info import ForwardMode, ModelWorkerBatch
         from scratchpad_amd.model_runner import ModelConfig, ModelRunner, ServerArgs, TpModelWorker
         from tests import smoke_impl
-        torch.cuda.set_device(rank)
-        d.init_distributed_environment(world, rank, f"tcp://127.0.0.1:{port}", rank, backend="nccl")
-        d.initialize_model_parallel(world, backend="nccl", local_rank=rank)
-        g, pfx, shape, w = smoke_impl.load_case("b")
-        cfg = ModelConfig(shape.hidden, shape.inter, shape.layers, shape.Hq, shape.Hkv, shape.vocab, context_len=60,
+        dtype = {"f32": torch.float32, "bf16": torch.bfloat16}[dt]
+        gpu = rank if backend == "nccl" else 0
+        torch.cuda.set_device(gpu)
+        d.init_distributed_environment(world, rank, f"tcp://127.0.0.1:{port}", gpu, backend=backend)
+        d.initialize_model_parallel(world, backend=backend, local_rank=gpu)
+        if wide:
+            shape = ollama.LlamaShape(WIDE["hidden"], WIDE["inter"], WIDE["layers"], WIDE["Hq"], WIDE["Hkv"],
+                                      WIDE["vocab"], False, 500000.0, None, 512, 1e-5)
+            w = _wide_weights()
+            lens, ctx_len, pool = [70, 37], 128, 256          # > 64 keys: the decode step splits and merges
+        else:
+            g, pfx, shape, w = smoke_impl.load_case("b")
+            lens, ctx_len, pool = [7, 4], 60, 96
+        cfg = ModelConfig(shape.hidden, shape.inter, shape.layers, shape.Hq, shape.Hkv, shape.vocab, context_len=ctx_len,
                           rms_norm_eps=shape.rms_eps, rope_theta=shape.rope_theta, max_position_embeddings=shape.max_pos,
                           tie_word_embeddings=shape.tie)
-        mr = ModelRunner(cfg, ServerArgs(max_total_tokens=96, max_running_requests=4, cuda_graph_bs=[2],
+        mr = ModelRunner(cfg, ServerArgs(max_total_tokens=pool, max_running_requests=4, cuda_graph_bs=[2],
                                          cuda_graph_max_bs=2),
-                         tp_rank=rank, tp_size=world, dtype=torch.float32, gpu_id=rank, init_weights=False)
+                         tp_rank=rank, tp_size=world, dtype=dtype, gpu_id=gpu, init_weights=False)
+        assert mr.token_to_kv_pool.head_num == max(1, shape.Hkv // world)
         mr.model.load_full_state_dict({k: v.to(mr.device) for k, v in w.items()})
+        if dtype != torch.float32:                            # the oracle on the values the model holds
+            w = {k: v.to(dtype).float() for k, v in w.items()}
+        # fp32: the VALU kernels, 1e-4 of the logit scale; bf16: the matrix-core kernels against the fp32 oracle on
+        # bf16-rounded weights (what torch's own bf16 evaluation of two layers deviates by: test_gpu_llama_real_width)
+        bound = 1e-4 if dtype == torch.float32 else 3e-2
         worker = TpModelWorker(mr)
         dev = mr.device
         gen = torch.Generator().manual_seed(5)
-        lens = [7, 4]
+        n0, n1 = lens
         ids = torch.randint(0, shape.vocab, (sum(lens),), generator=gen)
         loc = torch.arange(1, 1 + sum(lens))
         table = mr.req_to_token_pool.req_to_token
-        table[0, :7] = loc[:7].to(torch.int32).to(dev)
-        table[1, :4] = loc[7:].to(torch.int32).to(dev)
+        table[0, :n0] = loc[:n0].to(torch.int32).to(dev)
+        table[1, :n1] = loc[n0:].to(torch.int32).to(dev)
         req = torch.tensor([0, 1])
         batch = ModelWorkerBatch(bid=1, forward_mode=ForwardMode.EXTEND, input_ids=ids.to(dev),
                                  req_pool_indices=req.to(dev), seq_lens=torch.tensor(lens).to(dev),
                                  out_cache_loc=loc.to(dev), seq_lens_sum=sum(lens), extend_num_tokens=sum(lens),
                                  extend_seq_lens=lens, extend_prefix_lens=[0, 0])
         out, nxt = worker.forward_batch_generation(batch)
-        okv = ollama.OracleKV(shape, 96, 4, 64)
+        okv = ollama.OracleKV(shape, pool, 4, ctx_len + 4)
         okv.req_to_token.copy_(table.cpu())
         ext = torch.tensor(lens, dtype=torch.int32)
         pos, start = ops.compute_position(torch.zeros(2, dtype=torch.int32), ext)
         ref = ollama.forward(shape, w, okv, mode="extend", input_ids=ids, positions=pos, req_pool_indices=req,
                              seq_lens=torch.tensor(lens), out_cache_loc=loc, extend_seq_lens=ext, extend_start_loc=start)
         rel = lambda a, b: float((a.float().cpu() - b).abs().max() / b.abs().max())
-        assert rel(out.gather_full_logits(), ref) <= 1e-4, ("prefill over RCCL", rank)
-        assert torch.equal(nxt.cpu(), ref.argmax(-1))
-        loc2 = torch.tensor([20, 21])
-        table[0, 7] = 20
-        table[1, 4] = 21
-        seq2 = torch.tensor([8, 5])
+        assert rel(out.gather_full_logits(), ref) <= bound, ("prefill over RCCL", rank, rel(out.gather_full_logits(), ref))
+        if dtype == torch.float32:
+            assert torch.equal(nxt.cpu(), ref.argmax(-1))
+        nxt = ref.argmax(-1).to(dev)                          # every rank continues from the oracle's tokens
+        loc2 = torch.tensor([sum(lens) + 9, sum(lens) + 10])
+        table[0, n0] = int(loc2[0])
+        table[1, n1] = int(loc2[1])
+        seq2 = torch.tensor([n0 + 1, n1 + 1])
         okv.req_to_token.copy_(table.cpu())
         ref2 = ollama.forward(shape, w, okv, mode="decode", input_ids=nxt.cpu(), positions=ops.clamp_position(seq2),
                               req_pool_indices=req, seq_lens=seq2, out_cache_loc=loc2)
 
         def decode_once():
             b2 = ModelWorkerBatch(bid=2, forward_mode=ForwardMode.DECODE, input_ids=nxt, req_pool_indices=req.to(dev),
-                                  seq_lens=seq2.to(dev), out_cache_loc=loc2.to(dev), seq_lens_sum=13)
+                                  seq_lens=seq2.to(dev), out_cache_loc=loc2.to(dev), seq_lens_sum=int(seq2.sum()))
             return worker.forward_batch_generation(b2)
         out2, n2 = decode_once()                              # eager
-        assert rel(out2.gather_full_logits(), ref2) <= 1e-4, ("eager decode over RCCL", rank)
-        mr.init_cuda_graphs()                                 # collectives captured inside the graph
-        for _ in range(3):
-            out3, n3 = decode_once()
-            assert rel(out3.gather_full_logits(), ref2) <= 1e-4, ("graph decode over RCCL", rank)
-            assert torch.equal(n3, n2)
+        assert rel(out2.gather_full_logits(), ref2) <= bound, ("eager decode over RCCL", rank, rel(out2.gather_full_logits(), ref2))
+        if backend == "nccl" or custom_ar:
+            mr.init_cuda_graphs()                             # collectives captured inside the graph
+            for _ in range(3):
+                out3, n3 = decode_once()
+                assert rel(out3.gather_full_logits(), ref2) <= bound, ("graph decode over RCCL", rank)
+                assert torch.equal(n3, n2)
+        mr.attn_backend.check_plans()
         ca = d.get_tp_group().ca_comm
         assert (ca is not None) == custom_ar
         if ca is not None:
             ca.check()
+            assert ca.calls > 0 and (ca.fused_calls > 0) == ca.fuse_norm
             ca.close()
         torch.distributed.barrier()
         q.put((rank, None))
@@ -445,20 +507,98 @@ def _rccl_main(rank, world, port, q, custom_ar):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: RCCL refuses two ranks on one device")
 @pytest.mark.parametrize("custom_ar", [False, True], ids=["rccl", "direct-all-reduce"])
-def test_tp2_over_rccl_matches_unsharded_oracle(custom_ar):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_rccl_main, args=(r, 2, port, q, custom_ar)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    for rank, err in results:
-        assert err is None, f"rank {rank}:\n{err}"
+@pytest.mark.parametrize("world,wide,dt", [
+    pytest.param(2, False, "f32", marks=_needs(2), id="tp2-tiny"),
+    pytest.param(2, True, "f32", marks=_needs(2), id="tp2-70b-heads-f32"),
+    pytest.param(4, True, "f32", marks=_needs(4), id="tp4-70b-heads-f32"),
+    pytest.param(4, True, "bf16", marks=_needs(4), id="tp4-70b-heads-bf16"),
+    pytest.param(8, True, "f32", marks=_needs(8), id="tp8-70b-heads-f32"),
+    pytest.param(8, True, "bf16", marks=_needs(8), id="tp8-70b-heads-bf16")])
+def test_tp_over_rccl_matches_unsharded_oracle(world, wide, dt, custom_ar):
+    """One GPU per rank, RCCL (= torch's "nccl" backend) or the direct all-reduce carrying the row-parallel sums:
+    ragged prefill, eager decode and HIP-graph decode (collectives inside the graph) against the unsharded oracle.
+    tp8-70b-heads is BASELINE config 4's partitioning at its real size: 64 / 8 heads of 128 over 8 ranks, each rank's
+    decode attention on the Hq 8 / Hkv 1 shape.  RCCL refuses two ranks on one device, so nothing here runs on a
+    one-GPU box (parallel_state.py:256-353, pynccl.py:108-130)."""
+    _run_ranks(_rccl_main, world, (custom_ar, wide, dt), timeout=900)
+
+
+@pytest.mark.parametrize("world,dt,custom_ar", [(2, "bf16", True), (4, "f32", False)],
+                         ids=["tp2-bf16-direct-all-reduce-graph", "tp4-f32-gloo"])
+def test_70b_head_counts_sharded_on_one_gpu(world, dt, custom_ar):
+    """The flow of test_tp_over_rccl_matches_unsharded_oracle's 70b-heads cases with the ranks sharing cuda:0 over
+    gloo: everything of config 4's partitioning except the transport (64 / 8 heads of 128 sharded 2 and 4 ways: per
+    rank Hq 32 / Hkv 4 and Hq 16 / Hkv 2), so that the cases a TP node will run are not first executed there."""
+    _run_ranks(_rccl_main, world, (custom_ar, True, dt, "gloo"), timeout=900)
+
+
+def _rccl_graph_main(rank, world, port, q):
+    """RCCL all-reduce and all-gather captured inside a HIP graph at world >= 2, replayed with fresh inputs and
+    with eager collectives between the replays (cuda_graph_runner.py:400-420 captures the model's collectives the
+    same way; pynccl.py:108-130 is the call being captured)."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank,
+                                device_id=torch.device("cuda", rank))
+        gen = torch.Generator().manual_seed(77)            # the same stream on every rank: rank r's input is slice r
+        T, H = 128, 8192                                    # config 4's message: [bs 128, hidden 8192] bf16 = 2 MiB
+        xs = torch.zeros(T, H, dtype=torch.bfloat16, device="cuda")
+        gs = torch.zeros(T, 256, dtype=torch.bfloat16, device="cuda")
+        gathered = torch.zeros(world * T, 256, dtype=torch.bfloat16, device="cuda")
+        dist.all_reduce(xs)                                 # communicator set-up outside the capture
+        dist.all_gather_into_tensor(gathered, gs)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            dist.all_reduce(xs.clone())
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            ys = xs * 2
+            dist.all_reduce(ys)
+            zs = ys + 1
+            dist.all_reduce(zs)                             # two dependent collectives in one graph
+            dist.all_gather_into_tensor(gathered, gs)
+        for rep in range(4):
+            allx = torch.randn(world, T, H, generator=gen).to(torch.bfloat16)
+            allg = torch.randn(world, T, 256, generator=gen).to(torch.bfloat16)
+            xs.copy_(allx[rank])
+            gs.copy_(allg[rank])
+            graph.replay()
+            torch.cuda.synchronize()
+            want = (allx.float() * 2).sum(0)
+            err = (ys.float().cpu() - want).abs()
+            assert bool((err <= 2.0 ** -7 * want.abs() + 1e-2).all()), ("all-reduce in graph", rank, rep, float(err.max()))
+            want2 = (ys.float().cpu() + 1).to(torch.bfloat16).float() * world
+            err2 = (zs.float().cpu() - want2).abs()
+            assert bool((err2 <= 2.0 ** -7 * want2.abs() + 1e-2).all()), ("second all-reduce in graph", rank, rep)
+            assert torch.equal(gathered.cpu(), allg.reshape(world * T, 256)), ("all-gather in graph", rank, rep)
+            eager = xs.clone()
+            dist.all_reduce(eager)                          # an eager collective between replays
+            torch.cuda.synchronize()
+            e2 = (eager.float().cpu() - allx.float().sum(0)).abs()
+            assert bool((e2 <= 2.0 ** -7 * allx.float().sum(0).abs() + 1e-2).all())
+            outs = [None] * world
+            dist.all_gather_object(outs, ys.cpu())
+            assert all(torch.equal(outs[0], t) for t in outs), "every rank holds the same reduced bits"
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, None))
+    except Exception:
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [pytest.param(2, marks=_needs(2)), pytest.param(4, marks=_needs(4)),
+                                   pytest.param(8, marks=_needs(8))])
+def test_rccl_collectives_inside_a_hip_graph(world):
+    """What the single-rank test below cannot show: a captured RCCL all-reduce / all-gather that really exchanges
+    data between devices, replayed (needs one GPU per rank: skipped on this pool's one-GPU boxes)."""
+    _run_ranks(_rccl_graph_main, world, (), timeout=600)
 
 
 def _rccl_single_main(port, q):

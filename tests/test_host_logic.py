@@ -62,16 +62,43 @@ def test_req_to_token_pool_trace_matches_reference():
     assert torch.equal(other.req_to_token, rec.req_to_token) and rec.get_write_records() == []
 
 
-def test_kv_pool_layout_and_guards():
+@pytest.mark.parametrize("interleave", [True, False])
+def test_kv_pool_layout_and_guards(interleave, monkeypatch):
+    monkeypatch.setattr(MHATokenToKVPool, "interleave_kv", interleave)
     pool = MHATokenToKVPool(10, 1, torch.bfloat16, 2, 64, 3, "cpu")
     assert isinstance(pool, KVCache)
     k = pool.get_key_buffer(1)
-    assert k.shape == (11, 2, 64) and k.stride() == (128, 64, 1), "[size+1, Hkv, D] token-major"
-    # one arena per K/V: layer l is a view at l * (size+1) rows
-    assert pool.get_key_buffer(2).data_ptr() - pool.get_key_buffer(1).data_ptr() == 11 * 128 * 2
     kb, vb = pool.get_kv_buffer(0)
     assert kb.data_ptr() != vb.data_ptr()
+    assert k.shape == (11, 2, 64) and k.stride()[1:] == (64, 1), "[size+1, Hkv, D] token-major"
+    if interleave:
+        # ONE arena [layers, size+1, 2, Hkv, D]: a token's K row and V row of a layer are adjacent
+        assert k.stride(0) == 256
+        assert vb.data_ptr() - kb.data_ptr() == 128 * 2
+        assert pool.get_key_buffer(2).data_ptr() - pool.get_key_buffer(1).data_ptr() == 11 * 256 * 2
+        kb[3].fill_(1.0)
+        vb[3].fill_(2.0)
+        assert pool._kv_arena[0, 3].flatten().tolist() == [1.0] * 128 + [2.0] * 128
+    else:
+        # one arena per K/V: layer l is a view at l * (size+1) rows
+        assert k.stride(0) == 128
+        assert pool.get_key_buffer(2).data_ptr() - pool.get_key_buffer(1).data_ptr() == 11 * 128 * 2
     assert pool.get_kv_size_bytes() == (3 * 11 * 128 * 2,) * 2
+    # the flat-data / transfer pair keeps the reference's semantics (memory/pool.py:348-372) on either layout
+    idx = torch.tensor([2, 5, 9])
+    for l in range(3):
+        pool.k_buffer[l][idx] = torch.randn(3, 2, 64).to(torch.bfloat16)
+        pool.v_buffer[l][idx] = torch.randn(3, 2, 64).to(torch.bfloat16)
+    flat = pool.get_flat_data(idx)
+    assert flat.shape == (2, 3, 3, 2, 64) and torch.equal(flat[0, 1], pool.get_key_buffer(1)[idx])
+    other = MHATokenToKVPool(10, 1, torch.bfloat16, 2, 64, 3, "cpu")
+    other.transfer(idx, flat)
+    assert torch.equal(other.get_value_buffer(2)[idx], pool.get_value_buffer(2)[idx])
+    other.transfer_per_layer(torch.tensor([1]), torch.stack([kb[3:4], vb[3:4]]), 1)
+    assert torch.equal(other.get_key_buffer(1)[1], kb[3]) and torch.equal(other.get_value_buffer(1)[1], vb[3])
+    ptrs, lens, items = pool.get_contiguous_buf_infos()
+    assert len(ptrs) == 6 and items == [256] * 6
+    assert lens[0] == (10 * k.stride(0) + 128) * 2
     with pytest.raises(NotImplementedError):
         MHATokenToKVPool(10, 16, torch.bfloat16, 2, 64, 1, "cpu")
     with pytest.raises(RuntimeError, match="no CPU fallback"):   # the store itself is HIP-only
