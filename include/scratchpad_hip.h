@@ -60,6 +60,11 @@ SP_API const char* sp_status_string(int status);
  * tokens; the two forms agree bit for bit), "ar_fused_blocks", "skinny_nt".  Nothing on the call path reads the environment.  Returns
  * SP_ERR_INVALID_ARG for an unknown key.                                                          */
 SP_API int sp_debug_set(const char* key, int value);
+/* Read-only counterpart (ABI 6): "w64_descriptor_patched" (1 = the build's descriptor patch was applied, the
+ * 4-wave x 64-row extend kernels may launch; anything else: sp_extend_attention keeps to the 8-wave kernel),
+ * "extend_last_kernel" (what the last sp_extend_attention call launched: 1 = 8-wave matrix-core kernel, 2 = 4-wave
+ * x 64-row kernel, 3 = its persistent form, 4 = row streams on the decode kernel, 0 = none yet).  -1: unknown key. */
+SP_API int sp_debug_get(const char* key);
 
 /* ---- RMSNorm: replaces flashinfer.norm.rmsnorm / fused_add_rmsnorm
  *      (nn/layers/layernorm.py:22-32; semantics of forward_native 34-51).

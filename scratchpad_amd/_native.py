@@ -37,6 +37,7 @@ SIGNATURES = {
     "sp_abi_version": (_i32, []),
     "sp_status_string": (ctypes.c_char_p, [_i32]),
     "sp_debug_set": (_i32, [ctypes.c_char_p, _i32]),
+    "sp_debug_get": (_i32, [ctypes.c_char_p]),
     "sp_rmsnorm": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp]),
     "sp_fused_add_rmsnorm": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp]),
     "sp_silu_and_mul": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _i32, _vp]),
@@ -119,6 +120,19 @@ def debug_set(key: str, value: int) -> None:
     "extend_w64" (0 never / 1 where it pays (default) / 2 wherever it applies: the 4-wave x 64-row extend kernel),
     "extend_w64_persist" (the same three values for its persistent form on launches with a plan)."""
     _check(load().sp_debug_set(key.encode(), int(value)), f"sp_debug_set({key})")
+
+
+EXTEND_KERNELS = {0: "none", 1: "extend_mfma_kernel (8 waves)", 2: "extend_w64_kernel (4 waves x 64 rows)",
+                  3: "extend_w64p_kernel (persistent 4 waves x 64 rows)", 4: "row streams on the decode kernel"}
+
+
+def debug_get(key: str) -> int:
+    """sp_debug_get: "w64_descriptor_patched" (1 = the 4-wave x 64-row extend kernels may launch),
+    "extend_last_kernel" (a key of EXTEND_KERNELS: what the last extend_attention call launched)."""
+    v = int(load().sp_debug_get(key.encode()))
+    if v < 0:
+        raise RuntimeError(f"sp_debug_get({key}): unknown key")
+    return v
 
 
 def _dt(t: torch.Tensor) -> int:

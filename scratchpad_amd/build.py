@@ -38,6 +38,27 @@ def _newer(target, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
+def _hipcc_version() -> str:
+    try:
+        out = subprocess.run([HIPCC, "--version"], check=True, capture_output=True, text=True).stdout
+    except (OSError, subprocess.CalledProcessError) as e:
+        return f"hipcc --version failed: {e}"
+    return " | ".join(l.strip() for l in out.splitlines() if l.strip() and not l.startswith("InstalledDir"))
+
+
+def check_w64_descriptors(lib: str = LIB, verbose: bool = False) -> None:
+    """Raise unless the library's extend_w64 kernels carry the patched descriptors this source tree expects
+    (tools/patch_w64_descriptor.py --check --expect): an unpatched or differently laid-out library fails the BUILD,
+    not a parity test on a GPU box."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "patch_w64_descriptor.py"), lib, "--check", "--expect"],
+                       capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout + r.stderr, end="")
+    if r.returncode != 0:
+        raise RuntimeError(f"{lib}: the extend_w64 kernel descriptors are not what extend_w64.hip needs (see above); "
+                           "rebuild with `python -m scratchpad_amd.build --force`")
+
+
 def build_native(force: bool = False, verbose: bool = True) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(CSRC, "*.inc"))) + [
@@ -46,9 +67,11 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
     # every remaining file older than the library)
     stamp = LIB + ".sources"
     made_of = "\n".join([os.path.basename(x) for x in srcs] + [" ".join(FLAGS)] +
-                        [k + " " + " ".join(v) for k, v in sorted(PER_FILE_FLAGS.items())])
+                        [k + " " + " ".join(v) for k, v in sorted(PER_FILE_FLAGS.items())] +
+                        ["compiler: " + _hipcc_version()])
     same = os.path.exists(stamp) and open(stamp).read() == made_of
     if not force and same and _newer(LIB, srcs + hdrs):
+        check_w64_descriptors(LIB)       # (cheap: reads the ELF; a library somebody linked by hand fails here)
         return LIB
     force = force or not same
     os.makedirs(OBJ, exist_ok=True)
@@ -73,6 +96,7 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
     # the extend_w64 kernels own accumulation registers the compiler was never told about: size their allocation
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "patch_w64_descriptor.py"), LIB], check=True,
                    stdout=None if verbose else subprocess.DEVNULL)
+    check_w64_descriptors(LIB, verbose)
     with open(stamp, "w") as f:
         f.write(made_of)
     return LIB

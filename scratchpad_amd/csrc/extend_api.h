@@ -26,11 +26,17 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
                     const int32_t* plan, int plan_items, int num_tokens, int dtype, int kv8, hipStream_t st);
 
 // extend_w64.hip: the 4-wave x 64-row form of the same kernel (16-bit, D = 128, plain attention, query-head group a
-// multiple of 4); returns 1 when it took the launch.  set_extend_w64: 0 never, 1 where it pays (default), 2 always.
+// multiple of 4); returns 1 (one workgroup per item) or 2 (persistent workgroups) when it took the launch, 0 otherwise.
+// set_extend_w64: 0 never, 1 where it pays (default), 2 always.
 struct ExtendArgs;
 int try_extend_w64(const ExtendArgs& a, int head_dim, int dtype, int max_extend_len, int64_t max_seq_len, hipStream_t st);
 void set_extend_w64(int v);
 void set_extend_w64_persist(int v);   // 0: never, 1 (default): where it pays, 2: every launch with a plan the 4 x 64-row kernel applies to
+
+// which kernel the last sp_extend_attention call launched (sp_debug_get("extend_last_kernel")): 0 none yet, 1 the
+// 8-wave matrix-core kernel, 2 the 4-wave x 64-row kernel (one workgroup per item), 3 its persistent form, 4 row streams
+extern int g_extend_last_kernel;
+int w64_descriptor_patched();
 
 // test / tuning hooks behind sp_debug_set
 void set_extend_defer_x10(int tenths);

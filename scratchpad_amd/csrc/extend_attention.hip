@@ -151,6 +151,16 @@ extern "C" int sp_debug_set(const char* key, int value) {
   return SP_ERR_INVALID_ARG;
 }
 
+// read-only counterpart: "w64_descriptor_patched" (1 = tools/patch_w64_descriptor.py has sized the 4-wave x 64-row
+// kernels' register allocation in this library: they may launch), "extend_last_kernel" (see extend_api.h);
+// -1 for an unknown key
+extern "C" int sp_debug_get(const char* key) {
+  if (!key) return -1;
+  if (!strcmp(key, "w64_descriptor_patched")) return w64_descriptor_patched();
+  if (!strcmp(key, "extend_last_kernel")) return g_extend_last_kernel;
+  return -1;
+}
+
 #if defined(SP_EXTEND_STAMPS) || defined(SP_EXTEND_WGSTAMPS)
 namespace sp { void set_extend_stamp_buffer(void* p); }
 extern "C" SP_API int sp_debug_extend_stamp_buffer(void* device_u64x8) {
@@ -242,6 +252,7 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
   if (chunk > 0x7ffffff0LL) return SP_ERR_INVALID_ARG;
   a.chunk = (int)chunk; a.num_splits = 1; a.max_len = (int)chunk; a.max_slots = (int)num_tokens;
   a.hh_shift = decode_heads_per_load_shift(num_kv_heads, head_dim, dtype, &a.head_groups);
-  a.part_o = nullptr; a.part_lse = nullptr; a.plan = nullptr; a.kv8 = 0;
+  a.part_o = nullptr; a.part_lse = nullptr; a.plan = nullptr; a.kv8 = 0; a.fuse_groups = 0;
+  g_extend_last_kernel = 4;
   return run_decode(a, head_dim, G, dtype, st);
 }

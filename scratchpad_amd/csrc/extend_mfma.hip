@@ -662,6 +662,7 @@ void set_extend_stamp_buffer(void* p) {
 
 static int g_extend_dma = 1;
 void set_extend_dma(int v) { g_extend_dma = v; }
+int g_extend_last_kernel = 0;
 
 constexpr int kExtendWaves = 8;
 
@@ -743,10 +744,12 @@ int run_extend_mfma(void* out, const void* q, const void* k_buffer, const void* 
   if (plan && (plan_items <= 0 || plan_items > 65535)) a.plan = nullptr;   // grid.y limit: unplanned launch
   const int G = num_q_heads / num_kv_heads;
   if (max_extend_len <= 0) return SP_OK;
-  if (try_extend_w64(a, head_dim, dtype, max_extend_len, max_seq_len, st)) {
+  if (const int form = try_extend_w64(a, head_dim, dtype, max_extend_len, max_seq_len, st)) {
+    g_extend_last_kernel = form == 2 ? 3 : 2;
     SP_LAUNCH_CHECK();
     return SP_OK;
   }
+  g_extend_last_kernel = 1;
 #ifdef SP_EXTEND_ONLY_HEADLINE   // ISA experiments only: one instantiation family, seconds to compile
   if (dtype == SP_BF16 && head_dim == 128 && G % 4 == 0)
     return launch_extend<bf16_tag, 128, 4>(a, max_extend_len, G / 4, st);

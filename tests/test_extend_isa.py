@@ -79,6 +79,44 @@ def test_built_library_gives_the_w64_kernels_their_accumulation_registers():
     assert ctypes.c_int.in_dll(ctypes.CDLL(lib), "sp_w64_descriptor_patched").value == 1
 
 
+def test_build_refuses_an_unpatched_or_differently_laid_out_library(tmp_path):
+    """the descriptor patch must fail at BUILD time.  build_native() ends with
+    check_w64_descriptors(); a copy of the library with the patch undone (register granules back to what hipcc wrote,
+    or the host flag cleared) is refused, and so is one whose ACCUM_OFFSET is not the one the kernels' text assumes."""
+    import shutil
+    import struct
+    import sys
+    from scratchpad_amd import build
+    lib = os.path.join(ROOT, "scratchpad_amd", "lib", "libscratchpad_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    build.check_w64_descriptors(lib)                                   # the shipped library passes
+    assert "compiler: " in open(lib + ".sources").read(), "the build records hipcc --version next to the library"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import patch_w64_descriptor as pw
+    data = bytearray(open(lib, "rb").read())
+    descs = [off for base, _ in pw.device_elves(bytes(data)) for _name, off in pw.descriptors(bytes(data), base)]
+    descs = sorted(set(descs))            # (symtab and dynsym list the same descriptors)
+    assert len(descs) == 4
+    # (1) granule count of one kernel back to 32 granules = 256 registers, what the compiler believes it uses
+    broken = bytearray(data)
+    rsrc1, = struct.unpack_from("<I", broken, descs[0] + 48)
+    struct.pack_into("<I", broken, descs[0] + 48, (rsrc1 & ~0x3F) | 31)
+    # (2) the host flag cleared, descriptors intact
+    noflag = bytearray(data)
+    struct.pack_into("<i", noflag, pw.host_flag_offset(bytes(data)), 0)
+    # (3) another ACCUM_OFFSET (as a different register allocation would give), granules patched to match it
+    moved = bytearray(data)
+    rsrc3, = struct.unpack_from("<I", moved, descs[0] + 44)
+    struct.pack_into("<I", moved, descs[0] + 44, (rsrc3 & ~0x3F) | ((rsrc3 & 0x3F) - 2))
+    for name, blob in (("granules", broken), ("flag", noflag), ("accum_offset", moved)):
+        path = tmp_path / f"lib_{name}.so"
+        path.write_bytes(bytes(blob))
+        with pytest.raises(RuntimeError, match="extend_w64 kernel descriptors"):
+            build.check_w64_descriptors(str(path))
+    shutil.rmtree(tmp_path, ignore_errors=True)
+
+
 @pytest.fixture(scope="module")
 def w64_asm(tmp_path_factory):
     if not os.path.exists(HIPCC):

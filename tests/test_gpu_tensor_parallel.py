@@ -463,7 +463,7 @@ def _rccl_main(rank, world, port, q, custom_ar, wide=False, dt="f32", backend="n
                                  out_cache_loc=loc.to(dev), seq_lens_sum=sum(lens), extend_num_tokens=sum(lens),
                                  extend_seq_lens=lens, extend_prefix_lens=[0, 0])
         out, nxt = worker.forward_batch_generation(batch)
-        okv = ollama.OracleKV(shape, pool, 4, ctx_len + 4)
+        okv = ollama.OracleKV(shape, pool, table.shape[0], table.shape[1])
         okv.req_to_token.copy_(table.cpu())
         ext = torch.tensor(lens, dtype=torch.int32)
         pos, start = ops.compute_position(torch.zeros(2, dtype=torch.int32), ext)

@@ -11,7 +11,12 @@ descriptors to ACCUM_OFFSET + 256 registers - the unified register file of gfx90
 ACCUM_OFFSET + i of the wave's allocation (amdhsa kernel descriptor, LLVM AMDGPUUsage 'Kernel Descriptor').
 Once every descriptor is in place the script sets the library's host-side flag `sp_w64_descriptor_patched` to 1;
 extend_w64.hip refuses to launch its kernels while that flag is 0 (a library linked without this step).
-  python tools/patch_w64_descriptor.py LIB.so [--check]
+  python tools/patch_w64_descriptor.py LIB.so [--check] [--expect]
+--check: change nothing, exit 1 unless every descriptor and the flag are in place.
+--expect: also exit 1 unless each kernel's ACCUM_OFFSET and patched granule count are the ones this source tree was
+written for (EXPECTED below): the kernels' assembly text addresses a[0:235] on the assumption that the compiler keeps
+its own values in v[0:ACCUM_OFFSET) - a toolchain that lays the register file out differently (another ACCUM_OFFSET
+for the same source) has to be looked at by a person, at build time, not found by a failing parity test on a GPU.
 """
 import struct
 import sys
@@ -19,6 +24,8 @@ import sys
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 W64_AGPRS = 256     # a[0:191] O^T and Q; a[192:235]: the persistent form (the next item's kv slots and half of its Q rows)
 KERNELS = (b"extend_w64_kernel", b"extend_w64p_kernel")
+# kernel -> (ACCUM_OFFSET, register granules after the patch) with hipcc of ROCm 7.2.0 (build.py records the version)
+EXPECTED = {"extend_w64_kernel": (228, 61), "extend_w64p_kernel": (248, 63)}
 
 
 def device_elves(data):
@@ -81,6 +88,7 @@ def host_flag_offset(data):
 def main():
     path = sys.argv[1]
     check = "--check" in sys.argv
+    expect = "--expect" in sys.argv
     data = bytearray(open(path, "rb").read())
     seen, changed = {}, 0
     for base, _size in device_elves(bytes(data)):
@@ -113,6 +121,14 @@ def main():
         have_flag = 1
     print(f"sp_w64_descriptor_patched = {have_flag}")
     ok &= have_flag == 1
+    if expect:
+        for name, (accum, have, want, _state) in sorted(seen.items()):
+            kernel = next(k for k in EXPECTED if ("2sp%d%sI" % (len(k), k)) in name)
+            if (accum, max(have, want) + 1) != EXPECTED[kernel]:
+                print(f"{name}: accum_offset / granules {(accum, max(have, want) + 1)} differ from the expected "
+                      f"{EXPECTED[kernel]}: the compiler lays this kernel's registers out differently from the toolchain "
+                      "extend_w64.hip was written against - inspect before use")
+                ok = False
     if changed:
         open(path, "wb").write(data)
     sys.exit(0 if ok else 1)

@@ -3,8 +3,6 @@
 set -o pipefail
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-r4c}
 mkdir -p $OUT
-timeout -k 10 1100 python -m pytest tests/test_gpu_tensor_parallel.py tests/test_gpu_schedule_flow.py tests/test_gpu_llama.py tests/test_gpu_long_context.py tests/test_gpu_mllama.py -x -q -m gpu > $OUT/tests.log 2>&1 || { tail -40 $OUT/tests.log; exit 1; }
-tail -3 $OUT/tests.log
 B="python3 bench.py --no-cpu-baseline --no-ttft --steps 32 --warmup 8"
 run() { # name, env..., -- args
   name=$1; shift
@@ -33,3 +31,5 @@ run bs8_unfused SP_DECODE_FUSE_MERGE=0 -- --bs 8 --ctx 1024 &&
 run bs32_fused SP_DECODE_FUSE_MERGE=1 -- --bs 32 --ctx 1024 &&
 run bs32_unfused SP_DECODE_FUSE_MERGE=0 -- --bs 32 --ctx 1024
 cat $OUT/ab.txt
+timeout -k 10 700 python -m pytest tests/test_gpu_tensor_parallel.py tests/test_gpu_schedule_flow.py tests/test_gpu_llama.py tests/test_gpu_long_context.py tests/test_gpu_mllama.py -x -q -m gpu > $OUT/tests.log 2>&1 || { tail -40 $OUT/tests.log; exit 1; }
+tail -3 $OUT/tests.log
