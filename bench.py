@@ -439,7 +439,7 @@ def prefill_passes(args, mr, worker, rank, bs, warm, timed, profile_attention=Fa
         # one more pass with HIP events around every extend-attention launch (on the stream it is
         # launched on); flops of a launch = 4 Hq D sum(L^2 / 2 + L prefix) over its requests
         import scratchpad_amd.attention as att
-        orig, events = _native.extend_attention, []
+        orig, events, forms = _native.extend_attention, [], []
 
         def timed_call(*a_, **k_):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -447,6 +447,7 @@ def prefill_passes(args, mr, worker, rank, bs, warm, timed, profile_attention=Fa
             orig(*a_, **k_)
             e1.record()
             events.append((e0, e1))
+            forms.append(_native.debug_get("extend_last_kernel"))      # which kernel the library chose for this launch
 
         att._native.extend_attention = timed_call
         try:
@@ -459,8 +460,11 @@ def prefill_passes(args, mr, worker, rank, bs, warm, timed, profile_attention=Fa
         ms = sum(a_.elapsed_time(b_) for a_, b_ in calls)
         heads = cfg.num_attention_heads // mr.tp_size
         flops = per_layer * sum(4.0 * heads * cfg.head_dim * (n * n / 2.0 + n * args.prefix) for n in lens)
+        ran = forms[-per_layer * len(batches):]
         prof = {"launches": len(calls), "avg_launch_ms": ms / len(calls), "tflops": flops / (ms * 1e-3) / 1e12,
-                "flops_per_launch": flops / len(calls)}
+                "flops_per_launch": flops / len(calls),
+                "kernels": {_native.EXTEND_KERNELS[f]: ran.count(f) for f in sorted(set(ran))},
+                "w64_descriptor_patched": _native.debug_get("w64_descriptor_patched")}
     return el, tt, lens, len(batches), prof
 
 
@@ -494,7 +498,11 @@ def prefill_main(args, rank, local_rank, world):
 def prefill_roofline(prof):
     if prof is None:
         return None
-    return {"bound": "mfma", "kernel": "extend_w64_kernel (long prompts / long prefixes: the launches of this workload) | extend_mfma_kernel",
+    # "kernel": what the library actually launched in the profiled pass (sp_debug_get("extend_last_kernel") after every
+    # call), most frequent first - the 4-wave x 64-row kernels only launch from a library whose descriptor patch is in place
+    kernels = sorted(prof["kernels"].items(), key=lambda kv: -kv[1])
+    return {"bound": "mfma", "kernel": " | ".join(f"{k} x{n}" for k, n in kernels),
+            "w64_descriptor_patched": prof["w64_descriptor_patched"],
             "achieved": round(prof["tflops"], 1),
             "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(prof["tflops"] / MFMA_PEAK_TFLOPS, 4),
             "traffic": None, "avg_launch_ms": round(prof["avg_launch_ms"], 4), "launches": prof["launches"],
@@ -668,23 +676,33 @@ def serve_main(args, rank, local_rank, world):
            "itl_ms": {"p50": round(pct(itl, 0.5), 2), "p99": round(pct(itl, 0.99), 2)}}
     print(json.dumps(out), flush=True)
 
+def pmc_workload_key(args) -> str:
+    """the workload a PMC record under profiles/ was taken for (tools/pmc_decode.sh writes the same string)"""
+    return f"{args.model}|bs{args.bs}|ctx{args.ctx}|kv{args.kv_cache_dtype}"
+
+
 def pmc_traffic(alg_bytes, args):
     """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
-    (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; tools/pmc_decode_bf16.sh): the measured
-    traffic / algorithmic ratio of the same kernel SOURCES and workload, else None - a ratio recorded for
-    other kernel sources says nothing about this build."""
-    if args.model != "llama3-8b" or args.kv_cache_dtype != "auto" or args.bs != 256 or args.ctx != "uniform":
-        return None, "no PMC pass for this workload"
+    (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; tools/pmc_decode.sh): the measured
+    traffic / algorithmic ratio of the same kernel SOURCES and the same workload (attention shapes, batch,
+    contexts), else None - a ratio recorded for other kernel sources or another shape says nothing about this run."""
     import glob
     sha = decode_kernel_sources_sha1()
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_decode_attn_pmc.json")), reverse=True)
+    key = pmc_workload_key(args)
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_decode_attn_pmc*.json")), reverse=True)
+    stale = False
     for path in paths:                   # newest round first: the pass recorded for THESE kernel sources
         rec = json.load(open(path))
+        if rec.get("bench_workload", "llama3-8b|bs256|ctxuniform|kvauto") != key:
+            continue
         if rec.get("kernel_source_sha1") == sha:
             name = os.path.relpath(path, ROOT)
             return int(alg_bytes * rec["traffic_over_algorithmic"]), \
                 f"{name} (PMC ratio x algorithmic, same kernel sources)"
-    return None, "the PMC passes under profiles/ were recorded for other kernel sources (stale): not used"
+        stale = True
+    if stale:
+        return None, "the PMC passes under profiles/ were recorded for other kernel sources (stale): not used"
+    return None, "no PMC pass for this workload"
 
 
 def decode_kernel_sources_sha1() -> str:
@@ -983,7 +1001,9 @@ def main():
         alg = attention_algorithmic_bytes(cfg, sums[-1], args.bs, kv_elem)     # the replayed step's lengths
         achieved = alg / (avg_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(alg, args)
-        roofline = {"bound": "hbm", "kernel": "decode_mfma_kernel+decode_merge_kernel",
+        fused = bool(mr.attn_backend._fuse(args.bs))
+        roofline = {"bound": "hbm",
+                    "kernel": "decode_mfma_kernel (merges its splits: no merge launch)" if fused else "decode_mfma_kernel+decode_merge_kernel",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "traffic_source": traffic_src,
@@ -1054,4 +1074,11 @@ def main():
 
 
 if __name__ == "__main__":
+    # A/B switches of the library for measurement runs only (never read on the product's call path):
+    # SP_BENCH_DEBUG_SET="extend_w64_persist=2,extend_dma=0" -> sp_debug_set(key, value) before anything runs
+    if os.environ.get("SP_BENCH_DEBUG_SET"):
+        from scratchpad_amd import _native as _nat
+        for kv in os.environ["SP_BENCH_DEBUG_SET"].split(","):
+            k, v = kv.split("=")
+            _nat.debug_set(k.strip(), int(v))
     main()

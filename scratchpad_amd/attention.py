@@ -119,14 +119,15 @@ class HipAttnBackend(AttentionBackend):
     # LlamaAttention may hand rotary + KV store to the backend as one kernel (sp_rotary_embedding
     # with pool arguments); set False to keep the reference's two-step order
     fused_rope_kv_store = True
-    # the decode kernel can merge its split partials itself (plans with arrival counters: no merge launch).  Measured
-    # (round 4, tools/bench_decode_attn.py and bench.py): the workgroup that stores a partial has to see its stores
-    # acknowledged and then its arrival count returned before it may leave - two memory round trips with the
-    # workgroup's slot held - which costs MORE than the merge launch it saves on launches of several rounds of
-    # workgroups (headline shape 411 vs 396 us) and about the same on one full round (bs 32: 31.6 vs 28.5 us; 70B rank
-    # shape 36.2 vs 36.0); it wins where the whole launch is a few dozen workgroups (bs 1: 17.0 vs 20.0 us).
-    # "auto": fused for batches of at most FUSE_MAX_BS requests; SP_DECODE_FUSE_MERGE=1 / 0 forces it on / off
-    fused_split_merge = os.environ.get("SP_DECODE_FUSE_MERGE", "auto")
+    # the decode kernel can merge its split partials itself (plans with arrival counters: no merge launch; ABI 6).
+    # Measured in round 4 and NOT the default (profiles/r04_decode_variants.txt): the workgroup that stores a partial
+    # has to see its stores acknowledged and then its arrival count returned before it may leave - two memory round
+    # trips with the workgroup's slot held - and the last arriver's fence + merge runs on one workgroup where the merge
+    # launch spreads over the chip.  Under HIP-graph replay (a kernel boundary is cheap there) the step is slower
+    # fused at every batch size tried: bs 1 4.14 vs 4.00 ms, bs 8 4.68 vs 4.55, bs 256 20.03 vs 19.4 - 19.7 (attention
+    # 0.404 vs 0.386 - 0.395 ms per layer); only back-to-back eager launches of a few dozen workgroups gain (bs 1:
+    # 17.0 vs 20.0 us).  SP_DECODE_FUSE_MERGE=1 forces it on, "auto" = for batches of at most FUSE_MAX_BS requests.
+    fused_split_merge = os.environ.get("SP_DECODE_FUSE_MERGE", "0")
     FUSE_MAX_BS = 8
     # True: every plan's overflow word is read back right after it is built (one device sync per step: tests,
     # debugging).  False: the 16-byte header is copied to pinned memory asynchronously and checked when the

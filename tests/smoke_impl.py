@@ -99,6 +99,50 @@ def oracle_logits(name, dtype):
     return l1, l2
 
 
+def run_w64_smoke():
+    """One D = 128 launch of the 4-wave x 64-row extend kernels - the ones whose register allocation
+    tools/patch_w64_descriptor.py sizes in the linked library - against oracle.ops.extend_attention: a toolchain that
+    laid their registers out differently than the kernels' text assumes shows up HERE (the tiny model above has
+    D = 64 and never launches them).  Both forms: one workgroup per item, and persistent with a plan."""
+    from scratchpad_amd import _native
+    from tests.helpers import attn_error_units, cpu, paged_problem
+    assert _native.debug_get("w64_descriptor_patched") == 1, "the library was linked without the w64 descriptor patch"
+    dtype, Hq, Hkv, D = torch.bfloat16, 8, 2, 128
+    pre, ext = [0, 64, 5], [300, 200, 70]
+    seq = [a + b for a, b in zip(pre, ext)]
+    p = paged_problem(41, len(seq), Hq, Hkv, D, seq, dtype, "cuda")
+    g = torch.Generator().manual_seed(42)
+    q = torch.randn(sum(ext), Hq, D, generator=g).to(dtype).cuda()
+    ext_t = torch.tensor(ext, dtype=torch.int32, device="cuda")
+    start = torch.zeros(len(ext), dtype=torch.int32, device="cuda")
+    start[1:] = torch.cumsum(ext_t[:-1], 0)
+    ws = torch.empty(_native.extend_workspace_bytes(sum(ext), len(ext), Hq, D, dtype), dtype=torch.uint8, device="cuda")
+    plan = _native.extend_plan(ext_t, p["seq_lens"], sum(ext), Hq, Hkv, True)
+    c = cpu(p)
+    fn = lambda v: ops.extend_attention(q.cpu().float(), c["k_buffer"].float(), v, c["req_to_token"], c["req_pool_indices"],
+                                        c["seq_lens"], ext_t.cpu(), start.cpu(), D ** -0.5)
+    ref, aref = fn(c["v_buffer"].float()), fn(c["v_buffer"].float().abs())
+    got = {}
+    try:
+        for form, persist, use_plan in ((2, 0, None), (3, 2, plan)):
+            _native.debug_set("extend_w64", 2)
+            _native.debug_set("extend_w64_persist", persist)
+            o = torch.full_like(q, float("nan"))
+            _native.extend_attention(o, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"],
+                                     p["seq_lens"], ext_t, start, D ** -0.5, 0.0, True, max(ext), max(seq), ws, plan=use_plan)
+            torch.cuda.synchronize()
+            assert _native.debug_get("extend_last_kernel") == form, (
+                f"expected {_native.EXTEND_KERNELS[form]}, the library launched "
+                f"{_native.EXTEND_KERNELS[_native.debug_get('extend_last_kernel')]}")
+            got[form] = attn_error_units(o, ref, aref, dtype)
+            assert got[form] <= 1.0, f"{_native.EXTEND_KERNELS[form]}: {got[form]:.3f} units of bf16 round-off"
+    finally:
+        _native.debug_set("extend_w64", 1)
+        _native.debug_set("extend_w64_persist", 1)
+    print(f"smoke w64 ok: extend_w64_kernel {got[2]:.3f}, extend_w64p_kernel {got[3]:.3f} units of bf16 round-off vs the "
+          f"oracle (bound 1.0; {sum(ext)} tokens, Hq {Hq} / Hkv {Hkv} / D {D}, descriptor patch in place)")
+
+
 def run_smoke():
     torch.manual_seed(0)
     prefill, decode, nxt, gp, gd, gn, mr = run_case("a", torch.float32)
@@ -114,3 +158,4 @@ def run_smoke():
     assert r1 < 3e-2 and r2 < 3e-2, (r1, r2)
     print(f"smoke ok: fp32 rel logit dev prefill {e1:.2e} decode {e2:.2e}; "
           f"bf16+graph vs bf16 oracle {r1:.2e} {r2:.2e}")
+    run_w64_smoke()

@@ -51,3 +51,11 @@ def test_tiny_llama_bf16_and_graph_replay(name):
     # graph replay (padded from bs 3 to the bs-4 bucket) computes the same thing as eager
     assert torch.allclose(graph[1], eager[1], atol=1e-2 * float(eager[1].abs().max()))
     assert torch.equal(graph[0], eager[0]), "prefill is eager in both runs"
+
+
+def test_smoke_entry_point_covers_the_w64_kernels(capsys):
+    """__graft_entry__.smoke(): the tiny model, then one launch of each 4-wave x 64-row extend kernel at D = 128
+    (the driver's smoke must notice a library whose descriptor patch does not fit)."""
+    smoke_impl.run_smoke()
+    out = capsys.readouterr().out
+    assert "smoke ok" in out and "smoke w64 ok" in out

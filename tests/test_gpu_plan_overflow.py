@@ -63,3 +63,26 @@ def test_understated_seq_lens_sum_raises_instead_of_returning_wrong_logits():
     with pytest.raises(RuntimeError, match="split plan overflow"):
         worker.forward_batch_generation(bad)
     worker.forward_batch_generation(_decode_batch(mr, lens, sum(lens)))
+
+
+def test_fused_split_merge_in_the_backend_gives_the_same_logits(monkeypatch):
+    """HipAttnBackend.fused_split_merge = "1" (SP_DECODE_FUSE_MERGE=1; measured slower under graph replay, hence not the
+    default): the plans carry arrival counters and every layer's decode launch merges its own splits - the logits of a
+    step with ~10 splits per request are the bits of the default (merge launch) path, eager and replayed."""
+    from scratchpad_amd.attention import HipAttnBackend
+    from scratchpad_amd.model_runner import TpModelWorker
+    lens = [600, 130, 64, 1999]
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setattr(HipAttnBackend, "fused_split_merge", mode)
+        mr = _runner()
+        backend = mr.attn_backend
+        assert (backend._plan_groups > 0) == (mode == "1") and backend._fuse(len(lens)) == (mode == "1")
+        batch = _decode_batch(mr, lens, sum(lens))
+        out, _ = TpModelWorker(mr).forward_batch_generation(batch)
+        backend.check_plans()
+        outs.append(out.next_token_logits.float().cpu())
+        if mode == "1":
+            plan, slots, _ = backend.forward_metadata[3][0]
+            assert int(plan[4 + len(lens) + 2 * slots:].abs().sum()) == 0, "arrival counters back at zero after 2 layers"
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
