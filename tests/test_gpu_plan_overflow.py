@@ -68,7 +68,7 @@ def test_understated_seq_lens_sum_raises_instead_of_returning_wrong_logits():
 def test_fused_split_merge_in_the_backend_gives_the_same_logits(monkeypatch):
     """HipAttnBackend.fused_split_merge = "1" (SP_DECODE_FUSE_MERGE=1; measured slower under graph replay, hence not the
     default): the plans carry arrival counters and every layer's decode launch merges its own splits - the logits of a
-    step with ~10 splits per request are the bits of the default (merge launch) path, eager and replayed."""
+    step with ~10 splits per request are the bits of the default (merge launch) path."""
     from scratchpad_amd.attention import HipAttnBackend
     from scratchpad_amd.model_runner import TpModelWorker
     lens = [600, 130, 64, 1999]
