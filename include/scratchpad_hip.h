@@ -220,16 +220,20 @@ SP_API size_t sp_extend_attention_workspace_bytes(int64_t num_tokens, int batch_
  * and shared by every layer (the counterpart of flashinfer's begin_forward() for the prefill wrappers,
  * flashinfer_backend.py:400-444, 672-830).  It only decides which workgroup computes which rows (no
  * empty workgroups on ragged batches, longest rows first); results do not depend on it.  The plan carries
- * a header (block size, head counts, num_tokens, batch size): a launch whose own values differ - a stale
- * plan of another step, a plan built for other head counts - does not use its items and derives each
- * workgroup's rows by walking the requests instead, so a wrong plan costs order, never rows.
+ * a header (block size, head counts, num_tokens, batch size): a launch of ANOTHER SHAPE - other head counts,
+ * another token total or batch size - does not use its items and derives each workgroup's rows by walking the
+ * requests instead.  That check identifies a launch shape, not a step: a plan left from an earlier step with
+ * the same batch size and token total but other per-request lengths passes it and row blocks are then dropped
+ * or computed twice.  REQUIREMENT: call sp_extend_plan for every step, with that step's extend_seq_lens, before
+ * the step's first sp_extend_attention (HipAttnBackend.init_forward_metadata does).
  * sp_extend_plan_bytes() sizes the int32 buffer; `plan_bytes` (sp_extend_attention) must cover it, else
  * SP_ERR_WORKSPACE.  `causal` of sp_extend_plan is reserved (the item list does not depend on it).
  * The last 2 KiB of the buffer are counters of the attention kernel (the persistent form of the 4 x 64-row
  * kernel hands its workgroups the items by ticket): written by sp_extend_plan (zeros), counted up during
  * a launch that owns the plan and zero again when it ends - hence `plan` is not const, and one plan
- * buffer serves one launch at a time (the layers of a forward, one after the other on a stream: yes;
- * two streams at once: give each its own copy).  A plan that is not the launch's own is only read.   */
+ * buffer serves one launch at a time (the layers of a forward, one after the other on ONE stream: yes;
+ * two streams at once: give each its own copy); a launch that was aborted leaves the counters dirty until
+ * the next sp_extend_plan.  A plan that is not the launch's own is only read.                          */
 SP_API size_t sp_extend_plan_bytes(int64_t num_tokens, int batch_size, int num_q_heads, int num_kv_heads);
 SP_API int sp_extend_plan(int32_t* plan, size_t plan_bytes, const int32_t* extend_seq_lens, const void* seq_lens,
                    int idx64, int batch_size, int64_t num_tokens, int num_q_heads, int num_kv_heads,

@@ -34,8 +34,10 @@ struct ExtendArgs {
   float defer;  // the running maximum may trail the true row maximum by this much (log2 units)
   // optional work list from sp_extend_plan: header [count, BM, Hq, Hkv, num_tokens, bs, 0, 0], then
   // (request, row block) x count from word kExtPlanHeader.  A workgroup that finds the header built for
-  // another block size / head counts / step derives its item by walking the requests instead (correct,
-  // merely unordered): a stale or foreign plan can never drop rows.
+  // another block size / head counts / token total / batch size derives its item by walking the requests instead
+  // (correct, merely unordered).  The header identifies a launch SHAPE, not a step: a plan of an earlier step with
+  // the same shape but other per-request lengths is not detected - the host rebuilds the plan every step
+  // (scratchpad_hip.h, sp_extend_plan).
   const int32_t* plan;
   int plan_items;       // grid rows when a plan is given (an upper bound of its count)
   int num_tokens;       // sum of the extend lengths (host-known)

@@ -258,6 +258,12 @@ class ScheduleBatch:
         sampling parameters, encoder lengths, pending output ids - is merged through ``merge_batch``
         exactly as the reference does; only input_ids / out_cache_loc are the concatenations built
         here (merge_batch resets out_cache_loc)."""
+        # the reference's scheduler never mixes when either side returns logprobs (scheduler.py:944-949, "TODO: support
+        # return_logprob + mixed chunked prefill"): extend_input_logprob_token_ids is not extended for the running rows,
+        # so the logits processor would index [tokens, ids] with mismatched lengths.  Refuse here instead of there.
+        if self.return_logprob or running_batch.return_logprob:
+            raise RuntimeError("mix_with_running: a MIXED batch with return_logprob is not supported (the reference's "
+                               "scheduler does not build one either, scheduler/scheduler.py:944-949)")
         self.forward_mode = ForwardMode.MIXED
         running_bs = running_batch.batch_size()
         for req in running_batch.reqs:
