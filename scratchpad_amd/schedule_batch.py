@@ -258,12 +258,13 @@ class ScheduleBatch:
         sampling parameters, encoder lengths, pending output ids - is merged through ``merge_batch``
         exactly as the reference does; only input_ids / out_cache_loc are the concatenations built
         here (merge_batch resets out_cache_loc)."""
-        # the reference's scheduler never mixes when either side returns logprobs (scheduler.py:944-949, "TODO: support
-        # return_logprob + mixed chunked prefill"): extend_input_logprob_token_ids is not extended for the running rows,
-        # so the logits processor would index [tokens, ids] with mismatched lengths.  Refuse here instead of there.
-        if self.return_logprob or running_batch.return_logprob:
-            raise RuntimeError("mix_with_running: a MIXED batch with return_logprob is not supported (the reference's "
-                               "scheduler does not build one either, scheduler/scheduler.py:944-949)")
+        # The reference's scheduler never mixes when either side returns logprobs (scheduler.py:944-949, "TODO: support
+        # return_logprob + mixed chunked prefill"): its mix_with_running extends extend_logprob_start_lens by zeros but
+        # not extend_input_logprob_token_ids, so the logits processor would index [kept positions, ids] with
+        # mismatched lengths.  Here the id list is extended the way prepare_for_extend pads it ("the NEXT input token;
+        # zero past the prompt"): a running row is one kept position whose next token is not known yet -> one zero.
+        kept_own = sum(e - s for e, s in zip(self.extend_lens, self.extend_logprob_start_lens or [0] * len(self.extend_lens)))
+        own_ids = self.extend_input_logprob_token_ids
         self.forward_mode = ForwardMode.MIXED
         running_bs = running_batch.batch_size()
         for req in running_batch.reqs:
@@ -281,6 +282,10 @@ class ScheduleBatch:
         self.extend_lens = self.extend_lens + [1] * running_bs
         self.extend_num_tokens += running_bs
         self.extend_logprob_start_lens = list(self.extend_logprob_start_lens) + [0] * running_bs
+        if self.return_logprob:            # (merge_batch has or-ed the two flags)
+            if own_ids is None:
+                own_ids = torch.zeros(kept_own, dtype=torch.int64)
+            self.extend_input_logprob_token_ids = torch.cat([own_ids.cpu(), torch.zeros(running_bs, dtype=torch.int64)])
 
     def prepare_for_decode(self):
         self.forward_mode = ForwardMode.DECODE

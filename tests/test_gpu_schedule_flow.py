@@ -103,6 +103,28 @@ def test_extend_decode_mixed_trace_matches_oracle():
                       mix.out_cache_loc.cpu(), torch.tensor(mix.prefix_lens, dtype=torch.int32),
                       torch.tensor(mix.extend_lens, dtype=torch.int32))
     close(out.next_token_logits, ref, "mixed batch")
+    # ---- 4. the same kind of batch with prompt logprobs asked for: one id per kept position - the running
+    # rows contribute one each - so the processor's index lists line up; sampled rows and input logprobs = the oracle's
+    for r, tok in zip(mix.reqs, out.next_token_logits.argmax(-1).tolist()):
+        r.output_ids.append(tok)
+    mix.output_ids = out.next_token_logits.argmax(-1)
+    mix.prepare_for_decode()
+    lp = Req("r3", torch.randint(0, shape.vocab, (5,), generator=gen).tolist(), return_logprob=True, logprob_start_len=1,
+             top_logprobs_num=2)
+    mix2 = ScheduleBatch([lp], mr.req_to_token_pool, mr.token_to_kv_pool_allocator, dev)
+    mix2.prepare_for_extend()
+    assert mix2.extend_input_logprob_token_ids.tolist() == lp.origin_input_ids[2:] + [0]
+    mix2.mix_with_running(mix)
+    assert mix2.extend_lens == [5, 1, 1, 1] and mix2.extend_logprob_start_lens == [1, 0, 0, 0]
+    assert mix2.extend_input_logprob_token_ids.tolist() == lp.origin_input_ids[2:] + [0] + [0, 0, 0]
+    out2, _ = worker.forward_batch_generation(mix2.get_model_worker_batch())
+    mirror_tables()
+    ref2 = oracle_step(shape, w, okv, "extend", mix2.input_ids.cpu(), mix2.req_pool_indices.cpu(), mix2.seq_lens.cpu(),
+                       mix2.out_cache_loc.cpu(), torch.tensor(mix2.prefix_lens, dtype=torch.int32),
+                       torch.tensor(mix2.extend_lens, dtype=torch.int32))
+    close(out2.next_token_logits, ref2, "mixed batch with prompt logprobs: sampled rows")
+    assert out2.input_token_logprobs.shape[0] == 4 + 3 and torch.isfinite(out2.input_token_logprobs).all()
+    assert [len(v) for v in out2.input_top_logprobs_val] == [4, 1, 1, 1]
     # the two pools hold the same K rows in the same slots
     for layer in range(shape.layers):
         assert torch.allclose(mr.token_to_kv_pool.get_key_buffer(layer).cpu(), okv.k[layer], atol=2e-5)

@@ -361,6 +361,10 @@ def test_mixed_batch_merges_sampling_info_like_the_reference():
     new.mix_with_running(run)
     assert [r.extend_input_len for r in new.reqs] == [4, 1, 1]
     assert new.extend_logprob_start_lens == [0, 0, 0]
+    # one id per KEPT position - the prefill row's 4 (zeros: it asked for none) + one zero per running row
+    # (its next token is not known yet) - so LogitsProcessor's logprobs[arange, ids] lines up (the reference leaves
+    # the list short, schedule_batch.py:1073-1101, and its scheduler never builds this batch, scheduler.py:944-949)
+    assert new.extend_input_logprob_token_ids.tolist() == [0] * 6
     assert new.return_logprob and new.top_logprobs_nums == [0, 2, 0] and new.token_ids_logprobs == [None, None, [3, 4]]
     assert new.has_grammar and not new.has_stream
     new.reqs[1].init_next_round_input()                 # the pin does not outlive the round
