@@ -81,7 +81,7 @@ SIGNATURES = {
     "sp_custom_all_reduce": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _sz, _i64, _vp, _vp]),
     "sp_fused_allreduce_add_rmsnorm": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _f32, _i32, _vp, _i32, _i32,
                                               _sz, _i64, _vp, _vp]),
-    "sp_gemm_skinny": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp]),
+    "sp_gemm_skinny": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _vp]),
 }
 
 
@@ -727,6 +727,27 @@ def extend_rows(x: torch.Tensor, rows: int) -> Optional[torch.Tensor]:
     return torch.as_strided(x, (rows, x.shape[1]), (x.stride(0), 1), x.storage_offset())
 
 
+_SILU_LINEAR_ON = os.environ.get("SP_SKINNY_SILU", "1") != "0"
+
+
+def silu_mul_linear(gate_up: torch.Tensor, weight: torch.Tensor) -> Optional[torch.Tensor]:
+    """SiluAndMul(gate_up) @ weight.T as ONE launch (sp_gemm_skinny, prologue 1) for a step of at most
+    SKINNY_MAX_ROWS tokens: gate_up [M, 2K] (gate | up), weight [N, K].  Bit for bit silu_and_mul followed by the
+    skinny projection.  None when the shape is not taken (the caller runs the two steps)."""
+    if not (_SKINNY_ON and _SILU_LINEAR_ON and gate_up.is_cuda and gate_up.dim() == 2 and weight.dim() == 2
+            and 0 < gate_up.shape[0] <= SKINNY_MAX_ROWS and gate_up.shape[1] == 2 * weight.shape[1]
+            and gate_up.dtype in (torch.float16, torch.bfloat16) and weight.dtype == gate_up.dtype
+            and weight.shape[1] % 32 == 0 and gate_up.stride(1) == 1 and weight.stride(1) == 1
+            and gate_up.stride(0) % 8 == 0 and weight.stride(0) % 8 == 0
+            and gate_up.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0):
+        return None
+    M, (N, K) = gate_up.shape[0], weight.shape
+    out = empty_rows(M, N, gate_up.dtype, gate_up.device)
+    _check(load().sp_gemm_skinny(out.data_ptr(), gate_up.data_ptr(), weight.data_ptr(), M, N, K, gate_up.stride(0),
+                                 weight.stride(0), out.stride(0), 1, _dt(gate_up), _stream()), "sp_gemm_skinny(silu)")
+    return out
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """x @ weight.T.  Small-batch 16-bit products go to the weight-streaming kernel
     (sp_gemm_skinny) where it pays; everything else is the library GEMM - exactly F.linear, except
@@ -742,7 +763,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
         N = weight.shape[0]
         out = empty_rows(M, N, x.dtype, x.device)
         _check(load().sp_gemm_skinny(out.data_ptr(), x.data_ptr(), weight.data_ptr(), M, N, K, x.stride(0),
-                                     weight.stride(0), out.stride(0), _dt(x), _stream()), "sp_gemm_skinny")
+                                     weight.stride(0), out.stride(0), 0, _dt(x), _stream()), "sp_gemm_skinny")
         return out
     if (_LIBRARY_ROWS and x.is_cuda and x.dim() == 2 and 0 < x.shape[0] <= SLACK_MAX_ROWS and weight.dim() == 2
             and x.dtype in (torch.float16, torch.bfloat16) and weight.dtype == x.dtype and x.stride(1) == 1):

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void rmsnorm_scalar_kernel(void* out,  // m
 // ------------------------------------------------------------------------------ SiLU-and-mul
 // nn/layers/activation.py:22-24: F.silu(a) * b with both factors in `dtype` (silu rounded
 // before the product, as torch does).
-__device__ __forceinline__ float silu_f32(float a) { return a / (1.0f + expf(-a)); }
+__device__ __forceinline__ float silu_f32(float a) { return silu_ref(a); }   // sp_common.h
 
 template <typename Tag>
 __global__ __launch_bounds__(kBlock) void silu_mul_vec_kernel(void* __restrict__ out,

@@ -16,6 +16,13 @@
 //   * 8 k-steps of loads are in flight per wave before the first MFMA consumes one;
 //   * the 8 waves' 16x16 partial tiles are summed through LDS in a fixed order (deterministic),
 //     rounded once, and stored.
+//
+// Prologue fusion (round 4): with `prologue` = 1 the x operand is SiluAndMul (nn/layers/activation.py:21-31) of a
+// [M, 2K] gate|up row pair, computed on the way into the B registers - round(silu(gate)) * up, rounded, bit for bit
+// what sp_silu_and_mul would have written - so LlamaMLP's act_fn + down_proj (llama.py:62-66) are ONE launch at <= 16
+// rows: the activation kernel, its launch boundary and the write + re-read of the [M, inter] tensor go.  Every
+// workgroup recomputes the M x K activations it needs (all of them: 8 exponentials per lane and k-step, behind loads
+// that are in flight anyway).
 #include "sp_common.h"
 
 namespace sp {
@@ -45,6 +52,28 @@ struct SkinnyArgs {
   int64_t x_stride, w_stride, out_stride;   // elements
 };
 
+// the B fragment of k-step `off` (bytes): PRO 0: 16 bytes of x; PRO 1: SiluAndMul of the gate (xp + off) and up
+// (xp + 2 K + off) halves of the row - the arithmetic of silu_mul_vec_kernel (elementwise.hip), op for op
+template <typename Tag, int PRO>
+__device__ __forceinline__ u32x4 skinny_x_load(const char* xp, int64_t off, int64_t up_off, u32x4& up_raw) {
+  if constexpr (PRO == 1) up_raw = ld16(xp + up_off + off);
+  return ld16(xp + off);
+}
+template <typename Tag, int PRO>
+__device__ __forceinline__ u32x4 skinny_x_finish(const u32x4& raw, const u32x4& up_raw) {
+  if constexpr (PRO == 0) {
+    return raw;
+  } else {
+    typedef Elem<Tag> E;
+    float g[8], u[8], y[8];
+    unpack16<Tag>(raw, g);
+    unpack16<Tag>(up_raw, u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = __fmul_rn(E::round(silu_ref(g[e])), u[e]);
+    return pack16<Tag>(y);
+  }
+}
+
 constexpr int kSkWaves = 8;
 
 // NB = 16-column blocks per workgroup: one x fragment feeds NB MFMAs (x traffic out of L2 drops to
@@ -57,7 +86,7 @@ constexpr int kSkWaves = 8;
 // gate_up 46.5 vs 43.3, LM head 186 vs 166; bench.py --bs 1: 4.13 vs 3.98 ms/step (round 3, tools/bench_gemv.py).
 __device__ __forceinline__ u32x4 ld16_nt(const void* p) { return __builtin_nontemporal_load((const u32x4*)p); }
 
-template <typename Tag, int NB, int UNROLL, bool NT>
+template <typename Tag, int NB, int UNROLL, bool NT, int PRO>
 __global__ __launch_bounds__(kSkWaves * 64) void gemm_skinny_kernel(SkinnyArgs a) {
   typedef Elem<Tag> E;
   __shared__ float red[kSkWaves][NB][16 * 17];
@@ -73,6 +102,7 @@ __global__ __launch_bounds__(kSkWaves * 64) void gemm_skinny_kernel(SkinnyArgs a
   }
   const char* xp = a.x + ((int64_t)min(r16, a.M - 1) * a.x_stride + 8 * q) * 2;
   const int ksteps = a.K / 32;
+  const int64_t up_off = (int64_t)a.K * 2;            // PRO 1: the up half of a gate|up row, in bytes
   f32x4_g acc[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4_g{0.f, 0.f, 0.f, 0.f};
@@ -80,22 +110,32 @@ __global__ __launch_bounds__(kSkWaves * 64) void gemm_skinny_kernel(SkinnyArgs a
   // this wave's k-steps: wave, wave + 8, ...; processed in groups of UNROLL with all loads first
   int ks = wave;
   for (; ks + (UNROLL - 1) * kSkWaves < ksteps; ks += UNROLL * kSkWaves) {
-    u32x4 wf[UNROLL][NB], xf[UNROLL];
+    u32x4 wf[UNROLL][NB], xf[UNROLL], xu[PRO == 1 ? UNROLL : 1];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int64_t off = (int64_t)(ks + u * kSkWaves) * 64;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) wf[u][nb] = NT ? ld16_nt(wp[nb] + off) : ld16(wp[nb] + off);
-      xf[u] = mrow ? ld16(xp + off) : zero;
+      // (PRO 1 loads unconditionally - xp is clamped to a valid row - and zeroes the padding rows after the
+      // activation: no exec-masked memory operations between the weight loads)
+      if constexpr (PRO == 0) xf[u] = mrow ? ld16(xp + off) : zero;
+      else xf[u] = skinny_x_load<Tag, PRO>(xp, off, up_off, xu[PRO == 1 ? u : 0]);
     }
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u)
+    for (int u = 0; u < UNROLL; ++u) {
+      if constexpr (PRO != 0) {
+        const u32x4 y = skinny_x_finish<Tag, PRO>(xf[u], xu[PRO == 1 ? u : 0]);
+        xf[u] = mrow ? y : zero;
+      }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_g<Tag>(wf[u][nb], xf[u], acc[nb]);
+    }
   }
   for (; ks < ksteps; ks += kSkWaves) {
     const int64_t off = (int64_t)ks * 64;
-    const u32x4 xf = mrow ? ld16(xp + off) : zero;
+    u32x4 xu1 = zero;
+    const u32x4 raw = skinny_x_load<Tag, PRO>(xp, off, up_off, xu1);
+    const u32x4 xf = mrow ? skinny_x_finish<Tag, PRO>(raw, xu1) : zero;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_g<Tag>(NT ? ld16_nt(wp[nb] + off) : ld16(wp[nb] + off), xf, acc[nb]);
   }
@@ -122,26 +162,28 @@ static int g_skinny_nt = 0;     // sp_debug_set("skinny_nt", 0 / 1): A/B switch 
 void set_skinny_nt(int v) { g_skinny_nt = v; }
 
 template <typename Tag>
-static void launch_skinny(const SkinnyArgs& a, hipStream_t st) {
-  const dim3 block(kSkWaves * 64);
-  if (g_skinny_nt) gemm_skinny_kernel<Tag, 1, 8, true><<<dim3((a.N + 15) / 16), block, 0, st>>>(a);
-  else gemm_skinny_kernel<Tag, 1, 8, false><<<dim3((a.N + 15) / 16), block, 0, st>>>(a);
+static void launch_skinny(const SkinnyArgs& a, int prologue, hipStream_t st) {
+  const dim3 block(kSkWaves * 64), grid((a.N + 15) / 16);
+  if (prologue == 1) gemm_skinny_kernel<Tag, 1, 8, false, 1><<<grid, block, 0, st>>>(a);
+  else if (g_skinny_nt) gemm_skinny_kernel<Tag, 1, 8, true, 0><<<grid, block, 0, st>>>(a);
+  else gemm_skinny_kernel<Tag, 1, 8, false, 0><<<grid, block, 0, st>>>(a);
 }
 
 }  // namespace sp
 
 extern "C" int sp_gemm_skinny(void* out, const void* x, const void* w, int M, int N, int K, int64_t x_stride,
-                              int64_t w_stride, int64_t out_stride, int dtype, void* stream) {
-  SP_CHECK_ARG(M >= 0 && N >= 0 && K > 0);
+                              int64_t w_stride, int64_t out_stride, int prologue, int dtype, void* stream) {
+  SP_CHECK_ARG(M >= 0 && N >= 0 && K > 0 && (prologue == 0 || prologue == 1));
   if (M == 0 || N == 0) return SP_OK;
   SP_CHECK_ARG(out && x && w);
   if (M > 16 || K % 32 != 0) return SP_ERR_UNSUPPORTED;
   if (dtype != SP_BF16 && dtype != SP_F16) return SP_ERR_UNSUPPORTED;
-  SP_CHECK_ARG(x_stride % 8 == 0 && w_stride % 8 == 0 && x_stride >= K && w_stride >= K && out_stride >= N);
+  SP_CHECK_ARG(x_stride % 8 == 0 && w_stride % 8 == 0 && x_stride >= (prologue == 1 ? 2 : 1) * (int64_t)K &&
+               w_stride >= K && out_stride >= N);
   SP_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0);
   sp::SkinnyArgs a{(const char*)x, (const char*)w, out, M, N, K, x_stride, w_stride, out_stride};
-  if (dtype == SP_BF16) sp::launch_skinny<sp::bf16_tag>(a, (hipStream_t)stream);
-  else sp::launch_skinny<sp::f16_tag>(a, (hipStream_t)stream);
+  if (dtype == SP_BF16) sp::launch_skinny<sp::bf16_tag>(a, prologue, (hipStream_t)stream);
+  else sp::launch_skinny<sp::f16_tag>(a, prologue, (hipStream_t)stream);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

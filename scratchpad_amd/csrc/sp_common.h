@@ -139,6 +139,11 @@ __device__ __forceinline__ u32x4 pack16<f16_tag>(const float* f) {
   return v;
 }
 
+// SiLU as the reference's torch path evaluates it in fp32 (nn/layers/activation.py:22-24): a / (1 + exp(-a)), every
+// operation rounded on its own whatever the translation unit's contraction mode (shared by sp_silu_and_mul and the
+// fused prologue of sp_gemm_skinny, which must agree bit for bit)
+__device__ __forceinline__ float silu_ref(float a) { return __fdiv_rn(a, __fadd_rn(1.0f, expf(-a))); }
+
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *(const u32x4*)p; }
 __device__ __forceinline__ void st16(void* p, const u32x4& v) { *(u32x4*)p = v; }
 

@@ -24,7 +24,7 @@ def test_skinny_gemm_matches_fp32_reference(dtype, M, N, K):
     w = (torch.randn(N, K, generator=g) * 0.05).to(dtype).cuda()
     got = torch.empty(M, N, dtype=dtype, device="cuda")      # the kernel itself, whatever the dispatch rule says
     _native._check(_native.load().sp_gemm_skinny(got.data_ptr(), x.data_ptr(), w.data_ptr(), M, N, K, x.stride(0),
-                                                 w.stride(0), got.stride(0), _native._dt(x), _native._stream()),
+                                                 w.stride(0), got.stride(0), 0, _native._dt(x), _native._stream()),
                    "sp_gemm_skinny")
     check(got, x, w, dtype)
     got = _native.linear(x, w)
@@ -52,8 +52,64 @@ def test_skinny_gemm_views_fallbacks_and_determinism():
     w32 = torch.randn(8, 64, generator=g).cuda()
     assert torch.equal(_native.linear(x32, w32), torch.nn.functional.linear(x32, w32))
     lib = __import__("ctypes").CDLL(_native.lib_path())
-    assert lib.sp_gemm_skinny(None, None, None, 4, 8, 64, 64, 64, 8, 2, None) == -1      # null pointers
-    assert lib.sp_gemm_skinny(1, 1, 1, 17, 8, 64, 64, 64, 8, 2, None) == -2              # unsupported rows
+    assert lib.sp_gemm_skinny(None, None, None, 4, 8, 64, 64, 64, 8, 0, 2, None) == -1      # null pointers
+    assert lib.sp_gemm_skinny(1, 1, 1, 17, 8, 64, 64, 64, 8, 0, 2, None) == -2              # unsupported rows
+    assert lib.sp_gemm_skinny(1, 1, 1, 4, 8, 64, 64, 64, 8, 2, 2, None) == -1               # unknown prologue
+    assert lib.sp_gemm_skinny(1, 1, 1, 4, 8, 64, 64, 64, 8, 1, 2, None) == -1               # SiLU prologue: x rows hold 2 K
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [1, 3, 8, 16])
+@pytest.mark.parametrize("N,K", [(4096, 14336), (100, 64), (4104, 2048), (512, 288)])
+def test_silu_mul_fused_into_the_skinny_projection_is_bit_identical(dtype, M, N, K):
+    """sp_gemm_skinny(prologue = 1): SiluAndMul (nn/layers/activation.py:21-31) of the gate|up rows computed on the
+    way into the matrix-core operand registers - the bits of sp_silu_and_mul followed by the plain skinny projection,
+    and within one output rounding of the fp32 reference on the reference's own activation arithmetic."""
+    from scratchpad_amd import _native
+    g = torch.Generator().manual_seed(M * 77 + N + K)
+    gate_up = (torch.randn(M, 2 * K, generator=g) * 2.0).to(dtype).cuda()
+    gate_up[0, :4] = torch.tensor([0.0, -30.0, 30.0, -0.0]).to(dtype)          # saturating / signed-zero gates
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dtype).cuda()
+    act = _native.silu_and_mul(gate_up)
+    two_step = torch.empty(M, N, dtype=dtype, device="cuda")
+    _native._check(_native.load().sp_gemm_skinny(two_step.data_ptr(), act.data_ptr(), w.data_ptr(), M, N, K, act.stride(0),
+                                                 w.stride(0), two_step.stride(0), 0, _native._dt(act), _native._stream()),
+                   "sp_gemm_skinny")
+    fused = _native.silu_mul_linear(gate_up, w)
+    assert fused is not None and fused.shape == (M, N) and torch.equal(fused, two_step)
+    ref_act = (torch.nn.functional.silu(gate_up[:, :K].float()).to(dtype) * gate_up[:, K:]).float()   # torch's roundings
+    check(fused, ref_act.to(dtype), w, dtype)
+    # a row-strided view of a wider buffer (the merged projection's output inside a spare-row allocation)
+    wide = torch.zeros(M + 2, 2 * K + 64, dtype=dtype, device="cuda")
+    wide[:M, :2 * K] = gate_up
+    assert torch.equal(_native.silu_mul_linear(wide[:M, :2 * K], w), two_step)
+    # shapes the kernel does not take: the caller keeps the two steps
+    assert _native.silu_mul_linear(torch.zeros(17, 2 * K, dtype=dtype, device="cuda"), w) is None
+    assert _native.silu_mul_linear(gate_up[:, :K], w) is None
+
+
+def test_small_step_mlp_uses_the_fused_projection_and_matches_the_two_step_form(monkeypatch):
+    from scratchpad_amd import _native, distributed as dist_
+    from scratchpad_amd.llama import LlamaMLP
+    if not dist_.model_parallel_is_initialized():
+        dist_.initialize_model_parallel(1)
+    torch.manual_seed(3)
+    mlp = LlamaMLP(512, 1408, "silu", torch.bfloat16).cuda()
+    for p_ in mlp.parameters():
+        p_.data.normal_(0.0, 0.05)
+    calls = []
+    orig = _native.silu_mul_linear
+    monkeypatch.setattr(_native, "silu_mul_linear", lambda a, b: calls.append(a.shape[0]) or orig(a, b))
+    for rows in (1, 16, 17):
+        x = torch.randn(rows, 512, device="cuda").bfloat16()
+        got = mlp(x)
+        gate_up, _ = mlp.gate_up_proj(x)
+        want, _ = mlp.down_proj(mlp.act_fn(gate_up))
+        if rows <= 16:
+            assert torch.equal(got, want)
+        else:
+            assert torch.allclose(got.float(), want.float(), atol=1e-2)
+    assert calls == [1, 16, 17]
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
