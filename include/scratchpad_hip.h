@@ -292,12 +292,12 @@ SP_API int sp_top_k_top_p_min_p_renorm(const float* probs, int64_t row_stride, c
  *      1033-1155) and the LM-head matmul (nn/layers/logits_processor.py:340-376) when the step has
  *      at most 16 tokens; a weight-streaming kernel (HBM-bound).  Returns SP_ERR_UNSUPPORTED for
  *      other shapes: the caller keeps the library GEMM.  Strides in elements.
- *      `prologue` (ABI 6): 0 = x is [M, K]; 1 = x is the [M, 2K] gate|up output of the merged column projection and
- *      the operand is SiluAndMul(x) (nn/layers/activation.py:21-31) computed inside the kernel, bit for bit what
- *      sp_silu_and_mul would have written: LlamaMLP's act_fn + down_proj (nn/models/llama/llama.py:62-66) in one
- *      launch.                                                                                     */
+ *      `epilogue` (ABI 6): 0 = out[M, N] as above.  1 = w is the merged gate|up matrix [2 N, K] of LlamaMLP
+ *      (gate rows first; MergedColumnParallelLinear, linear.py:423-470) and out[M, N] = SiluAndMul of the projection
+ *      (nn/layers/activation.py:21-31), bit for bit the plain call followed by sp_silu_and_mul: gate_up_proj +
+ *      act_fn (nn/models/llama/llama.py:62-66) in one launch.                                      */
 SP_API int sp_gemm_skinny(void* out, const void* x, const void* w, int M, int N, int K, int64_t x_stride,
-                   int64_t w_stride, int64_t out_stride, int prologue, int dtype, void* stream);
+                   int64_t w_stride, int64_t out_stride, int epilogue, int dtype, void* stream);
 
 /* ---- Direct all-reduce through IPC-mapped peer regions: fills GroupCoordinator.ca_comm
  *      (distributed/parallel_state.py:266-267, 326-347; the reference never constructs one and always

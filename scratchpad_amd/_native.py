@@ -730,21 +730,23 @@ def extend_rows(x: torch.Tensor, rows: int) -> Optional[torch.Tensor]:
 _SILU_LINEAR_ON = os.environ.get("SP_SKINNY_SILU", "1") != "0"
 
 
-def silu_mul_linear(gate_up: torch.Tensor, weight: torch.Tensor) -> Optional[torch.Tensor]:
-    """SiluAndMul(gate_up) @ weight.T as ONE launch (sp_gemm_skinny, prologue 1) for a step of at most
-    SKINNY_MAX_ROWS tokens: gate_up [M, 2K] (gate | up), weight [N, K].  Bit for bit silu_and_mul followed by the
-    skinny projection.  None when the shape is not taken (the caller runs the two steps)."""
-    if not (_SKINNY_ON and _SILU_LINEAR_ON and gate_up.is_cuda and gate_up.dim() == 2 and weight.dim() == 2
-            and 0 < gate_up.shape[0] <= SKINNY_MAX_ROWS and gate_up.shape[1] == 2 * weight.shape[1]
-            and gate_up.dtype in (torch.float16, torch.bfloat16) and weight.dtype == gate_up.dtype
-            and weight.shape[1] % 32 == 0 and gate_up.stride(1) == 1 and weight.stride(1) == 1
-            and gate_up.stride(0) % 8 == 0 and weight.stride(0) % 8 == 0
-            and gate_up.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0):
+def linear_silu_mul(x: torch.Tensor, gate_up_weight: torch.Tensor) -> Optional[torch.Tensor]:
+    """SiluAndMul(x @ gate_up_weight.T) as ONE launch (sp_gemm_skinny, epilogue 1) for a step of at most
+    SKINNY_MAX_ROWS tokens: x [M, K], gate_up_weight [2 I, K] (gate rows first), result [M, I].  Bit for bit the
+    skinny projection followed by silu_and_mul.  None when the shape is not taken (the caller runs the two steps)."""
+    if not (_SKINNY_ON and _SILU_LINEAR_ON and x.is_cuda and x.dim() == 2 and gate_up_weight.dim() == 2
+            and 0 < x.shape[0] <= SKINNY_MAX_ROWS and gate_up_weight.shape[1] == x.shape[1]
+            and gate_up_weight.shape[0] % 16 == 0
+            and x.dtype in (torch.float16, torch.bfloat16) and gate_up_weight.dtype == x.dtype
+            and x.shape[1] % 32 == 0 and x.stride(1) == 1 and gate_up_weight.stride(1) == 1
+            and x.stride(0) % 8 == 0 and gate_up_weight.stride(0) % 8 == 0
+            and x.data_ptr() % 16 == 0 and gate_up_weight.data_ptr() % 16 == 0):
         return None
-    M, (N, K) = gate_up.shape[0], weight.shape
-    out = empty_rows(M, N, gate_up.dtype, gate_up.device)
-    _check(load().sp_gemm_skinny(out.data_ptr(), gate_up.data_ptr(), weight.data_ptr(), M, N, K, gate_up.stride(0),
-                                 weight.stride(0), out.stride(0), 1, _dt(gate_up), _stream()), "sp_gemm_skinny(silu)")
+    M, K = x.shape
+    inter = gate_up_weight.shape[0] // 2
+    out = empty_rows(M, inter, x.dtype, x.device)
+    _check(load().sp_gemm_skinny(out.data_ptr(), x.data_ptr(), gate_up_weight.data_ptr(), M, inter, K, x.stride(0),
+                                 gate_up_weight.stride(0), out.stride(0), 1, _dt(x), _stream()), "sp_gemm_skinny(silu)")
     return out
 
 

@@ -17,12 +17,15 @@
 //   * the 8 waves' 16x16 partial tiles are summed through LDS in a fixed order (deterministic),
 //     rounded once, and stored.
 //
-// Prologue fusion (round 4): with `prologue` = 1 the x operand is SiluAndMul (nn/layers/activation.py:21-31) of a
-// [M, 2K] gate|up row pair, computed on the way into the B registers - round(silu(gate)) * up, rounded, bit for bit
-// what sp_silu_and_mul would have written - so LlamaMLP's act_fn + down_proj (llama.py:62-66) are ONE launch at <= 16
-// rows: the activation kernel, its launch boundary and the write + re-read of the [M, inter] tensor go.  Every
-// workgroup recomputes the M x K activations it needs (all of them: 8 exponentials per lane and k-step, behind loads
-// that are in flight anyway).
+// Epilogue fusion (round 4): with `epilogue` = 1 the weight is the merged gate|up matrix [2 I, K] of LlamaMLP
+// (nn/models/llama/llama.py:62-66) and the output is SiluAndMul (nn/layers/activation.py:21-31) of the projection,
+// [M, I]: a workgroup streams 8 gate rows and the 8 matching up rows (still 16 rows of W, still one workgroup per
+// 16 rows), and the lanes that finish the gate columns take the up sums of the same columns from the LDS reduction
+// and write round(silu(round(gate))) * round(up), rounded - bit for bit the plain projection followed by
+// sp_silu_and_mul, with the activation launch, its boundary and the [M, 2 I] round trip gone.  (The other way round -
+// the activation in the PROLOGUE of the down projection, every workgroup recomputing the M x K activations it
+// streams - was built first and measured 2 x SLOWER than the two launches: 76 vs 38 us at 1 row; the exponentials
+// of all 16 lane rows of every k-step are vector work the stream cannot hide.  profiles/NOTES.md, round 4.)
 #include "sp_common.h"
 
 namespace sp {
@@ -52,28 +55,6 @@ struct SkinnyArgs {
   int64_t x_stride, w_stride, out_stride;   // elements
 };
 
-// the B fragment of k-step `off` (bytes): PRO 0: 16 bytes of x; PRO 1: SiluAndMul of the gate (xp + off) and up
-// (xp + 2 K + off) halves of the row - the arithmetic of silu_mul_vec_kernel (elementwise.hip), op for op
-template <typename Tag, int PRO>
-__device__ __forceinline__ u32x4 skinny_x_load(const char* xp, int64_t off, int64_t up_off, u32x4& up_raw) {
-  if constexpr (PRO == 1) up_raw = ld16(xp + up_off + off);
-  return ld16(xp + off);
-}
-template <typename Tag, int PRO>
-__device__ __forceinline__ u32x4 skinny_x_finish(const u32x4& raw, const u32x4& up_raw) {
-  if constexpr (PRO == 0) {
-    return raw;
-  } else {
-    typedef Elem<Tag> E;
-    float g[8], u[8], y[8];
-    unpack16<Tag>(raw, g);
-    unpack16<Tag>(up_raw, u);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) y[e] = __fmul_rn(E::round(silu_ref(g[e])), u[e]);
-    return pack16<Tag>(y);
-  }
-}
-
 constexpr int kSkWaves = 8;
 
 // NB = 16-column blocks per workgroup: one x fragment feeds NB MFMAs (x traffic out of L2 drops to
@@ -86,23 +67,26 @@ constexpr int kSkWaves = 8;
 // gate_up 46.5 vs 43.3, LM head 186 vs 166; bench.py --bs 1: 4.13 vs 3.98 ms/step (round 3, tools/bench_gemv.py).
 __device__ __forceinline__ u32x4 ld16_nt(const void* p) { return __builtin_nontemporal_load((const u32x4*)p); }
 
-template <typename Tag, int NB, int UNROLL, bool NT, int PRO>
+// EPI 1 (NB = 1 only): a.N = I output columns; the 16 W rows of a workgroup are gate rows n0 .. n0+7 (tile rows 0-7) and
+// up rows I + n0 .. I + n0 + 7 (tile rows 8-15)
+template <typename Tag, int NB, int UNROLL, bool NT, int EPI>
 __global__ __launch_bounds__(kSkWaves * 64) void gemm_skinny_kernel(SkinnyArgs a) {
   typedef Elem<Tag> E;
+  static_assert(EPI == 0 || NB == 1, "the SiLU-mul epilogue pairs the two halves of one 16-row tile");
   __shared__ float red[kSkWaves][NB][16 * 17];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r16 = lane & 15, q = lane >> 4;            // operand row / k-quarter of the lane
-  const int n0 = blockIdx.x * 16 * NB;
+  const int n0 = EPI == 1 ? blockIdx.x * 8 : blockIdx.x * 16 * NB;
   const bool mrow = r16 < a.M;
   const char* wp[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    const int n = min(n0 + 16 * nb + r16, a.N - 1);    // clamp: columns past N are computed, never stored
+    int n = min(n0 + 16 * nb + r16, a.N - 1);          // clamp: columns past N are computed, never stored
+    if constexpr (EPI == 1) n = (r16 < 8 ? 0 : a.N) + min(n0 + (r16 & 7), a.N - 1);
     wp[nb] = a.w + ((int64_t)n * a.w_stride + 8 * q) * 2;
   }
   const char* xp = a.x + ((int64_t)min(r16, a.M - 1) * a.x_stride + 8 * q) * 2;
   const int ksteps = a.K / 32;
-  const int64_t up_off = (int64_t)a.K * 2;            // PRO 1: the up half of a gate|up row, in bytes
   f32x4_g acc[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4_g{0.f, 0.f, 0.f, 0.f};
@@ -110,32 +94,22 @@ __global__ __launch_bounds__(kSkWaves * 64) void gemm_skinny_kernel(SkinnyArgs a
   // this wave's k-steps: wave, wave + 8, ...; processed in groups of UNROLL with all loads first
   int ks = wave;
   for (; ks + (UNROLL - 1) * kSkWaves < ksteps; ks += UNROLL * kSkWaves) {
-    u32x4 wf[UNROLL][NB], xf[UNROLL], xu[PRO == 1 ? UNROLL : 1];
+    u32x4 wf[UNROLL][NB], xf[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int64_t off = (int64_t)(ks + u * kSkWaves) * 64;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) wf[u][nb] = NT ? ld16_nt(wp[nb] + off) : ld16(wp[nb] + off);
-      // (PRO 1 loads unconditionally - xp is clamped to a valid row - and zeroes the padding rows after the
-      // activation: no exec-masked memory operations between the weight loads)
-      if constexpr (PRO == 0) xf[u] = mrow ? ld16(xp + off) : zero;
-      else xf[u] = skinny_x_load<Tag, PRO>(xp, off, up_off, xu[PRO == 1 ? u : 0]);
+      xf[u] = mrow ? ld16(xp + off) : zero;
     }
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      if constexpr (PRO != 0) {
-        const u32x4 y = skinny_x_finish<Tag, PRO>(xf[u], xu[PRO == 1 ? u : 0]);
-        xf[u] = mrow ? y : zero;
-      }
+    for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_g<Tag>(wf[u][nb], xf[u], acc[nb]);
-    }
   }
   for (; ks < ksteps; ks += kSkWaves) {
     const int64_t off = (int64_t)ks * 64;
-    u32x4 xu1 = zero;
-    const u32x4 raw = skinny_x_load<Tag, PRO>(xp, off, up_off, xu1);
-    const u32x4 xf = mrow ? skinny_x_finish<Tag, PRO>(raw, xu1) : zero;
+    const u32x4 xf = mrow ? ld16(xp + off) : zero;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma_g<Tag>(NT ? ld16_nt(wp[nb] + off) : ld16(wp[nb] + off), xf, acc[nb]);
   }
@@ -152,8 +126,19 @@ __global__ __launch_bounds__(kSkWaves * 64) void gemm_skinny_kernel(SkinnyArgs a
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < kSkWaves; ++w) s += red[w][nb][col * 17 + r16];
-      const int n = n0 + 16 * nb + col;
-      if (mrow && n < a.N) E::store(a.out, (int64_t)r16 * a.out_stride + n, s);
+      if constexpr (EPI == 1) {
+        // tile columns 0-7 are gate sums, 8-15 the up sums of the same output columns: the lanes of the gate half
+        // finish both (same summation order as above) and apply silu_mul_vec_kernel's arithmetic to the ROUNDED sums
+        float su = 0.f;
+#pragma unroll
+        for (int w = 0; w < kSkWaves; ++w) su += red[w][nb][((col & 7) + 8) * 17 + r16];
+        const int n = n0 + col;
+        if (mrow && q < 2 && n < a.N)
+          E::store(a.out, (int64_t)r16 * a.out_stride + n, __fmul_rn(E::round(silu_ref(E::round(s))), E::round(su)));
+      } else {
+        const int n = n0 + 16 * nb + col;
+        if (mrow && n < a.N) E::store(a.out, (int64_t)r16 * a.out_stride + n, s);
+      }
     }
   }
 }
@@ -162,28 +147,27 @@ static int g_skinny_nt = 0;     // sp_debug_set("skinny_nt", 0 / 1): A/B switch 
 void set_skinny_nt(int v) { g_skinny_nt = v; }
 
 template <typename Tag>
-static void launch_skinny(const SkinnyArgs& a, int prologue, hipStream_t st) {
-  const dim3 block(kSkWaves * 64), grid((a.N + 15) / 16);
-  if (prologue == 1) gemm_skinny_kernel<Tag, 1, 8, false, 1><<<grid, block, 0, st>>>(a);
-  else if (g_skinny_nt) gemm_skinny_kernel<Tag, 1, 8, true, 0><<<grid, block, 0, st>>>(a);
-  else gemm_skinny_kernel<Tag, 1, 8, false, 0><<<grid, block, 0, st>>>(a);
+static void launch_skinny(const SkinnyArgs& a, int epilogue, hipStream_t st) {
+  const dim3 block(kSkWaves * 64);
+  if (epilogue == 1) gemm_skinny_kernel<Tag, 1, 8, false, 1><<<dim3((a.N + 7) / 8), block, 0, st>>>(a);
+  else if (g_skinny_nt) gemm_skinny_kernel<Tag, 1, 8, true, 0><<<dim3((a.N + 15) / 16), block, 0, st>>>(a);
+  else gemm_skinny_kernel<Tag, 1, 8, false, 0><<<dim3((a.N + 15) / 16), block, 0, st>>>(a);
 }
 
 }  // namespace sp
 
 extern "C" int sp_gemm_skinny(void* out, const void* x, const void* w, int M, int N, int K, int64_t x_stride,
-                              int64_t w_stride, int64_t out_stride, int prologue, int dtype, void* stream) {
-  SP_CHECK_ARG(M >= 0 && N >= 0 && K > 0 && (prologue == 0 || prologue == 1));
+                              int64_t w_stride, int64_t out_stride, int epilogue, int dtype, void* stream) {
+  SP_CHECK_ARG(M >= 0 && N >= 0 && K > 0 && (epilogue == 0 || epilogue == 1));
   if (M == 0 || N == 0) return SP_OK;
   SP_CHECK_ARG(out && x && w);
   if (M > 16 || K % 32 != 0) return SP_ERR_UNSUPPORTED;
   if (dtype != SP_BF16 && dtype != SP_F16) return SP_ERR_UNSUPPORTED;
-  SP_CHECK_ARG(x_stride % 8 == 0 && w_stride % 8 == 0 && x_stride >= (prologue == 1 ? 2 : 1) * (int64_t)K &&
-               w_stride >= K && out_stride >= N);
+  SP_CHECK_ARG(x_stride % 8 == 0 && w_stride % 8 == 0 && x_stride >= K && w_stride >= K && out_stride >= N);
   SP_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0);
   sp::SkinnyArgs a{(const char*)x, (const char*)w, out, M, N, K, x_stride, w_stride, out_stride};
-  if (dtype == SP_BF16) sp::launch_skinny<sp::bf16_tag>(a, prologue, (hipStream_t)stream);
-  else sp::launch_skinny<sp::f16_tag>(a, prologue, (hipStream_t)stream);
+  if (dtype == SP_BF16) sp::launch_skinny<sp::bf16_tag>(a, epilogue, (hipStream_t)stream);
+  else sp::launch_skinny<sp::f16_tag>(a, epilogue, (hipStream_t)stream);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }

@@ -194,14 +194,6 @@ class RowParallelLinear(_ShardedLinear):
             out = tensor_model_parallel_all_reduce(out)
         return out, None
 
-    def forward_silu_mul(self, gate_up, reduce_output: bool = True):
-        """SiluAndMul(gate_up) through this projection as ONE launch where the step is small enough for the
-        weight-streaming kernel (<= 16 tokens); None otherwise (the caller runs act_fn, then forward)."""
-        out = _native.silu_mul_linear(gate_up, self.weight)
-        if out is not None and self.reduce_results and reduce_output and self.tp_size > 1:
-            out = tensor_model_parallel_all_reduce(out)
-        return out
-
 
 def norm_after_row_parallel(norm: RMSNorm, x_partial: torch.Tensor, residual: torch.Tensor):
     """RMSNorm(all_reduce(x_partial), residual): the all-reduce RowParallelLinear would have run
@@ -364,13 +356,13 @@ class LlamaMLP(nn.Module):
         self.act_fn = SiluAndMul()
 
     def forward(self, x, reduce_output: bool = True):
-        gate_up, _ = self.gate_up_proj(x)
-        # small decode steps: activation and down projection in one weight-streaming launch (bit-identical)
-        fused = self.down_proj.forward_silu_mul(gate_up, reduce_output)
-        if fused is not None:
-            return fused
-        x = self.act_fn(gate_up)
-        x, _ = self.down_proj(x, reduce_output)
+        # small decode steps (<= 16 tokens): projection and activation in one weight-streaming launch, the bits of
+        # the skinny projection followed by act_fn
+        act = _native.linear_silu_mul(x, self.gate_up_proj.weight)
+        if act is None:
+            gate_up, _ = self.gate_up_proj(x)
+            act = self.act_fn(gate_up)
+        x, _ = self.down_proj(act, reduce_output)
         return x
 
 

@@ -54,38 +54,39 @@ def test_skinny_gemm_views_fallbacks_and_determinism():
     lib = __import__("ctypes").CDLL(_native.lib_path())
     assert lib.sp_gemm_skinny(None, None, None, 4, 8, 64, 64, 64, 8, 0, 2, None) == -1      # null pointers
     assert lib.sp_gemm_skinny(1, 1, 1, 17, 8, 64, 64, 64, 8, 0, 2, None) == -2              # unsupported rows
-    assert lib.sp_gemm_skinny(1, 1, 1, 4, 8, 64, 64, 64, 8, 2, 2, None) == -1               # unknown prologue
-    assert lib.sp_gemm_skinny(1, 1, 1, 4, 8, 64, 64, 64, 8, 1, 2, None) == -1               # SiLU prologue: x rows hold 2 K
+    assert lib.sp_gemm_skinny(1, 1, 1, 4, 8, 64, 64, 64, 8, 2, 2, None) == -1               # unknown epilogue
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M", [1, 3, 8, 16])
-@pytest.mark.parametrize("N,K", [(4096, 14336), (100, 64), (4104, 2048), (512, 288)])
-def test_silu_mul_fused_into_the_skinny_projection_is_bit_identical(dtype, M, N, K):
-    """sp_gemm_skinny(prologue = 1): SiluAndMul (nn/layers/activation.py:21-31) of the gate|up rows computed on the
-    way into the matrix-core operand registers - the bits of sp_silu_and_mul followed by the plain skinny projection,
-    and within one output rounding of the fp32 reference on the reference's own activation arithmetic."""
+@pytest.mark.parametrize("I,K", [(14336, 4096), (3584, 4096), (104, 64), (8, 32), (2056, 288)])
+def test_silu_mul_fused_into_the_skinny_gate_up_projection_is_bit_identical(dtype, M, I, K):
+    """sp_gemm_skinny(epilogue = 1): the merged gate|up projection with SiluAndMul (nn/layers/activation.py:21-31) in
+    its epilogue - the bits of the plain skinny projection followed by sp_silu_and_mul, and within one output
+    rounding of an fp32 evaluation with torch's own roundings of the activation."""
     from scratchpad_amd import _native
-    g = torch.Generator().manual_seed(M * 77 + N + K)
-    gate_up = (torch.randn(M, 2 * K, generator=g) * 2.0).to(dtype).cuda()
-    gate_up[0, :4] = torch.tensor([0.0, -30.0, 30.0, -0.0]).to(dtype)          # saturating / signed-zero gates
-    w = (torch.randn(N, K, generator=g) * 0.05).to(dtype).cuda()
-    act = _native.silu_and_mul(gate_up)
-    two_step = torch.empty(M, N, dtype=dtype, device="cuda")
-    _native._check(_native.load().sp_gemm_skinny(two_step.data_ptr(), act.data_ptr(), w.data_ptr(), M, N, K, act.stride(0),
-                                                 w.stride(0), two_step.stride(0), 0, _native._dt(act), _native._stream()),
+    g = torch.Generator().manual_seed(M * 77 + I + K)
+    x = torch.randn(M, K, generator=g).to(dtype).cuda()
+    w = (torch.randn(2 * I, K, generator=g) * (2.0 / K ** 0.5)).to(dtype).cuda()
+    w[0].zero_()                                               # a gate column that is exactly 0
+    two = torch.empty(M, 2 * I, dtype=dtype, device="cuda")
+    _native._check(_native.load().sp_gemm_skinny(two.data_ptr(), x.data_ptr(), w.data_ptr(), M, 2 * I, K, x.stride(0),
+                                                 w.stride(0), two.stride(0), 0, _native._dt(x), _native._stream()),
                    "sp_gemm_skinny")
-    fused = _native.silu_mul_linear(gate_up, w)
-    assert fused is not None and fused.shape == (M, N) and torch.equal(fused, two_step)
-    ref_act = (torch.nn.functional.silu(gate_up[:, :K].float()).to(dtype) * gate_up[:, K:]).float()   # torch's roundings
-    check(fused, ref_act.to(dtype), w, dtype)
-    # a row-strided view of a wider buffer (the merged projection's output inside a spare-row allocation)
-    wide = torch.zeros(M + 2, 2 * K + 64, dtype=dtype, device="cuda")
-    wide[:M, :2 * K] = gate_up
-    assert torch.equal(_native.silu_mul_linear(wide[:M, :2 * K], w), two_step)
-    # shapes the kernel does not take: the caller keeps the two steps
-    assert _native.silu_mul_linear(torch.zeros(17, 2 * K, dtype=dtype, device="cuda"), w) is None
-    assert _native.silu_mul_linear(gate_up[:, :K], w) is None
+    two_step = _native.silu_and_mul(two)
+    fused = _native.linear_silu_mul(x, w)
+    assert fused is not None and fused.shape == (M, I) and torch.equal(fused, two_step)
+    gu = (x.float().cpu() @ w.float().cpu().T)
+    ref = torch.nn.functional.silu(gu[:, :I]) * gu[:, I:]
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    err = (fused.float().cpu() - ref).abs()
+    assert bool((err <= 4 * eps * ref.abs() + 4 * eps * ref.abs().max()).all()), float(err.max())
+    # a row-strided input view, and the shapes the kernel does not take (the caller keeps the two steps)
+    wide = torch.zeros(M + 2, K + 64, dtype=dtype, device="cuda")
+    wide[:M, :K] = x
+    assert torch.equal(_native.linear_silu_mul(wide[:M, :K], w), two_step)
+    assert _native.linear_silu_mul(torch.zeros(17, K, dtype=dtype, device="cuda"), w) is None
+    assert _native.linear_silu_mul(x, w[:2 * I - 8]) is None
 
 
 def test_small_step_mlp_uses_the_fused_projection_and_matches_the_two_step_form(monkeypatch):
@@ -97,19 +98,22 @@ def test_small_step_mlp_uses_the_fused_projection_and_matches_the_two_step_form(
     mlp = LlamaMLP(512, 1408, "silu", torch.bfloat16).cuda()
     for p_ in mlp.parameters():
         p_.data.normal_(0.0, 0.05)
-    calls = []
-    orig = _native.silu_mul_linear
-    monkeypatch.setattr(_native, "silu_mul_linear", lambda a, b: calls.append(a.shape[0]) or orig(a, b))
+    taken = []
+    orig = _native.linear_silu_mul
+    monkeypatch.setattr(_native, "linear_silu_mul", lambda a, b: taken.append(orig(a, b) is not None) or orig(a, b))
     for rows in (1, 16, 17):
         x = torch.randn(rows, 512, device="cuda").bfloat16()
         got = mlp(x)
-        gate_up, _ = mlp.gate_up_proj(x)
-        want, _ = mlp.down_proj(mlp.act_fn(gate_up))
-        if rows <= 16:
-            assert torch.equal(got, want)
+        gate_up = torch.empty(rows, 2816, dtype=torch.bfloat16, device="cuda")
+        if rows <= 16:                                          # the skinny projection, unfused, then the activation
+            _native._check(_native.load().sp_gemm_skinny(gate_up.data_ptr(), x.data_ptr(), mlp.gate_up_proj.weight.data_ptr(),
+                                                         rows, 2816, 512, 512, 512, 2816, 0, _native._dt(x), _native._stream()),
+                           "sp_gemm_skinny")
         else:
-            assert torch.allclose(got.float(), want.float(), atol=1e-2)
-    assert calls == [1, 16, 17]
+            gate_up, _ = mlp.gate_up_proj(x)
+        want, _ = mlp.down_proj(mlp.act_fn(gate_up))
+        assert torch.equal(got, want), rows
+    assert taken == [True, True, False]
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -48,19 +48,18 @@ def main():
                 tot_a += a
                 tot_b += b
         print(f"M={M:2d} per-layer total: skinny {tot_a:.1f} us, library {tot_b:.1f} us", flush=True)
-        # act_fn + down_proj (LlamaMLP): fused into one skinny launch vs SiluAndMul + the projection the dispatch picks
-        N, K = shapes["down"]
-        gus = [torch.randn(M, 2 * K, device="cuda").bfloat16() for _ in range(2)]
+        # gate_up_proj + act_fn (LlamaMLP): SiluAndMul in the skinny projection's epilogue vs projection + activation launch
+        N, K = shapes["gate_up"]
+        x = torch.randn(M, K, device="cuda").bfloat16()
         ws = [(torch.randn(N, K, device="cuda") * 0.02).bfloat16() for _ in range(6)]
         it = [0]
 
         def w_():
             it[0] += 1
             return ws[it[0] % len(ws)]
-        fused = timeit(lambda: _native.silu_mul_linear(gus[it[0] % 2], w_()))
-        two = timeit(lambda: _native.linear(_native.silu_and_mul(gus[it[0] % 2]), w_()))
-        print(f"M={M:2d} silu_mul + down: fused skinny {fused:7.1f} us   two launches {two:7.1f} us", flush=True)
-
+        fused = timeit(lambda: _native.linear_silu_mul(x, w_()))
+        two = timeit(lambda: _native.silu_and_mul(_native.linear(x, w_())))
+        print(f"M={M:2d} gate_up + silu_mul: fused skinny {fused:7.1f} us   two launches {two:7.1f} us", flush=True)
 
 if __name__ == "__main__":
     main()
