@@ -728,14 +728,20 @@ def extend_rows(x: torch.Tensor, rows: int) -> Optional[torch.Tensor]:
 
 
 _SILU_LINEAR_ON = os.environ.get("SP_SKINNY_SILU", "1") != "0"
+# rows up to which the fused form is used.  Measured (round 4, bench.py --ctx 1024, HIP-graph replay, ms/step fused vs
+# projection + activation launch): bs 1 3.977 vs 4.006, bs 8 4.469 vs 4.579, bs 16 5.052 vs 4.698 - at 16 rows the
+# merged projection is faster on the library (61 vs 68 us) and the activation launch it saves costs ~1 us under replay
+SILU_FUSED_MAX_ROWS = 8
 
 
-def linear_silu_mul(x: torch.Tensor, gate_up_weight: torch.Tensor) -> Optional[torch.Tensor]:
+def linear_silu_mul(x: torch.Tensor, gate_up_weight: torch.Tensor, any_rows: bool = False) -> Optional[torch.Tensor]:
     """SiluAndMul(x @ gate_up_weight.T) as ONE launch (sp_gemm_skinny, epilogue 1) for a step of at most
-    SKINNY_MAX_ROWS tokens: x [M, K], gate_up_weight [2 I, K] (gate rows first), result [M, I].  Bit for bit the
-    skinny projection followed by silu_and_mul.  None when the shape is not taken (the caller runs the two steps)."""
+    SILU_FUSED_MAX_ROWS tokens (any_rows: up to the kernel's 16): x [M, K], gate_up_weight [2 I, K] (gate rows first),
+    result [M, I].  Bit for bit the skinny projection followed by silu_and_mul.  None when the shape is not taken (the
+    caller runs the two steps)."""
     if not (_SKINNY_ON and _SILU_LINEAR_ON and x.is_cuda and x.dim() == 2 and gate_up_weight.dim() == 2
-            and 0 < x.shape[0] <= SKINNY_MAX_ROWS and gate_up_weight.shape[1] == x.shape[1]
+            and 0 < x.shape[0] <= (SKINNY_MAX_ROWS if any_rows else SILU_FUSED_MAX_ROWS)
+            and gate_up_weight.shape[1] == x.shape[1]
             and gate_up_weight.shape[0] % 16 == 0
             and x.dtype in (torch.float16, torch.bfloat16) and gate_up_weight.dtype == x.dtype
             and x.shape[1] % 32 == 0 and x.stride(1) == 1 and gate_up_weight.stride(1) == 1

@@ -74,8 +74,9 @@ def test_silu_mul_fused_into_the_skinny_gate_up_projection_is_bit_identical(dtyp
                                                  w.stride(0), two.stride(0), 0, _native._dt(x), _native._stream()),
                    "sp_gemm_skinny")
     two_step = _native.silu_and_mul(two)
-    fused = _native.linear_silu_mul(x, w)
+    fused = _native.linear_silu_mul(x, w, any_rows=True)          # the kernel itself, whatever the dispatch threshold says
     assert fused is not None and fused.shape == (M, I) and torch.equal(fused, two_step)
+    assert (_native.linear_silu_mul(x, w) is not None) == (M <= _native.SILU_FUSED_MAX_ROWS)
     gu = (x.float().cpu() @ w.float().cpu().T)
     ref = torch.nn.functional.silu(gu[:, :I]) * gu[:, I:]
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
@@ -84,9 +85,9 @@ def test_silu_mul_fused_into_the_skinny_gate_up_projection_is_bit_identical(dtyp
     # a row-strided input view, and the shapes the kernel does not take (the caller keeps the two steps)
     wide = torch.zeros(M + 2, K + 64, dtype=dtype, device="cuda")
     wide[:M, :K] = x
-    assert torch.equal(_native.linear_silu_mul(wide[:M, :K], w), two_step)
-    assert _native.linear_silu_mul(torch.zeros(17, K, dtype=dtype, device="cuda"), w) is None
-    assert _native.linear_silu_mul(x, w[:2 * I - 8]) is None
+    assert torch.equal(_native.linear_silu_mul(wide[:M, :K], w, any_rows=True), two_step)
+    assert _native.linear_silu_mul(torch.zeros(17, K, dtype=dtype, device="cuda"), w, any_rows=True) is None
+    assert _native.linear_silu_mul(x, w[:2 * I - 8], any_rows=True) is None
 
 
 def test_small_step_mlp_uses_the_fused_projection_and_matches_the_two_step_form(monkeypatch):
@@ -101,11 +102,11 @@ def test_small_step_mlp_uses_the_fused_projection_and_matches_the_two_step_form(
     taken = []
     orig = _native.linear_silu_mul
     monkeypatch.setattr(_native, "linear_silu_mul", lambda a, b: taken.append(orig(a, b) is not None) or orig(a, b))
-    for rows in (1, 16, 17):
+    for rows in (1, 8, 17):
         x = torch.randn(rows, 512, device="cuda").bfloat16()
         got = mlp(x)
         gate_up = torch.empty(rows, 2816, dtype=torch.bfloat16, device="cuda")
-        if rows <= 16:                                          # the skinny projection, unfused, then the activation
+        if rows <= 8:                                           # the skinny projection, unfused, then the activation
             _native._check(_native.load().sp_gemm_skinny(gate_up.data_ptr(), x.data_ptr(), mlp.gate_up_proj.weight.data_ptr(),
                                                          rows, 2816, 512, 512, 512, 2816, 0, _native._dt(x), _native._stream()),
                            "sp_gemm_skinny")

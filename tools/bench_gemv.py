@@ -57,7 +57,7 @@ def main():
         def w_():
             it[0] += 1
             return ws[it[0] % len(ws)]
-        fused = timeit(lambda: _native.linear_silu_mul(x, w_()))
+        fused = timeit(lambda: _native.linear_silu_mul(x, w_(), any_rows=True))
         two = timeit(lambda: _native.silu_and_mul(_native.linear(x, w_())))
         print(f"M={M:2d} gate_up + silu_mul: fused skinny {fused:7.1f} us   two launches {two:7.1f} us", flush=True)
 
