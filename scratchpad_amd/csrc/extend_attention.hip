@@ -106,6 +106,7 @@ __global__ __launch_bounds__(kPlanThreads) void extend_plan_kernel(
 int extend_block_rows(int num_q_heads, int num_kv_heads);   // extend_mfma.hip
 void set_ar_fused_blocks(int n);                            // allreduce.hip
 void set_skinny_nt(int v);                                  // gemm_skinny.hip
+void set_skinny_unroll16(int v);                            // gemm_skinny.hip
 
 }  // namespace sp
 
@@ -148,6 +149,7 @@ extern "C" int sp_debug_set(const char* key, int value) {
   if (!strcmp(key, "extend_w64_persist")) { set_extend_w64_persist(value); return SP_OK; }
   if (!strcmp(key, "ar_fused_blocks")) { set_ar_fused_blocks(value); return SP_OK; }
   if (!strcmp(key, "skinny_nt")) { set_skinny_nt(value); return SP_OK; }
+  if (!strcmp(key, "skinny_unroll16")) { set_skinny_unroll16(value); return SP_OK; }
   return SP_ERR_INVALID_ARG;
 }
 

@@ -145,11 +145,18 @@ __global__ __launch_bounds__(kSkWaves * 64) void gemm_skinny_kernel(SkinnyArgs a
 
 static int g_skinny_nt = 0;     // sp_debug_set("skinny_nt", 0 / 1): A/B switch of the non-temporal weight loads
 void set_skinny_nt(int v) { g_skinny_nt = v; }
+// sp_debug_set("skinny_unroll16", 0 / 1): 16 k-steps of loads in flight per wave where a wave's share is a multiple of
+// 16 (K = 4096: the whole share in ONE round of loads instead of two)
+static int g_skinny_u16 = 0;
+void set_skinny_unroll16(int v) { g_skinny_u16 = v; }
 
 template <typename Tag>
 static void launch_skinny(const SkinnyArgs& a, int epilogue, hipStream_t st) {
   const dim3 block(kSkWaves * 64);
-  if (epilogue == 1) gemm_skinny_kernel<Tag, 1, 8, false, 1><<<dim3((a.N + 7) / 8), block, 0, st>>>(a);
+  const bool u16 = g_skinny_u16 && (a.K / 32) % (16 * kSkWaves) == 0;
+  if (epilogue == 1 && u16) gemm_skinny_kernel<Tag, 1, 16, false, 1><<<dim3((a.N + 7) / 8), block, 0, st>>>(a);
+  else if (epilogue == 1) gemm_skinny_kernel<Tag, 1, 8, false, 1><<<dim3((a.N + 7) / 8), block, 0, st>>>(a);
+  else if (u16) gemm_skinny_kernel<Tag, 1, 16, false, 0><<<dim3((a.N + 15) / 16), block, 0, st>>>(a);
   else if (g_skinny_nt) gemm_skinny_kernel<Tag, 1, 8, true, 0><<<dim3((a.N + 15) / 16), block, 0, st>>>(a);
   else gemm_skinny_kernel<Tag, 1, 8, false, 0><<<dim3((a.N + 15) / 16), block, 0, st>>>(a);
 }

@@ -40,9 +40,12 @@ def main():
             _native.debug_set("skinny_nt", 1)
             a0 = timeit(lambda: _native.linear(x, nxt()))          # non-temporal weight loads, for comparison (not shipped)
             _native.debug_set("skinny_nt", 0)
+            _native.debug_set("skinny_unroll16", 1)
+            a16 = timeit(lambda: _native.linear(x, nxt()))         # 16 k-steps in flight per wave where the share allows
+            _native.debug_set("skinny_unroll16", 0)
             b = timeit(lambda: torch.nn.functional.linear(x, nxt()))
             gb = N * K * 2 / 1e9
-            print(f"M={M:2d} {name:8s} N={N:6d} K={K:5d}: skinny {a:7.1f} us ({gb / a * 1e3:5.2f} TB/s; nt loads {a0:6.1f})   "
+            print(f"M={M:2d} {name:8s} N={N:6d} K={K:5d}: skinny {a:7.1f} us ({gb / a * 1e3:5.2f} TB/s; nt loads {a0:6.1f}; unroll 16 {a16:6.1f})   "
                   f"library {b:7.1f} us ({gb / b * 1e3:5.2f} TB/s)", flush=True)
             if name != "lm_head":
                 tot_a += a
