@@ -108,9 +108,14 @@ class HipAttnBackend(AttentionBackend):
     # work items (request x split x head-group) we want per launch: one per CU.  Measured sweep
     # (tools/bench_decode_attn.py, bs 1-128 x ctx 1024/4096): fewer, longer workgroups win as soon
     # as every CU has one - the per-workgroup prologue (index -> gather -> first tile) is amortised
-    # over more tiles - e.g. bs 32 x 1024: chunk 256 (256 items) 28.5 us vs chunk 64 (1024) 34.1 us
+    # over more tiles - e.g. bs 32 x 1024: chunk 256 (256 items) 28.5 us vs chunk 64 (1024) 34.1 us.
+    # MAX_CHUNK caps the split (load balance of ragged batches).  512 until round 4; re-measured then in the model
+    # (profiles/r04_decode_variants.txt section 5, same box, 512 -> 1024): headline 13.11 / 12.98 -> 13.08 / 12.93 k
+    # tokens/s (noise), ctx 1024 18.68 -> 19.48 k (+4.3 %, attention 212 -> 196 us), ctx 4096 +1.6 %, 70B rank shape
+    # +1.2 % (attention 40.6 -> 38.8 us), bs 128 +1.0 %, fp8 KV +2.0 %, bs 64 -1.5 %; 2048 is worse again (ctx 2048
+    # -2 %, bs 32 x ctx 4096 -5 %).  SP_DECODE_MAX_CHUNK overrides it for such A/B runs.
     TARGET_ITEMS = 256
-    MIN_CHUNK, MAX_CHUNK = 64, 512
+    MIN_CHUNK, MAX_CHUNK = 64, int(os.environ.get("SP_DECODE_MAX_CHUNK", "1024"))
     # graph replay: work items / partial slots a captured launch of bucket bs covers (the launch geometry is
     # a function of this number only; the split size travels in the step's plan).  max(1024, 8 bs) + bs keeps
     # 512-key splits up to a mean context of 4096 per request and lets the splits grow beyond that, so the
