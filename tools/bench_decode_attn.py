@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--no-fuse", action="store_true", help="separate merge launch (default: the attention kernel merges)")
     ap.add_argument("--interleave", action="store_true",
                     help="one [P+1, 2, Hkv, D] arena: a token's K and V rows are adjacent (pool.py's layout)")
+    ap.add_argument("--slots", type=int, default=0,
+                    help="work items the launch covers (graph replay covers max(1024, 8 bs) + bs; default: what the step needs)")
     ap.add_argument("--gemm", action="store_true", help="interleave a bf16 GEMM between launches (as in a model)")
     a = ap.parse_args()
     if a.lib:
@@ -71,15 +73,16 @@ def main():
     max_len = int(ctx.max())
     ref = None
     for chunk in [int(c) for c in a.chunks.split(",")]:
-        ws = torch.empty(_native.decode_workspace_bytes(a.bs, a.Hq, a.D, max_len, chunk), dtype=torch.uint8, device=dev)
+        slots = a.slots or None
+        ws = torch.empty(_native.decode_workspace_bytes(a.bs, a.Hq, a.D, max_len, chunk, slots), dtype=torch.uint8, device=dev)
         plan = None
         if not a.no_plan:
             groups = 0 if a.no_fuse else a.Hkv
-            plan = torch.empty(_native.decode_plan_bytes(a.bs, max_len, chunk, fuse_groups=groups) // 4, dtype=torch.int32, device=dev)
-            _native.decode_plan(plan, seq, max_len, chunk, fuse_groups=groups)
+            plan = torch.empty(_native.decode_plan_bytes(a.bs, max_len, chunk, slots, fuse_groups=groups) // 4, dtype=torch.int32, device=dev)
+            _native.decode_plan(plan, seq, max_len, chunk, slots, fuse_groups=groups)
         groups = 0 if (a.no_fuse or a.no_plan) else a.Hkv
         run = lambda: _native.decode_attention(o, q, kb, vb, r2t, req, seq, a.D ** -0.5, 0.0, max_len, chunk, ws, None, plan,
-                                               plan_fuse_groups=groups)
+                                               plan_fuse_groups=groups, max_slots=slots)
         for _ in range(a.warmup):
             run()
         torch.cuda.synchronize()
