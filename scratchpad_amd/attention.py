@@ -164,6 +164,7 @@ class HipAttnBackend(AttentionBackend):
         self._graph_ws = None          # graph replay: ONE partials workspace / plan-buffer triple for all buckets
         self._graph_plans = None
         self._extend_plan = None       # int32 work list of the current extend step (sp_extend_plan)
+        self.replay_max_hint = None    # set by HipGraphRunner.replay for the next replay hook call
         # arrival counters every plan carries (their use is decided per launch: _fuse)
         self._plan_groups = self.num_kv_head if str(self.fused_split_merge) not in ("0", "False") else 0
         self._plan_checks = []         # (pinned header copy, event, max_slots) of plans not yet checked
@@ -178,10 +179,38 @@ class HipAttnBackend(AttentionBackend):
             hh *= 2
         return self.num_kv_head // hh
 
-    def _plan_chunk(self, kv_tokens: int, dtype: torch.dtype) -> int:
+    # a batch counts as near-uniform when its longest request is at most this many times its mean length
+    UNIFORM_RATIO = 1.35
+    uniform_policy = os.environ.get("SP_DECODE_UNIFORM", "1") != "0"      # (0: A/B runs without the hint)
+
+    def _wg_groups(self) -> int:
+        """workgroups per (request, split) item of the matrix-core decode kernel: the kv heads in fours where they
+        divide by four (a wave per head), else one workgroup per kv head"""
+        return self.num_kv_head // 4 if self.num_kv_head % 4 == 0 else self.num_kv_head
+
+    def _plan_chunk(self, kv_tokens: int, dtype: torch.dtype, bs: Optional[int] = None,
+                    max_hint: Optional[int] = None) -> int:
+        """Split size of a decode step from what the host knows: sum(seq_lens) (a bound), the batch size and - where
+        the scheduler tracks it - an upper bound of the longest request (`max_hint`, advisory).
+        Default: about one item per CU, between MIN_CHUNK and MAX_CHUNK.  A NEAR-UNIFORM batch (max <= UNIFORM_RATIO x
+        mean) is treated on its own (round 4, profiles/r04_decode_variants.txt section 6): splitting requests of equal
+        length buys no balance, so with at least one workgroup per CU without splitting the split covers the whole
+        request - no partials, nothing to merge (bs 256: ctx 1064 193 vs 207 us, ctx 4136 723 vs 768; bs 128 99 vs 105 and
+        351 vs 368; below one workgroup per CU it loses badly: bs 64 74 vs 50) - and otherwise the default size is evened
+        out over the longest request's splits (1064 keys: 2 x 532 instead of 1024 + 40)."""
         groups = self._head_groups(dtype)
         chunk = _pow2_floor(max(kv_tokens, 1) * groups // self.TARGET_ITEMS)
-        return max(self.MIN_CHUNK, min(self.MAX_CHUNK, chunk))
+        chunk = max(self.MIN_CHUNK, min(self.MAX_CHUNK, chunk))
+        if not max_hint or not bs or not self.uniform_policy:
+            return chunk
+        mean = kv_tokens / bs
+        if max_hint < mean or max_hint > self.UNIFORM_RATIO * mean:      # no usable hint / a ragged batch
+            return chunk
+        whole = -(-int(max_hint) // 64) * 64
+        if bs * self._wg_groups() >= self.TARGET_ITEMS:
+            return max(self.MIN_CHUNK, whole)
+        n = -(-int(max_hint) // chunk)
+        return max(self.MIN_CHUNK, -(-(-(-int(max_hint) // n)) // 64) * 64)
 
     def _ensure_workspace(self, nbytes: int) -> torch.Tensor:
         if self._workspace.numel() < nbytes:
@@ -198,7 +227,7 @@ class HipAttnBackend(AttentionBackend):
             chunk *= 2
         return chunk
 
-    def _build_plans(self, plans, bs, windows, max_len, max_slots=None):
+    def _build_plans(self, plans, bs, windows, max_len, max_slots=None, hints=(None, None, None)):
         """One split plan per kv window (self-attention lens; encoder lens for cross-attention - the
         reference keeps two flashinfer wrappers for the same reason, flashinfer_backend.py:121-131; the
         sliding-window layers' lens).  windows: per plan (lens tensor or None, host bound on their sum).
@@ -209,7 +238,7 @@ class HipAttnBackend(AttentionBackend):
             if lens is None:
                 out.append(None)
                 continue
-            chunk = self._plan_chunk(kv_tokens, self.kv_dtype)
+            chunk = self._plan_chunk(kv_tokens, self.kv_dtype, bs, hints[i])
             if max_slots is None:          # eager: exactly what this step can need
                 slots = max(1, _native.decode_plan_slots(bs, max_len, chunk, kv_tokens))
             else:                          # graph replay: the captured launch's capacity is fixed
@@ -294,8 +323,11 @@ class HipAttnBackend(AttentionBackend):
             enc = forward_batch.encoder_lens if self.is_encoder_decoder else None
             enc_sum = sum(forward_batch.encoder_lens_cpu) if forward_batch.encoder_lens_cpu else None
             self._window = self._window_of(forward_batch.seq_lens)
+            hint = (max_len if forward_batch.seq_lens_cpu is not None
+                    else getattr(forward_batch, "seq_lens_max_hint", None))
             plans, slots = self._build_plans(self._plans, bs, self._windows(
-                bs, forward_batch.seq_lens, forward_batch.seq_lens_sum, enc, enc_sum), max_len)
+                bs, forward_batch.seq_lens, forward_batch.seq_lens_sum, enc, enc_sum), max_len,
+                hints=(hint, enc_max or None, None))
             ws = self._ensure_workspace(_native.decode_workspace_bytes(bs, self.num_head, self.v_head_dim, max_len,
                                                                        self.MIN_CHUNK, slots))
             self.forward_metadata = (self.MIN_CHUNK, max_len, ws, plans)
@@ -339,11 +371,11 @@ class HipAttnBackend(AttentionBackend):
         """attention scratch held for graph replay (workspace + plan buffers), all buckets together"""
         return self._graph_ws.numel() + sum(p.numel() * 4 for p in self._graph_plans)
 
-    def _graph_metadata(self, bs, seq_lens, seq_lens_sum, encoder_lens):
+    def _graph_metadata(self, bs, seq_lens, seq_lens_sum, encoder_lens, max_hint=None):
         assert bs <= self._graph_max_bs
         plans, _ = self._build_plans(self._graph_plans, bs, self._windows(bs, seq_lens, seq_lens_sum, encoder_lens,
                                                                           None),
-                                     self.cuda_graph_max_seq_len, self._graph_slots(bs))
+                                     self.cuda_graph_max_seq_len, self._graph_slots(bs), hints=(max_hint, None, None))
         # MIN_CHUNK: the smallest split size a replayed plan may carry (the merge launch is always captured)
         self.forward_metadata = (self.MIN_CHUNK, self.cuda_graph_max_seq_len, self._graph_ws, plans)
 
@@ -363,7 +395,11 @@ class HipAttnBackend(AttentionBackend):
         # (triton_backend.py:103-113, flashinfer_backend.py:330-373).  The split size is chosen HERE, per
         # step, from seq_lens_sum (it is plan data, not launch geometry).
         self._window = self._window_of(seq_lens[:bs], self._graph_window, bs)
-        self._graph_metadata(bs, seq_lens[:bs], seq_lens_sum, None if encoder_lens is None else encoder_lens[:bs])
+        # the advisory bound of the longest request (ForwardBatch.seq_lens_max_hint): the hook's signature is the
+        # reference's, so the graph runner leaves it in replay_max_hint just before the call
+        hint = int(seq_lens_cpu.max()) if seq_lens_cpu is not None else self.replay_max_hint
+        self.replay_max_hint = None
+        self._graph_metadata(bs, seq_lens[:bs], seq_lens_sum, None if encoder_lens is None else encoder_lens[:bs], hint)
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1  # padded rows attend to the dummy slot 0 only (triton_backend.py:115-116)

@@ -104,6 +104,11 @@ class ModelWorkerBatch:
     # stand-in for the (un-hosted) vision tower: projected + flattened vision states of the requests
     # whose encoder is not cached, [sum(encoder_lens_need), hidden] (mllama.py:966-979)
     encoder_states: Optional[torch.Tensor] = None
+    # ADVISORY (no reference counterpart; the reference declares seq_lens_cpu for this and never fills it,
+    # schedule_batch.py:1407-1408): a host-side upper bound of max(seq_lens), kept by ScheduleBatch the way it keeps
+    # seq_lens_sum.  The attention backend uses it only to CHOOSE the decode split size (a batch of near-equal
+    # lengths is not split); a wrong or missing value costs speed, never results.
+    seq_lens_max_hint: Optional[int] = None
 
 
 @dataclass
@@ -117,6 +122,7 @@ class ForwardBatch:
     out_cache_loc: torch.Tensor
     seq_lens_sum: int
     seq_lens_cpu: Optional[torch.Tensor] = None
+    seq_lens_max_hint: Optional[int] = None          # advisory, see ModelWorkerBatch
     return_logprob: bool = False
     top_logprobs_nums: Optional[List[int]] = None
     token_ids_logprobs: Optional[List[List[int]]] = None
@@ -161,7 +167,8 @@ class ForwardBatch:
             out_cache_loc=batch.out_cache_loc, mm_inputs=batch.multimodal_inputs,
             encoder_cached=batch.encoder_cached, encoder_lens=batch.encoder_lens,
             encoder_lens_cpu=batch.encoder_lens_cpu, encoder_out_cache_loc=batch.encoder_out_cache_loc,
-            seq_lens_sum=batch.seq_lens_sum, return_logprob=batch.return_logprob,
+            seq_lens_sum=batch.seq_lens_sum, seq_lens_max_hint=getattr(batch, "seq_lens_max_hint", None),
+            return_logprob=batch.return_logprob,
             top_logprobs_nums=batch.top_logprobs_nums, token_ids_logprobs=batch.token_ids_logprobs,
             can_run_dp_cuda_graph=batch.can_run_dp_cuda_graph, topping_paths=batch.toppings_paths,
             sampling_info=batch.sampling_info, req_to_token_pool=model_runner.req_to_token_pool,

@@ -40,8 +40,13 @@ def main():
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
     dev = "cuda"
     g = torch.Generator().manual_seed(0)
-    ctx = (torch.randint(128, 4097, (a.bs,), generator=g) if a.ctx == "uniform"
-           else torch.full((a.bs,), int(a.ctx)))
+    if a.ctx == "uniform":
+        ctx = torch.randint(128, 4097, (a.bs,), generator=g)
+    elif ":" in a.ctx:                                   # "lo:hi" = uniform integers in [lo, hi]
+        lo, hi = (int(x) for x in a.ctx.split(":"))
+        ctx = torch.randint(lo, hi + 1, (a.bs,), generator=g)
+    else:
+        ctx = torch.full((a.bs,), int(a.ctx))
     total = int(ctx.sum())
     P = total + 1024
     if a.interleave:
