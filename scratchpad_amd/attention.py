@@ -193,11 +193,13 @@ class HipAttnBackend(AttentionBackend):
         """Split size of a decode step from what the host knows: sum(seq_lens) (a bound), the batch size and - where
         the scheduler tracks it - an upper bound of the longest request (`max_hint`, advisory).
         Default: about one item per CU, between MIN_CHUNK and MAX_CHUNK.  A NEAR-UNIFORM batch (max <= UNIFORM_RATIO x
-        mean) is treated on its own (round 4, profiles/r04_decode_variants.txt section 6): splitting requests of equal
-        length buys no balance, so with at least one workgroup per CU without splitting the split covers the whole
-        request - no partials, nothing to merge (bs 256: ctx 1064 193 vs 207 us, ctx 4136 723 vs 768; bs 128 99 vs 105 and
-        351 vs 368; below one workgroup per CU it loses badly: bs 64 74 vs 50) - and otherwise the default size is evened
-        out over the longest request's splits (1064 keys: 2 x 532 instead of 1024 + 40)."""
+        mean) that still has a workgroup per CU when nothing is split is NOT split: requests of equal length gain no
+        balance from it, and whole requests need no partials and no merge.  Measured (round 4,
+        profiles/r04_decode_variants.txt section 6): kernel alone, bs 256: ctx 1064 193 vs 207 us, ctx 4136 723 vs 768;
+        bs 128: 99 vs 105 and 351 vs 368; in the model ctx 1024 19.89 vs 19.50 k tokens/s, ctx 4096 8.69 vs 8.57 k
+        (attention 6.16 TB/s = 77 % of peak).  Below one workgroup per CU it loses badly (bs 64: 74 vs 50 us) and the
+        default stays; evening the default size out over the longest request's splits (5 x 832 instead of 4 x 1024 + 40)
+        was tried for that case and measured 2 - 4 % SLOWER in the model, so it is not done."""
         groups = self._head_groups(dtype)
         chunk = _pow2_floor(max(kv_tokens, 1) * groups // self.TARGET_ITEMS)
         chunk = max(self.MIN_CHUNK, min(self.MAX_CHUNK, chunk))
@@ -206,11 +208,9 @@ class HipAttnBackend(AttentionBackend):
         mean = kv_tokens / bs
         if max_hint < mean or max_hint > self.UNIFORM_RATIO * mean:      # no usable hint / a ragged batch
             return chunk
-        whole = -(-int(max_hint) // 64) * 64
-        if bs * self._wg_groups() >= self.TARGET_ITEMS:
-            return max(self.MIN_CHUNK, whole)
-        n = -(-int(max_hint) // chunk)
-        return max(self.MIN_CHUNK, -(-(-(-int(max_hint) // n)) // 64) * 64)
+        if bs * self._wg_groups() < self.TARGET_ITEMS:                   # unsplit would leave CUs without work
+            return chunk
+        return max(chunk, -(-int(max_hint) // 64) * 64)
 
     def _ensure_workspace(self, nbytes: int) -> torch.Tensor:
         if self._workspace.numel() < nbytes:

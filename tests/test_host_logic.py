@@ -432,7 +432,7 @@ def test_library_row_table_is_gated_on_the_build_it_was_measured_on(monkeypatch)
 def test_decode_split_size_policy_and_the_advisory_max_hint():
     """HipAttnBackend._plan_chunk (host logic only): about one item per CU between MIN_CHUNK and MAX_CHUNK; a
     near-uniform batch (advisory ModelWorkerBatch.seq_lens_max_hint <= 1.35 x mean) is not split when that still leaves a
-    workgroup per CU, and otherwise gets evenly sized splits; a missing, ragged or implausible hint changes nothing."""
+    workgroup per CU; a missing, ragged or implausible hint changes nothing."""
     from scratchpad_amd.attention import HipAttnBackend
     b = HipAttnBackend.__new__(HipAttnBackend)
     b.num_kv_head, b.head_dim = 8, 128
@@ -443,13 +443,13 @@ def test_decode_split_size_policy_and_the_advisory_max_hint():
     assert b._plan_chunk(553000, dt, 256, 1) == 1024                  # a hint below the mean is no bound at all: ignored
     assert b._plan_chunk(1064 * 256, dt, 256, 1064) == 1088           # 512 workgroups unsplit: whole requests
     assert b._plan_chunk(4136 * 128, dt, 128, 4136) == 4160           # 256 workgroups unsplit: still one per CU
-    assert b._plan_chunk(1064 * 64, dt, 64, 1064) == 384              # 128 unsplit would idle half the chip: 3 even splits
+    assert b._plan_chunk(1064 * 64, dt, 64, 1064) == 512              # 128 unsplit would idle half the chip: the default
     assert b._plan_chunk(3584 * 256, dt, 256, 4096) == 4096           # U[3072, 4096]: near-uniform
     assert b._plan_chunk(2560 * 256, dt, 256, 4096) == 1024           # U[1024, 4096]: ragged
     assert b._plan_chunk(40 * 8, dt, 8, 40) == 64 and b._plan_chunk(10 ** 9, dt, 4, 10 ** 9 // 4) >= 1024
     b.num_kv_head = 1                                                 # 70B / TP 8 rank: one workgroup per item
     assert b._plan_chunk(288000, dt, 128, 4096) == 1024
-    assert b._plan_chunk(4136 * 128, dt, 128, 4136) == 832            # 128 unsplit workgroups < 256 CUs: 5 even splits
+    assert b._plan_chunk(4136 * 128, dt, 128, 4136) == 1024           # 128 unsplit workgroups < 256 CUs: the default
     assert b._plan_chunk(4136 * 256, dt, 256, 4136) == 4160
     # the hint is tracked by ScheduleBatch like seq_lens_sum, on the host
     from scratchpad_amd.schedule_batch import ScheduleBatch
