@@ -120,7 +120,10 @@ struct DmCfg {
 // (bf16 q is converted once per workgroup; P is rounded to fp16); the output keeps the model dtype.
 // HBM bytes per context token halve; everything after the LDS tile is unchanged.
 template <typename Tag, int D, bool HPW, bool KV8>
-__global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
+#ifndef SP_DEC_WAVES
+#define SP_DEC_WAVES 3
+#endif
+__global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeArgs a) {
   typedef DmCfg<D> C;
   typedef Elem<Tag> E;
   typedef typename std::conditional<KV8, f16_tag, Tag>::type CT;      // dtype of the tile math
@@ -216,6 +219,9 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
         if constexpr (KV8) {
           st16(ldsK + R * ROW_B + ld_ch * 16, expand_e5m2x8(ks[i]));
           st16(ldsV + R * ROW_B + ld_ch * 16, expand_e5m2x8(vs[i]));
+        } else {
+          st16(ldsK + R * ROW_B + ld_ch * 16, ks[i]);
+          st16(ldsV + R * ROW_B + ld_ch * 16, vs[i]);
         }
       }
     };
@@ -292,6 +298,8 @@ __global__ __launch_bounds__(256, 3) void decode_mfma_kernel(DecodeArgs a) {
     // the other waves of the SIMD: ~100 VGPRs => 4 waves per SIMD)
 #ifdef SP_DEC_ONESET   // diagnostic build: one register set for byte pools too
     constexpr bool kTwoSets = false;
+#elif defined(SP_DEC_TWOSETS)   // diagnostic build: two register sets for 16-bit pools too (with -DSP_DEC_WAVES=2: no spills)
+    constexpr bool kTwoSets = true;
 #else
     constexpr bool kTwoSets = KV8;
 #endif
