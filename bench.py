@@ -690,7 +690,10 @@ def pmc_traffic(alg_bytes, args):
     import glob
     sha = decode_kernel_sources_sha1()
     key = pmc_workload_key(args)
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_decode_attn_pmc*.json")), reverse=True)
+    # newest round first; within a round the in-model record (tools/pmc_bench.sh: rocprofv3 --pmc around bench.py itself)
+    # before the kernel-alone ones (tools/pmc_decode.sh)
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_bench_pmc*.json")), reverse=True) + \
+        sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_decode_attn_pmc*.json")), reverse=True)
     stale = False
     for path in paths:                   # newest round first: the pass recorded for THESE kernel sources
         rec = json.load(open(path))
