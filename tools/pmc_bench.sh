@@ -16,7 +16,7 @@ cd $GRAFT_REPO_ROOT
 { echo "# rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE} --kernel-trace -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-ttft --profile-steps 1 $*"
   python tools/pmc_summary.py $OUT/f decode_mfma_kernel decode_merge_kernel
   python tools/pmc_summary.py $OUT/w decode_mfma_kernel decode_merge_kernel
-  tail -1 $OUT/f.log | cut -c1-600; } > $OUT/summary.txt
+  grep -h '^{"metric"' $OUT/f.log | tail -1 | cut -c1-600; } > $OUT/summary.txt
 KEY=$KEY python - <<'PY'
 import csv, glob, json, os, re, sys
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
@@ -41,7 +41,7 @@ def steady(root, counter):
     return sum(a) / len(a), sum(mm) / len(mm), len(a)
 fa, fm, n = steady(os.path.join(out, "f"), "FETCH_SIZE")
 wa, wm, _ = steady(os.path.join(out, "w"), "WRITE_SIZE")
-line = json.loads(open(os.path.join(out, "f.log")).read().strip().splitlines()[-1])
+line = json.loads([l for l in open(os.path.join(out, "f.log")) if l.startswith('{"metric"')][-1])
 alg = line["roofline"]["algorithmic_bytes_per_launch"]
 hbm = (2 * fa + wa + fm + wm) * 1024.0
 rec = {"workload": "python3 bench.py " + " ".join(sys.argv[1:]) + " (in the model, HIP-graph replay)", "bench_workload": os.environ["KEY"],
