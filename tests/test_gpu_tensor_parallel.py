@@ -524,12 +524,12 @@ def test_tp_over_rccl_matches_unsharded_oracle(world, wide, dt, custom_ar):
     _run_ranks(_rccl_main, world, (custom_ar, wide, dt), timeout=900)
 
 
-@pytest.mark.parametrize("world,dt,custom_ar", [(2, "bf16", True), (4, "f32", False)],
-                         ids=["tp2-bf16-direct-all-reduce-graph", "tp4-f32-gloo"])
+@pytest.mark.parametrize("world,dt,custom_ar", [(2, "bf16", True)], ids=["tp2-bf16-direct-all-reduce-graph"])
 def test_70b_head_counts_sharded_on_one_gpu(world, dt, custom_ar):
     """The flow of test_tp_over_rccl_matches_unsharded_oracle's 70b-heads cases with the ranks sharing cuda:0 over
-    gloo: everything of config 4's partitioning except the transport (64 / 8 heads of 128 sharded 2 and 4 ways: per
-    rank Hq 32 / Hkv 4 and Hq 16 / Hkv 2), so that the cases a TP node will run are not first executed there."""
+    gloo: everything of config 4's partitioning except the transport (64 / 8 heads of 128 sharded 2 ways: per
+    rank Hq 32 / Hkv 4; a TP 4 fp32 variant of this ran green in round 4 and was dropped for its 53 s of four time-sliced
+    ranks), so that the cases a TP node will run are not first executed there."""
     _run_ranks(_rccl_main, world, (custom_ar, True, dt, "gloo"), timeout=900)
 
 
