@@ -113,9 +113,13 @@ class HipAttnBackend(AttentionBackend):
     # (profiles/r04_decode_variants.txt section 5, same box, 512 -> 1024): headline 13.11 / 12.98 -> 13.08 / 12.93 k
     # tokens/s (noise), ctx 1024 18.68 -> 19.48 k (+4.3 %, attention 212 -> 196 us), ctx 4096 +1.6 %, 70B rank shape
     # +1.2 % (attention 40.6 -> 38.8 us), bs 128 +1.0 %, fp8 KV +2.0 %, bs 64 -1.5 %; 2048 is worse again (ctx 2048
-    # -2 %, bs 32 x ctx 4096 -5 %).  SP_DECODE_MAX_CHUNK overrides it for such A/B runs.
+    # -2 %, bs 32 x ctx 4096 -5 %).  Then 1024 -> 768 (the cap need not be a power of two; sections 5c / 5d, one box
+    # each): headline 13.12 / 13.13 -> 13.14 / 13.20 k (attention 391 -> 388 us), bs 128 +1.4 %, bs 64 +1.0 %, 70B rank
+    # shape +0.9 % (attention 37.8 -> 36.7 us), fp8 KV +0.9 %; 640 and 896 are worse at the headline (12.97 / 13.07 k
+    # against 13.11).  Tuned on contexts U[128, 4096]; near-uniform batches do not use it (_plan_chunk).
+    # SP_DECODE_MAX_CHUNK overrides it for such A/B runs.
     TARGET_ITEMS = 256
-    MIN_CHUNK, MAX_CHUNK = 64, int(os.environ.get("SP_DECODE_MAX_CHUNK", "1024"))
+    MIN_CHUNK, MAX_CHUNK = 64, int(os.environ.get("SP_DECODE_MAX_CHUNK", "768"))
     # graph replay: work items / partial slots a captured launch of bucket bs covers (the launch geometry is
     # a function of this number only; the split size travels in the step's plan).  max(1024, 8 bs) + bs keeps
     # 512-key splits up to a mean context of 4096 per request and lets the splits grow beyond that, so the

@@ -437,19 +437,19 @@ def test_decode_split_size_policy_and_the_advisory_max_hint():
     b = HipAttnBackend.__new__(HipAttnBackend)
     b.num_kv_head, b.head_dim = 8, 128
     dt = torch.bfloat16
-    assert (b.MIN_CHUNK, b.MAX_CHUNK, b.TARGET_ITEMS) == (64, 1024, 256)
+    assert (b.MIN_CHUNK, b.MAX_CHUNK, b.TARGET_ITEMS) == (64, 768, 256)
     ragged = b._plan_chunk(553000, dt, 256, 4096)                    # the headline batch: max / mean = 1.9
-    assert ragged == b._plan_chunk(553000, dt) == b._plan_chunk(553000, dt, 256, None) == 1024
-    assert b._plan_chunk(553000, dt, 256, 1) == 1024                  # a hint below the mean is no bound at all: ignored
+    assert ragged == b._plan_chunk(553000, dt) == b._plan_chunk(553000, dt, 256, None) == 768
+    assert b._plan_chunk(553000, dt, 256, 1) == 768                  # a hint below the mean is no bound at all: ignored
     assert b._plan_chunk(1064 * 256, dt, 256, 1064) == 1088           # 512 workgroups unsplit: whole requests
     assert b._plan_chunk(4136 * 128, dt, 128, 4136) == 4160           # 256 workgroups unsplit: still one per CU
     assert b._plan_chunk(1064 * 64, dt, 64, 1064) == 512              # 128 unsplit would idle half the chip: the default
     assert b._plan_chunk(3584 * 256, dt, 256, 4096) == 4096           # U[3072, 4096]: near-uniform
-    assert b._plan_chunk(2560 * 256, dt, 256, 4096) == 1024           # U[1024, 4096]: ragged
-    assert b._plan_chunk(40 * 8, dt, 8, 40) == 64 and b._plan_chunk(10 ** 9, dt, 4, 10 ** 9 // 4) >= 1024
+    assert b._plan_chunk(2560 * 256, dt, 256, 4096) == 768           # U[1024, 4096]: ragged
+    assert b._plan_chunk(40 * 8, dt, 8, 40) == 64 and b._plan_chunk(10 ** 9, dt, 4, 10 ** 9 // 4) >= 768
     b.num_kv_head = 1                                                 # 70B / TP 8 rank: one workgroup per item
-    assert b._plan_chunk(288000, dt, 128, 4096) == 1024
-    assert b._plan_chunk(4136 * 128, dt, 128, 4136) == 1024           # 128 unsplit workgroups < 256 CUs: the default
+    assert b._plan_chunk(288000, dt, 128, 4096) == 768
+    assert b._plan_chunk(4136 * 128, dt, 128, 4136) == 768            # 128 unsplit workgroups < 256 CUs: the default
     assert b._plan_chunk(4136 * 256, dt, 256, 4136) == 4160
     # the hint is tracked by ScheduleBatch like seq_lens_sum, on the host
     from scratchpad_amd.schedule_batch import ScheduleBatch
