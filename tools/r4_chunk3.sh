@@ -12,11 +12,10 @@ d=json.loads(sys.stdin.read()); r=d.get('roofline',{})
 print(json.dumps({'value':d['value'],'ms_per_step':d['ms_per_step'],'attn_ms':r.get('avg_launch_ms'),'attn_GBs':r.get('achieved')}))" >> $OUT/ab.txt || exit 1
 }
 : > $OUT/ab.txt
-for c in 640 768 896; do
-run headline_$c SP_DECODE_MAX_CHUNK=$c -- &&
-run bs128_$c SP_DECODE_MAX_CHUNK=$c -- --bs 128 &&
-run bs64_$c SP_DECODE_MAX_CHUNK=$c -- --bs 64 &&
-run bs192_$c SP_DECODE_MAX_CHUNK=$c -- --bs 192 &&
-run r70b_$c SP_DECODE_MAX_CHUNK=$c -- --model llama3-70b-tp8-rank --bs 128 || exit 1
+for c in 64 32 16; do
+run bs1_min$c SP_DECODE_MIN_CHUNK=$c -- --bs 1 --ctx 1024 &&
+run bs1ctx4096_min$c SP_DECODE_MIN_CHUNK=$c -- --bs 1 --ctx 4096 &&
+run bs4_min$c SP_DECODE_MIN_CHUNK=$c -- --bs 4 --ctx 1024 &&
+run bs8_min$c SP_DECODE_MIN_CHUNK=$c -- --bs 8 --ctx 1024 || exit 1
 done
 paste - - < $OUT/ab.txt
