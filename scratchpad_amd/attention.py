@@ -117,9 +117,10 @@ class HipAttnBackend(AttentionBackend):
     # each): headline 13.12 / 13.13 -> 13.14 / 13.20 k (attention 391 -> 388 us), bs 128 +1.4 %, bs 64 +1.0 %, 70B rank
     # shape +0.9 % (attention 37.8 -> 36.7 us), fp8 KV +0.9 %; 640 and 896 are worse at the headline (12.97 / 13.07 k
     # against 13.11).  Tuned on contexts U[128, 4096]; near-uniform batches do not use it (_plan_chunk).
-    # SP_DECODE_MAX_CHUNK / SP_DECODE_MIN_CHUNK override them for such A/B runs (MIN_CHUNK 32 / 16 measured equal or slower
+    # TARGET_ITEMS 128 measured 2 - 11 % slower on bs 8 - 64 x ctx 1024 / 4096, 512 within +-1.5 % of 256.
+    # SP_DECODE_MAX_CHUNK / SP_DECODE_MIN_CHUNK / SP_DECODE_TARGET_ITEMS override them for such A/B runs (MIN_CHUNK 32 / 16 measured equal or slower
     # at bs 1 - 8: 3.952 / 3.965 / 4.004 ms per step at bs 1; 4.126 / 4.238 / 4.240 at bs 1 x ctx 4096).
-    TARGET_ITEMS = 256
+    TARGET_ITEMS = int(os.environ.get("SP_DECODE_TARGET_ITEMS", "256"))
     MIN_CHUNK, MAX_CHUNK = int(os.environ.get("SP_DECODE_MIN_CHUNK", "64")), int(os.environ.get("SP_DECODE_MAX_CHUNK", "768"))
     # graph replay: work items / partial slots a captured launch of bucket bs covers (the launch geometry is
     # a function of this number only; the split size travels in the step's plan).  max(1024, 8 bs) + bs keeps

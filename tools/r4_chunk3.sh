@@ -12,10 +12,11 @@ d=json.loads(sys.stdin.read()); r=d.get('roofline',{})
 print(json.dumps({'value':d['value'],'ms_per_step':d['ms_per_step'],'attn_ms':r.get('avg_launch_ms'),'attn_GBs':r.get('achieved')}))" >> $OUT/ab.txt || exit 1
 }
 : > $OUT/ab.txt
-for c in 64 32 16; do
-run bs1_min$c SP_DECODE_MIN_CHUNK=$c -- --bs 1 --ctx 1024 &&
-run bs1ctx4096_min$c SP_DECODE_MIN_CHUNK=$c -- --bs 1 --ctx 4096 &&
-run bs4_min$c SP_DECODE_MIN_CHUNK=$c -- --bs 4 --ctx 1024 &&
-run bs8_min$c SP_DECODE_MIN_CHUNK=$c -- --bs 8 --ctx 1024 || exit 1
+for c in 256 128 512; do
+run bs32ctx1024_t$c SP_DECODE_TARGET_ITEMS=$c -- --bs 32 --ctx 1024 &&
+run bs16ctx4096_t$c SP_DECODE_TARGET_ITEMS=$c -- --bs 16 --ctx 4096 &&
+run bs8ctx4096_t$c SP_DECODE_TARGET_ITEMS=$c -- --bs 8 --ctx 4096 &&
+run bs64ctx1024_t$c SP_DECODE_TARGET_ITEMS=$c -- --bs 64 --ctx 1024 &&
+run bs32_t$c SP_DECODE_TARGET_ITEMS=$c -- --bs 32 || exit 1
 done
 paste - - < $OUT/ab.txt
