@@ -71,12 +71,45 @@ def rope_inv_freq(base: float, rotary_dim: int,
 
 def rope_cos_sin_cache(max_position: int, base: float, rotary_dim: int,
                        llama3: Optional[Sequence[float]] = None,
-                       dtype: torch.dtype = torch.float32) -> torch.Tensor:
+                       dtype: torch.dtype = torch.float32, scaling: Optional[dict] = None) -> torch.Tensor:
     """RotaryEmbedding._compute_cos_sin_cache - rotary_embedding.py:92-101, cast to the model
-    dtype as __init__ does (72-75).  Layout [max_position, rotary_dim] = cos || sin."""
-    inv = rope_inv_freq(base, rotary_dim, llama3)
-    t = torch.arange(max_position, dtype=torch.float)
+    dtype as __init__ does (72-75).  Layout [max_position, rotary_dim] = cos || sin.
+    ``scaling``: a get_rope dict of type "linear" / "dynamic" / "yarn" (rotary_embedding.py:996-1036 ->
+    LinearScalingRotaryEmbedding 214-245 with ONE factor, DynamicNTKScalingRotaryEmbedding 281-299,
+    YaRNScalingRotaryEmbedding 373-414): the table then covers context * factor positions."""
+    if scaling is None:
+        inv = rope_inv_freq(base, rotary_dim, llama3)
+        t = torch.arange(max_position, dtype=torch.float)
+        freqs = torch.einsum("i,j -> ij", t, inv)
+        return torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(dtype)
+    kind, factor = scaling["rope_type"], scaling["factor"]
+    mscale = 1.0
+    if kind == "linear":                                   # 232-236: t / factor over max_position * factor entries
+        t = torch.arange(max_position * factor, dtype=torch.float) / factor
+        inv = rope_inv_freq(base, rotary_dim)
+    elif kind == "dynamic":                                # 286-292: the NTK base at the extended length
+        n = max_position * factor
+        ntk = base * ((factor * n / max_position) - (factor - 1)) ** (rotary_dim / (rotary_dim - 2))
+        t = torch.arange(n, dtype=torch.float)
+        inv = rope_inv_freq(ntk, rotary_dim)
+    elif kind == "yarn":                                   # 302-345, 382-414; the context is the ORIGINAL one (1018-1036)
+        ctx = scaling["original_max_position_embeddings"]
+        fast, slow = scaling.get("beta_fast", 32), scaling.get("beta_slow", 1)
+        pos_freqs = base ** (torch.arange(0, rotary_dim, 2, dtype=torch.float) / rotary_dim)
+        dim_of = lambda rot: (rotary_dim * math.log(ctx / (rot * 2 * math.pi))) / (2 * math.log(base))
+        low, high = max(math.floor(dim_of(fast)), 0), min(math.ceil(dim_of(slow)), rotary_dim - 1)
+        if low == high:
+            high += 0.001
+        ramp = torch.clamp((torch.arange(rotary_dim // 2, dtype=torch.float) - low) / (high - low), 0, 1)
+        mask = (1 - ramp) * scaling.get("extrapolation_factor", 1)
+        inv = 1.0 / (factor * pos_freqs) * (1 - mask) + 1.0 / pos_freqs * mask
+        mscale = float((0.1 * math.log(factor) + 1.0 if factor > 1 else 1.0) * scaling.get("attn_factor", 1))
+        t = torch.arange(ctx * factor, dtype=torch.float32)
+    else:
+        raise ValueError(kind)
     freqs = torch.einsum("i,j -> ij", t, inv)
+    if kind == "yarn":
+        return torch.cat((freqs.cos() * mscale, freqs.sin() * mscale), dim=-1).to(dtype)
     return torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(dtype)
 
 

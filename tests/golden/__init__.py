@@ -14,3 +14,16 @@ def load(name):
             a = z[k]
             out[k] = a.astype(np.float32) if a.dtype == np.float16 else a
     return out
+
+
+def rope_scaling(g, i):
+    """the rope_scaling dict of case i of rotary.npz (None: plain RoPE): llama3 parameters are stored as an array of
+    four numbers, every other variant as the JSON text of the dict handed to the reference's get_rope"""
+    import json
+    if f"c{i}_scaling" in g:
+        f = g[f"c{i}_scaling"]
+        return {"rope_type": "llama3", "factor": float(f[0]), "low_freq_factor": float(f[1]),
+                "high_freq_factor": float(f[2]), "original_max_position_embeddings": int(f[3])}
+    if f"c{i}_scaling_json" in g:
+        return json.loads(str(g[f"c{i}_scaling_json"]))
+    return None

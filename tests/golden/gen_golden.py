@@ -110,12 +110,21 @@ def gen_rotary():
         (128, 128, 320, 500000, True, dict(llama3, factor=8.0), 4, 1, 5),
         (64, 64, 128, 10000, False, None, 4, 4, 5),      # GPT-J interleaved style
         (64, 32, 128, 10000, True, None, 4, 2, 5),       # partial rotary
+        # context-extension variants (rotary_embedding.py:173-414): the table covers max_pos * factor positions
+        (64, 64, 64, 10000, True, {"rope_type": "linear", "factor": 4.0}, 4, 2, 6),
+        (128, 128, 48, 500000, True, {"rope_type": "dynamic", "factor": 2.0}, 4, 1, 5),
+        (64, 64, 96, 10000, True, {"rope_type": "yarn", "factor": 4.0, "original_max_position_embeddings": 32}, 4, 2, 6),
+        (128, 128, 256, 1000000, True, {"rope_type": "yarn", "factor": 8.0, "original_max_position_embeddings": 24,
+                                        "beta_fast": 16, "beta_slow": 2, "attn_factor": 1.25}, 8, 2, 5),
+        (64, 32, 64, 10000, False, {"rope_type": "yarn", "factor": 2.0, "original_max_position_embeddings": 40,
+                                    "extrapolation_factor": 0.5}, 4, 4, 5),
     ]
     for i, (hs, rd, mp, base, neox, sc, Hq, Hkv, T) in enumerate(cases):
         rope = get_rope(hs, rd, mp, base, neox, sc, dtype=torch.float32)
-        pos = torch.randint(0, mp, (T,), generator=g, dtype=torch.int64)
+        span = rope.cos_sin_cache.shape[0]                   # = mp, or the extended length of a scaled variant
+        pos = torch.randint(0, span, (T,), generator=g, dtype=torch.int64)
         pos[0] = 0
-        pos[-1] = mp - 1
+        pos[-1] = span - 1
         q = _randn(T, Hq * hs, generator=g)
         k = _randn(T, Hkv * hs, generator=g)
         q2, k2 = rope.forward_native(pos, q.clone(), k.clone())
@@ -127,10 +136,13 @@ def gen_rotary():
             # the whole cache pins _compute_inv_freq/_compute_cos_sin_cache (incl. llama3)
             f"c{i}_cos_sin_cache": rope.cos_sin_cache,
         })
-        if sc is not None:
+        if sc is not None and sc["rope_type"] == "llama3":
             out[f"c{i}_scaling"] = np.array([sc["factor"], sc["low_freq_factor"],
                                              sc["high_freq_factor"],
                                              sc["original_max_position_embeddings"]], np.float64)
+        elif sc is not None:                                 # the other variants: the dict itself, as JSON text
+            import json
+            out[f"c{i}_scaling_json"] = np.array(json.dumps(sc))
     out["num_cases"] = np.int64(len(cases))
     _save("rotary", **out)
 

@@ -109,11 +109,7 @@ def test_rotary_golden_and_cache(nat, dt):
     g = golden.load("rotary")
     for i in range(int(g["num_cases"])):
         hs, rd, mp = (int(g[f"c{i}_{n}"]) for n in ("head_size", "rotary_dim", "max_pos"))
-        sc = None
-        if f"c{i}_scaling" in g:
-            f = g[f"c{i}_scaling"]
-            sc = {"rope_type": "llama3", "factor": float(f[0]), "low_freq_factor": float(f[1]),
-                  "high_freq_factor": float(f[2]), "original_max_position_embeddings": int(f[3])}
+        sc = golden.rope_scaling(g, i)           # None / llama3 / linear / dynamic NTK / YaRN
         rope = get_rope(hs, rd, mp, float(g[f"c{i}_base"]), bool(g[f"c{i}_neox"]), sc, dtype=dtype)
         if dtype == torch.float32:   # cache = the reference's, bit for bit (host fp32 math)
             assert np.array_equal(rope.cos_sin_cache.cpu().numpy(), g[f"c{i}_cos_sin_cache"])

@@ -122,19 +122,20 @@ def test_forward_mode_semantics():
 def test_rope_cache_is_the_references_bit_for_bit():
     g = golden.load("rotary")
     for i in range(int(g["num_cases"])):
-        sc = None
-        if f"c{i}_scaling" in g:
-            f = g[f"c{i}_scaling"]
-            sc = {"rope_type": "llama3", "factor": float(f[0]), "low_freq_factor": float(f[1]),
-                  "high_freq_factor": float(f[2]), "original_max_position_embeddings": int(f[3])}
+        sc = golden.rope_scaling(g, i)          # None, llama3, or (round 4) linear / dynamic NTK / YaRN
         rope = get_rope(int(g[f"c{i}_head_size"]), int(g[f"c{i}_rotary_dim"]), int(g[f"c{i}_max_pos"]),
                         float(g[f"c{i}_base"]), bool(g[f"c{i}_neox"]), sc, dtype=torch.float32)
-        assert np.array_equal(rope.cos_sin_cache.numpy(), g[f"c{i}_cos_sin_cache"]), f"case {i}"
+        assert np.array_equal(rope.cos_sin_cache.numpy(), g[f"c{i}_cos_sin_cache"]), f"case {i} {sc}"
     a = get_rope(64, 64, 128, 10000, True, None, torch.float32)
     assert a is get_rope(64, 64, 128, 10000, True, None, torch.float32), "cached per key"
     assert get_rope(64, 64, 128, 10000, True, None, torch.float32, partial_rotary_factor=0.5).rotary_dim == 32
-    with pytest.raises(ValueError):
-        get_rope(64, 64, 128, 10000, True, {"rope_type": "yarn", "factor": 2.0}, torch.float32)
+    kinds = [golden.rope_scaling(g, i)["rope_type"] for i in range(int(g["num_cases"])) if golden.rope_scaling(g, i)]
+    assert sorted(set(kinds)) == ["dynamic", "linear", "llama3", "yarn"]
+    for unbuilt in ("deepseek_yarn", "longrope"):           # MLA / Phi-3 model families: out of scope
+        with pytest.raises(ValueError):
+            get_rope(64, 64, 128, 10000, True, {"rope_type": unbuilt, "factor": 2.0}, torch.float32)
+    with pytest.raises(NotImplementedError):                 # per-LoRA tables (a list of linear factors)
+        get_rope(64, 64, 128, 10000, True, {"rope_type": "linear", "factor": [2.0, 4.0]}, torch.float32)
 
 
 def test_model_config_head_math_and_graph_buckets():

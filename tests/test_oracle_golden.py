@@ -44,7 +44,8 @@ def test_rotary_cache_and_apply():
     for i in range(int(g["num_cases"])):
         hs, rd, mp = int(g[f"c{i}_head_size"]), int(g[f"c{i}_rotary_dim"]), int(g[f"c{i}_max_pos"])
         sc = tuple(g[f"c{i}_scaling"]) if f"c{i}_scaling" in g else None
-        cache = ops.rope_cos_sin_cache(mp, float(g[f"c{i}_base"]), rd, sc)
+        other = golden.rope_scaling(g, i) if f"c{i}_scaling_json" in g else None      # linear / dynamic / yarn
+        cache = ops.rope_cos_sin_cache(mp, float(g[f"c{i}_base"]), rd, sc, scaling=other)
         # cache built with the same torch ops on the same CPU: bit-exact
         assert np.array_equal(cache.numpy(), g[f"c{i}_cos_sin_cache"]), f"case {i}"
         q, k = ops.rotary_embedding(T(g[f"c{i}_positions"]), T(g[f"c{i}_q"]), T(g[f"c{i}_k"]), hs,
