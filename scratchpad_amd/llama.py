@@ -356,7 +356,7 @@ class LlamaMLP(nn.Module):
         self.act_fn = SiluAndMul()
 
     def forward(self, x, reduce_output: bool = True):
-        # small decode steps (<= 16 tokens): projection and activation in one weight-streaming launch, the bits of
+        # small decode steps (<= _native.SILU_FUSED_MAX_ROWS tokens): projection and activation in one weight-streaming launch, the bits of
         # the skinny projection followed by act_fn
         act = _native.linear_silu_mul(x, self.gate_up_proj.weight)
         if act is None:

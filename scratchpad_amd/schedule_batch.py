@@ -404,7 +404,9 @@ class ScheduleBatch:
         self.seq_lens = torch.cat([self.seq_lens, other.seq_lens])
         self.out_cache_loc = None
         self.seq_lens_sum += other.seq_lens_sum
-        self.seq_lens_max = max(self.seq_lens_max, other.seq_lens_max)
+        # (a side that has requests but no bound makes the merged bound unknown, not too small)
+        known = all(b.seq_lens_max or not b.reqs for b in (self, other))
+        self.seq_lens_max = max(self.seq_lens_max, other.seq_lens_max) if known else 0
         if self.output_ids is not None:
             # as the reference: a side that carries pending output ids needs the other side's, or the rows
             # would no longer line up with reqs / seq_lens - fail loudly instead of keeping the old length
