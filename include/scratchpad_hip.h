@@ -148,7 +148,7 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  * kv head) combines them, in the same order and to the same bits as the merge launch.
  *   - Without a plan the grid is the static (request, split) rectangle: slot0[b] = b * num_splits,
  *     num_splits = ceil(max_seq_len / chunk), max_slots is ignored (= batch_size * num_splits).
- *   - With a `plan` (sp_decode_plan: [count, chunk, needed, 0 | slot0[bs] | (b, c) x max_slots | counters], built once per step from
+ *   - With a `plan` (sp_decode_plan: [count, chunk, needed, keys | slot0[bs] | (b, c) x max_slots | counters], built once per step from
  *     the same seq_lens and shared by all layers - the counterpart of flashinfer's begin_forward()/plan,
  *     flashinfer_backend.py:623-670, and of TritonAttnBackend.init_forward_metadata,
  *     triton_backend.py:48-68) the launch covers `max_slots` work items, the kernels read the split size
@@ -173,6 +173,13 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  * (the caller's bound on sum(seq_lens) was too small) the surplus splits are not computed and the affected
  * output rows are wrong or unwritten.  Nothing on the device reports this by itself: the caller reads plan[2]
  * (a 16-byte copy of the header at a point where it synchronises anyway) and raises - HipAttnBackend does.
+ *
+ * Streaming gathers.  The plan's word 3 holds the keys the step gathers per kv head (the sum of the clamped lengths).
+ * When a launch's K + V bytes (that sum x 2 x num_kv_heads x head_dim x element size) reach a threshold
+ * (sp_debug_set("decode_nt_min_mb", n); 0 = always, -1 = never, -2 = the default) the matrix-core kernel gathers K/V rows with
+ * NON-TEMPORAL loads: rows read once per step no longer displace the rest of the step's data from the caches.  It is plan
+ * data, so a captured launch follows each step's own size; results are the same bits either way; plan-less launches
+ * use plain loads.
  *
  * `kv_dtype` = `dtype`, or SP_FP8_E5M2 for a uint8 pool written by sp_kv_store_fp8 (16-bit q
  * only; kv_buffer_stride then counts bytes): the kernels widen e5m2 to half exactly and compute

@@ -11,7 +11,9 @@ from typing import Optional
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libscratchpad_hip.so")
+# SP_NATIVE_LIB names a diagnostic build under lib/ (A/B runs of a kernel variant through the whole model); unset = the product
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                         os.environ.get("SP_NATIVE_LIB") or "libscratchpad_hip.so")
 _lib = None
 
 SP_F32, SP_F16, SP_BF16 = 0, 1, 2
@@ -343,7 +345,7 @@ def decode_workspace_bytes(bs: int, Hq: int, Dv: int, max_seq_len: int, chunk: i
     return int(load().sp_decode_attention_workspace_bytes(max_slots, Hq, Dv))
 
 
-PLAN_HEADER_WORDS = 4          # [items listed, chunk, items the lengths need, 0]
+PLAN_HEADER_WORDS = 4          # [items listed, chunk, items the lengths need, keys the step gathers per kv head]
 
 
 def decode_plan_bytes(bs: int, max_seq_len: int, chunk: int, max_slots: Optional[int] = None,
@@ -355,7 +357,7 @@ def decode_plan_bytes(bs: int, max_seq_len: int, chunk: int, max_slots: Optional
 
 def decode_plan(plan: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int, chunk: int,
                 max_slots: Optional[int] = None, fuse_groups: int = 0) -> None:
-    """Fill `plan` (int32: [count, chunk, needed, 0 | slot0[bs] | (request, split) x max_slots | counters]) for this
+    """Fill `plan` (int32: [count, chunk, needed, keys | slot0[bs] | (request, split) x max_slots | counters]) for this
     step's lengths.  `max_slots`: the item / partial-slot capacity the launches using this plan are given (default:
     the static bound bs * ceil(max_seq_len / chunk)).  `fuse_groups` > 0 (the layers' kv head count): the plan
     carries arrival counters and decode_attention(plan_fuse_groups=...) merges the splits inside the kernel.

@@ -25,16 +25,23 @@ struct DecodeArgs {
   float* part_o;    // [Hq, max_slots, D]   slot of (request b, split c): slot0[b] + c (a request's splits are adjacent)
   float* part_lse;  // [Hq, max_slots]      (log2 domain)
   int kv8;              // 1: the pool holds fp8 e5m2 bytes (kv_stride in bytes); 16-bit q/out only
-  // optional, from sp_decode_plan: [count, chunk, needed, 0 | slot0[bs] | (b, c) x max_slots | arrival counters].
+  // optional, from sp_decode_plan: [count, chunk, needed, keys | slot0[bs] | (b, c) x max_slots | arrival counters].
   // The CHUNK is part of the plan (device memory), so a captured launch follows whatever split size the step's
   // plan was built with; slot0[b] = first partial slot of request b (exclusive scan of its split count);
   // needed = the item count BEFORE the cut at max_slots (needed > count: the host's bound on sum(seq_lens) was
-  // broken and items were dropped - the host checks this word, see sp_decode_plan).
+  // broken and items were dropped - the host checks this word, see sp_decode_plan); keys = sum of the (clamped)
+  // lengths, i.e. the key rows this step's launches gather per kv head.
   const int32_t* plan;
   // > 0: the plan carries fuse_groups arrival counters per request behind its items (zeroed by sp_decode_plan, reset
   // by the last arriver): the matrix-core kernel merges a request's splits itself - the workgroup (wave, where a wave
   // owns its heads) whose partials arrive last combines them - and no merge kernel is launched.  0: separate merge.
   int fuse_groups;
+  // K/V gathers of the matrix-core kernel are NON-TEMPORAL loads when the step reads at least this many keys in total
+  // (plan[3], written by sp_decode_plan): a stream that is read once and is larger than the caches then no longer
+  // displaces everything else in them, at the price of about a microsecond of latency per dependent round of gathers,
+  // which only a launch of several rounds of workgroups hides.  0 = always, INT_MAX = never; plan-less launches: never
+  // (unless 0).
+  int nt_min_keys;
 };
 
 static constexpr int kPlanHdr = 4;   // int32 words in front of slot0[]
@@ -136,5 +143,6 @@ int decode_heads_per_load_shift(int num_kv_heads, int head_dim, int dtype, int* 
 
 // test / tuning hooks behind sp_debug_set
 void set_decode_kernel(int which);
+void set_decode_nt_min_mb(int mb);
 
 }  // namespace sp

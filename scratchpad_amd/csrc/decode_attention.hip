@@ -322,6 +322,8 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ 
                                                            int max_items, int fuse_groups) {
   __shared__ int s_scan[256];
   __shared__ int s_base;
+  __shared__ unsigned long long s_keys;
+  if (threadIdx.x == 0) s_keys = 0;
   int32_t* items = plan + kPlanHdr + bs;
   int32_t* counters = items + 2 * (int64_t)max_items;
   for (int i = threadIdx.x; i < bs * fuse_groups; i += 256) counters[i] = 0;
@@ -345,6 +347,7 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ 
         tail = rem > 0 && (4 - pass) == (int)(((int64_t)rem * 4 - 1) / chunk) ? 1 : 0;
       }
       const int mine = pass == -1 ? nfull + (rem > 0 ? 1 : 0) : (pass == 0 ? nfull : tail);
+      if (pass == -1 && b < bs) atomicAdd(&s_keys, (unsigned long long)(nfull * (int64_t)chunk + rem));
       s_scan[threadIdx.x] = mine;
       __syncthreads();
       for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ 
     plan[0] = min(s_base, max_items);
     plan[1] = chunk;
     plan[2] = s_base;
-    plan[3] = 0;
+    plan[3] = (int)min(s_keys, 0x7fffffffULL);     // keys this step gathers per kv head (DecodeArgs::nt_min_keys)
   }
 }
 
@@ -465,6 +468,12 @@ int run_decode_merge(const DecodeArgs& a, int head_dim, int dtype, hipStream_t s
 // measurements and tests only; a process-wide variable, never the environment on the call path).
 static int g_decode_kernel_forced = 0;
 void set_decode_kernel(int which) { g_decode_kernel_forced = which; }
+// sp_debug_set("decode_nt_min_mb", n): the K + V bytes a decode launch has to gather (over all its kv heads) before its
+// gathers become non-temporal loads; 0 = always, -1 = never, -2 = back to the default.  See DecodeArgs::nt_min_keys and
+// DESIGN 4.1 for the measurements behind the default.
+static constexpr int kDecodeNtMinMbDefault = 0;
+static int g_decode_nt_min_mb = kDecodeNtMinMbDefault;
+void set_decode_nt_min_mb(int mb) { g_decode_nt_min_mb = mb == -2 ? kDecodeNtMinMbDefault : mb; }
 static int decode_kernel_choice(int group, int dtype) {
   if (dtype == SP_F32 || group > 16) return 1;
   if (g_decode_kernel_forced == 1 || g_decode_kernel_forced == 2) return g_decode_kernel_forced;
@@ -601,6 +610,12 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
   // sp_decode_plan was given as fuse_groups; the partials are then addressed through a buffer descriptor (32-bit offsets)
   SP_CHECK_ARG(plan_fuse_groups >= 0 && (plan_fuse_groups == 0 || (plan && plan_fuse_groups >= num_kv_heads)));
   a.fuse_groups = plan ? plan_fuse_groups : 0;
+  {
+    // bytes of K + V one key row costs this launch (all its kv heads)
+    const int64_t key_bytes = 2LL * num_kv_heads * head_dim * (kv8 ? 1 : eb);
+    a.nt_min_keys = g_decode_nt_min_mb < 0 ? 0x7fffffff
+                                           : (int)(((int64_t)g_decode_nt_min_mb << 20) / key_bytes);   // (< 2^31: mb is an int)
+  }
   if (a.fuse_groups > 0 &&
       sp_decode_attention_workspace_bytes(max_slots, num_q_heads, head_dim) >= 0x7fffffffULL) a.fuse_groups = 0;
   if (S > 1) {

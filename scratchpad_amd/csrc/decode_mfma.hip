@@ -188,6 +188,10 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
   const int ws = HPW ? cs : cs + wave * sub;
   const int we = min(ws + sub, ce);
 
+  // The key loop exists twice: with plain and with NON-TEMPORAL K/V gathers (DecodeArgs::nt_min_keys; the choice is
+  // uniform over the launch - plan data - and made once, here, so that each form is a loop of its own).
+  auto key_loop = [&](auto nt_c) {
+  constexpr bool NT = decltype(nt_c)::value;
   int nextidx = (ws + lane < we) ? idx_row[ws + lane] : 0;
   for (int ps = ws; ps < we; ps += 64) {           // pieces of <= 64 keys: one index register
     const int n = min(64, we - ps);
@@ -206,8 +210,13 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
         const int R = i * RPL + ld_row;
         const int64_t off = (key < nkeys ? (int64_t)slot : 0) * tok_bytes + head_off +
                             ((ld_ch ^ (R & (CPR - 1))) * SRC_CH_B);
-        kd[i] = *(const raw_t*)(a.kbuf + off);
-        vd[i] = *(const raw_t*)(a.vbuf + off);
+        if constexpr (NT) {
+          kd[i] = __builtin_nontemporal_load((const raw_t*)(a.kbuf + off));
+          vd[i] = __builtin_nontemporal_load((const raw_t*)(a.vbuf + off));
+        } else {
+          kd[i] = *(const raw_t*)(a.kbuf + off);
+          vd[i] = *(const raw_t*)(a.vbuf + off);
+        }
       }
     };
     auto issue_to = [&](int tile, raw_t (&kd)[NLD], raw_t (&vd)[NLD]) { issue_from(tile, myidx, n, kd, vd); };
@@ -328,6 +337,9 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
     }
     }
   }
+  };
+  const bool nt = a.plan ? a.plan[3] >= a.nt_min_keys : a.nt_min_keys == 0;
+  if (nt) key_loop(std::true_type{}); else key_loop(std::false_type{});
 
   // split partials: plain stores for the merge kernel; write-through (sc1) through a buffer descriptor when this
   // kernel merges them itself (a.fuse_groups > 0) - written through, they need no release fence before the arrival

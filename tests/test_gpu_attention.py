@@ -214,7 +214,8 @@ def test_decode_plan_is_exact_and_changes_nothing(nat):
                       if l % chunk and ((l % chunk) * 4 - 1) // chunk == cls]
     n, nb = pl[0], len(lens)
     assert n == len(want_full) + len(want_tail) and pl[1] == chunk
-    assert pl[2] == n and pl[3] == 0, "word 2: the items the lengths need (= listed: no overflow)"
+    assert pl[2] == n, "word 2: the items the lengths need (= listed: no overflow)"
+    assert pl[3] == sum(lens), "word 3: the keys the step gathers per kv head"
     # slot0[b] = first partial slot of request b: the exclusive scan of the requests' split counts
     nsplit = [-(-l // chunk) for l in lens]
     assert pl[4:4 + nb] == [sum(nsplit[:b]) for b in range(nb)]
@@ -760,6 +761,7 @@ def test_decode_plan_fuzz_planned_equals_static_bit_for_bit(nat, seed):
             nat.decode_plan(plan, s_, max_len, chunk, slots, groups)
             host = plan.cpu()
             assert int(host[0]) == int(host[2]) == int(nsplit.sum()) <= slots and int(host[1]) == chunk
+            assert int(host[3]) == int(lens.sum())
             assert torch.equal(host[4:4 + bs].long(), torch.cumsum(nsplit, 0) - nsplit)
             for rep in range(3 if groups else 1):
                 ws2.fill_(0x7f)                                # stale partials of "another layer"
@@ -776,6 +778,48 @@ def test_decode_plan_fuzz_planned_equals_static_bit_for_bit(nat, seed):
     live = [r for r in rows if int(lens[r]) > 0]
     assert_close(o_plan[live], ref[live], torch.bfloat16, what=f"decode fuzz seed {seed}")
     assert float(o_plan[rows[1]].float().abs().max()) == 0.0, "an empty row is left untouched"
+
+
+@pytest.mark.parametrize("kv", ["same", "fp8"])
+@pytest.mark.parametrize("Hq,Hkv,D", [(8, 1, 128), (32, 8, 128), (24, 4, 64), (6, 2, 64)])
+def test_decode_streaming_gathers_change_no_bit(nat, kv, Hq, Hkv, D):
+    """Non-temporal K/V gathers (chosen per launch from the plan's key count against sp_debug_set("decode_nt_min_mb")):
+    the same loop with another cache policy on its loads - always, never and the default give the same bits, in both
+    forms of the kernel (a wave per kv head / the waves split one head's keys) and on a byte pool; the clamp of a
+    device-side length above max_seq_len counts the clamped length."""
+    g = torch.Generator().manual_seed(Hq + 7 * Hkv)
+    bs, chunk, max_len = 40, 128, 1500
+    lens = torch.randint(1, 1200, (bs,), generator=g)
+    lens[:3] = torch.tensor([1500, 1, 129])
+    p = paged_problem(500 + Hq, bs, Hq, Hkv, D, lens.tolist(), torch.bfloat16, DEV)
+    kb, vb, kw = p["k_buffer"], p["v_buffer"], {}
+    if kv == "fp8":
+        kb = kb.to(torch.float8_e5m2).view(torch.uint8)
+        vb = vb.to(torch.float8_e5m2).view(torch.uint8)
+        kw = dict(k_scale=1.0, v_scale=1.0)
+    slots = nat.decode_plan_slots(bs, max_len, chunk, kv_tokens=int(lens.sum()))
+    ws = torch.empty(nat.decode_workspace_bytes(bs, Hq, D, max_len, chunk, slots), dtype=torch.uint8, device=DEV)
+    plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, slots) // 4, dtype=torch.int32, device=DEV)
+    nat.decode_plan(plan, p["seq_lens"], max_len, chunk, slots)
+    assert int(plan[3]) == int(lens.sum())
+    outs = {}
+    try:
+        for name, mb in (("default", -2), ("always", 0), ("never", -1), ("1 MB", 1)):
+            nat.debug_set("decode_nt_min_mb", mb)
+            o = torch.zeros_like(p["q"])
+            nat.decode_attention(o, p["q"], kb, vb, p["req_to_token"], p["req_pool_indices"], p["seq_lens"], 0.1, 0.0,
+                                 max_len, chunk, ws, None, plan, max_slots=slots, **kw)
+            outs[name] = o
+    finally:
+        nat.debug_set("decode_nt_min_mb", -2)
+    assert torch.isfinite(outs["always"].float()).all()
+    for name in ("always", "never", "1 MB"):
+        assert torch.equal(outs[name], outs["default"]), name
+    if kv == "same":
+        check_decode(outs["always"], p, 0.1, torch.bfloat16, "streaming gathers")
+    # a plan built with a smaller max_seq_len than the device-side lengths counts the CLAMPED keys
+    nat.decode_plan(plan, p["seq_lens"], 100, chunk, slots)
+    assert int(plan[3]) == int(lens.clamp(max=100).sum())
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
