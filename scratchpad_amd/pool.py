@@ -6,10 +6,10 @@ slot 0 is the reserved dummy slot for padded rows) with the bookkeeping re-desig
 are rings (host ring for request rows, device ring for KV slots) instead of lists that are rebuilt
 on every alloc/free.
 
-MI355X layout: K and V each live in ONE allocation [layers, P+1, Hkv, D] (token-major, NHD);
-``get_key_buffer(l)`` is a view of layer l, so addresses and strides are what the reference's
-per-layer tensors would have, while a 288 GB HBM pool is a single contiguous arena (an interleaved
-K/V arena is an option, measured and not the default: MHATokenToKVPool.interleave_kv).
+MI355X layout: the whole pool is ONE allocation [layers, P+1, 2, Hkv, D] (token-major; a token's K and V
+rows of a layer adjacent - MHATokenToKVPool.interleave_kv, the default since the end of round 4; the
+other layout is one arena [layers, P+1, Hkv, D] per side).  ``get_key_buffer(l)`` / ``get_value_buffer(l)``
+are views of layer l with the reference's shape [P+1, Hkv, D] (NHD) and a token stride the kernels take.
 """
 import abc
 import os
@@ -283,14 +283,16 @@ class MHATokenToKVPool(KVCache):
         self.layer_transfer_counter = None
         self.capture_mode = False
 
-    # Default: K and V each in ONE arena [layers, P+1, Hkv, D] (memory/pool.py:295-318 allocates one tensor per layer
-    # and side).  SP_KV_INTERLEAVE=1: one arena [layers, P+1, 2, Hkv, D] - a token's K row and V row of a layer adjacent
-    # (one 4 KiB run at Llama-3-8B's 8 KV heads, 512 B per rank at 70B / TP 8), k_buffer[l] / v_buffer[l] its two
-    # strided views of the reference's shape [P+1, Hkv, D]; every kernel takes the token stride, so nothing else
-    # changes.  Measured in round 4 and NOT the default: in the model (73 GB pool) the headline decode attention is
-    # 3 % slower interleaved (0.399 / 0.408 ms vs 0.386 / 0.395 per layer, two runs each), equal at ctx 128 and at the
-    # 70B rank shape; the stand-alone kernel on a 2 GB pool read +1 % / +6 % (profiles/r04_decode_variants.txt).
-    interleave_kv = os.environ.get("SP_KV_INTERLEAVE", "0") == "1"
+    # Default: ONE arena [layers, P+1, 2, Hkv, D] - a token's K row and V row of a layer adjacent (one 4 KiB run at
+    # Llama-3-8B's 8 KV heads, 512 B per rank at 70B / TP 8); k_buffer[l] / v_buffer[l] are its two strided views of the
+    # reference's shape [P+1, Hkv, D] (memory/pool.py:295-318 allocates one tensor per layer and side); every kernel takes
+    # the token stride, so nothing else changes.  SP_KV_INTERLEAVE=0: K and V each in one arena [layers, P+1, Hkv, D].
+    # Measured twice in round 4 (profiles/r04_decode_variants.txt sections 1 and 7e): while the decode kernel's gathers
+    # were plain loads the interleaved arena was 3 % SLOWER in the model at the headline; with non-temporal gathers
+    # (the stream no longer thrashes the caches, DRAM locality is what is left) it is faster everywhere it matters -
+    # headline +1.1 - 1.7 % tokens/s (attention 0.385 -> 0.372 ms per layer), ctx 1024 +1.3 - 1.6 %, ctx 4096 +1.3 %,
+    # bs 32 / 128 and the fp8 pool +1.1 - 1.2 %; bs 8, the 70B rank shape and the TTFT pass equal.
+    interleave_kv = os.environ.get("SP_KV_INTERLEAVE", "1") != "0"
 
     def _create_buffers(self):
         rows = self.size + self.page_size

@@ -9,11 +9,11 @@ if [ "$ONLY" = "all" ]; then
 timeout -k 10 300 python -m pytest tests/test_gpu_plan_overflow.py tests/test_gpu_llama.py -x -q -m gpu > $OUT/tests.log 2>&1 || { tail -40 $OUT/tests.log; exit 1; }
 tail -2 $OUT/tests.log
 fi
-bash tools/pmc_decode.sh headline "llama3-8b|bs256|ctxuniform|kvauto" "--chunks 768" nofuse > $OUT/pmc_headline.log 2>&1 &&
-bash tools/pmc_decode.sh hkv1 "llama3-70b-tp8-rank|bs128|ctxuniform|kvauto" "--bs 128 --Hq 8 --Hkv 1 --chunks 768" nofuse > $OUT/pmc_hkv1.log 2>&1 &&
-bash tools/pmc_decode.sh ctx128 "llama3-8b|bs256|ctx128|kvauto" "--ctx 128 --chunks 128" nofuse > $OUT/pmc_ctx128.log 2>&1 &&
-bash tools/pmc_decode.sh bs32 "llama3-8b|bs32|ctx1024|kvauto" "--bs 32 --ctx 1024 --chunks 256" nofuse > $OUT/pmc_bs32.log 2>&1 &&
-bash tools/pmc_decode.sh fp8 "llama3-8b|bs256|ctxuniform|kvfp8_e5m2" "--kv fp8 --chunks 768" nofuse > $OUT/pmc_fp8.log 2>&1 || { tail -5 $OUT/pmc_*.log; exit 1; }
+bash tools/pmc_decode.sh headline "llama3-8b|bs256|ctxuniform|kvauto" "--chunks 768 --interleave" nofuse > $OUT/pmc_headline.log 2>&1 &&
+bash tools/pmc_decode.sh hkv1 "llama3-70b-tp8-rank|bs128|ctxuniform|kvauto" "--bs 128 --Hq 8 --Hkv 1 --chunks 768 --interleave" nofuse > $OUT/pmc_hkv1.log 2>&1 &&
+bash tools/pmc_decode.sh ctx128 "llama3-8b|bs256|ctx128|kvauto" "--ctx 128 --chunks 128 --interleave" nofuse > $OUT/pmc_ctx128.log 2>&1 &&
+bash tools/pmc_decode.sh bs32 "llama3-8b|bs32|ctx1024|kvauto" "--bs 32 --ctx 1024 --chunks 256 --interleave" nofuse > $OUT/pmc_bs32.log 2>&1 &&
+bash tools/pmc_decode.sh fp8 "llama3-8b|bs256|ctxuniform|kvfp8_e5m2" "--kv fp8 --chunks 768 --interleave" nofuse > $OUT/pmc_fp8.log 2>&1 || { tail -5 $OUT/pmc_*.log; exit 1; }
 for n in headline hkv1 ctx128 bs32 fp8; do tail -1 $OUT/pmc_$n.log | cut -c1-400; done
 [ "$ONLY" = "pmc" ] && exit 0
 T=$GRAFT_REPO_ROOT/tools/bench_decode_attn.py
