@@ -204,7 +204,7 @@ def populate_batch(mr, ctx, gen):
     perm = torch.randperm(alloc.size, generator=gen) + 1
     alloc.free_slots = perm.to(torch.int64).to(dev)
     reqs = [Req(rid=str(i), origin_input_ids=[]) for i in range(bs)]
-    batch = ScheduleBatch(reqs, mr.req_to_token_pool, alloc, dev)
+    batch = ScheduleBatch(reqs, mr.req_to_token_pool, alloc, device=dev)
     rows = batch.alloc_req_slots(bs)
     batch.req_pool_indices = torch.tensor(rows, dtype=torch.int64, device=dev)
     batch.seq_lens = ctx.to(torch.int64).to(dev)
@@ -405,8 +405,8 @@ def prefill_passes(args, mr, worker, rank, bs, warm, timed, profile_attention=Fa
         mr.token_to_kv_pool_allocator.clear()
         prefix_slots = None
         if args.prefix:     # a radix-cache hit: the prefix KV is already in the pool (computed once)
-            pre = ScheduleBatch([Req("prefix", prefix_ids)], mr.req_to_token_pool,
-                                mr.token_to_kv_pool_allocator, dev)
+            pre = ScheduleBatch([Req("prefix", "", prefix_ids, None)], mr.req_to_token_pool,
+                                mr.token_to_kv_pool_allocator, device=dev)
             pre.prepare_for_extend()
             worker.forward_batch_generation(pre.get_model_worker_batch())
             prefix_slots = pre.out_cache_loc.clone()
@@ -415,8 +415,8 @@ def prefill_passes(args, mr, worker, rank, bs, warm, timed, profile_attention=Fa
         t0 = time.perf_counter()
         ttft = [0.0] * bs
         for ids in batches:
-            reqs = [Req(str(i), prefix_ids + prompts[i], prefix_indices=prefix_slots) for i in ids]
-            sb = ScheduleBatch(reqs, mr.req_to_token_pool, mr.token_to_kv_pool_allocator, dev)
+            reqs = [Req(str(i), "", prefix_ids + prompts[i], None, prefix_indices=prefix_slots) for i in ids]
+            sb = ScheduleBatch(reqs, mr.req_to_token_pool, mr.token_to_kv_pool_allocator, device=dev)
             sb.prepare_for_extend()
             _, nxt = worker.forward_batch_generation(sb.get_model_worker_batch())
             nxt.cpu()                       # first token delivered to the host
@@ -560,7 +560,7 @@ def serve_main(args, rank, local_rank, world):
         tree.reset()
         r2t.clear()
         alloc.clear()
-        reqs = [Req(str(i), list(prompts[i]), sampling_params=sampling) for i in range(n_req)]
+        reqs = [Req(str(i), "", list(prompts[i]), sampling) for i in range(n_req)]
         waiting = list(range(n_req))
         running = None
         first_t, last_t, itl = [None] * n_req, [None] * n_req, []
@@ -586,7 +586,7 @@ def serve_main(args, rank, local_rank, world):
                 budget -= r.extend_input_len
                 reserved += out_lens[admit[-1]] - 1      # one slot per decode step of this request
             if admit:
-                nb = ScheduleBatch([reqs[i] for i in admit], r2t, alloc, dev, tree_cache=tree)
+                nb = ScheduleBatch([reqs[i] for i in admit], r2t, alloc, device=dev, tree_cache=tree)
                 nb.prepare_for_extend()
                 if args.sample:
                     nb.sampling_info = SamplingBatchInfo.from_schedule_batch(nb, cfg.vocab_size)

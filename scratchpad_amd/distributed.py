@@ -8,10 +8,33 @@ initialize_model_parallel (881-997) - and distributed/communication_op.py:9-33.
 ``backend="nccl"`` IS RCCL on ROCm; ``backend="gloo"`` runs the same code on CPU (tests).
 PP groups are not built: no reference model uses them.
 """
+import contextlib
+from dataclasses import dataclass
 from typing import Optional
 
 import torch
 import torch.distributed as dist
+
+
+@dataclass
+class GraphCaptureContext:
+    """parallel_state.py:38-40: the stream a graph is captured on."""
+    stream: "torch.cuda.Stream"
+
+
+@contextlib.contextmanager
+def _capture_on(ca_comm, graph_capture_context: Optional[GraphCaptureContext]):
+    """parallel_state.py:257-302 without pynccl: make the capture stream current (after everything already enqueued)
+    and, when the custom all-reduce slot is filled, enter its ``capture()`` so that launches inside the graph
+    register their buffers once (custom_all_reduce.py)."""
+    if graph_capture_context is None:
+        graph_capture_context = GraphCaptureContext(torch.cuda.Stream())
+    stream = graph_capture_context.stream
+    curr = torch.cuda.current_stream()
+    if curr != stream:
+        stream.wait_stream(curr)
+    with torch.cuda.stream(stream), (ca_comm.capture() if ca_comm is not None else contextlib.nullcontext()):
+        yield graph_capture_context
 
 
 class GroupCoordinator:
@@ -45,6 +68,11 @@ class GroupCoordinator:
     @property
     def is_first_rank(self):
         return self.rank == self.first_rank
+
+    def graph_capture(self, graph_capture_context: Optional[GraphCaptureContext] = None):
+        """Context manager around graph capture (parallel_state.py:257-302; entered by the graph runner,
+        cuda_graph_runner.py:296): yields the GraphCaptureContext whose stream the capture runs on."""
+        return _capture_on(self.ca_comm, graph_capture_context)
 
     def all_reduce(self, input_: torch.Tensor) -> torch.Tensor:
         """SUM all-reduce; applied in place or out of place - always use the return value."""
@@ -143,6 +171,9 @@ class _SingleRankGroup:
     rank_in_group = 0
     ca_comm = None
 
+    def graph_capture(self, graph_capture_context: Optional[GraphCaptureContext] = None):
+        return _capture_on(None, graph_capture_context)
+
     def all_reduce(self, input_):
         return input_
 
@@ -174,6 +205,11 @@ def destroy_model_parallel():
 def get_tp_group():
     assert _TP is not None, "tensor model parallel group is not initialized"
     return _TP
+
+
+def graph_capture():
+    """parallel_state.py:852-870 (TP group only: no PP groups are built)."""
+    return get_tp_group().graph_capture()
 
 
 def get_tensor_model_parallel_world_size() -> int:

@@ -75,9 +75,11 @@ class ModelWorkerBatch:
     input_ids: torch.Tensor
     req_pool_indices: torch.Tensor
     seq_lens: torch.Tensor
-    out_cache_loc: torch.Tensor
-    seq_lens_sum: int
+    # (the reference's order; everything from here on is required upstream and passed by keyword there - here the
+    # defaults let a caller leave out what the path does not read)
     seq_lens_cpu: Optional[torch.Tensor] = None
+    out_cache_loc: torch.Tensor = None
+    seq_lens_sum: int = None
     return_logprob: bool = False
     top_logprobs_nums: Optional[List[int]] = None
     token_ids_logprobs: Optional[List[List[int]]] = None
@@ -113,7 +115,8 @@ class ModelWorkerBatch:
 
 @dataclass
 class ForwardBatch:
-    """model_executor/forward_info.py:84-177."""
+    """model_executor/forward_info.py:84-177: the reference's fields in the reference's order
+    (tests/test_api_surface.py pins names, order and defaults against tests/golden/api_surface.json)."""
     forward_mode: ForwardMode
     batch_size: int
     input_ids: torch.Tensor
@@ -122,10 +125,14 @@ class ForwardBatch:
     out_cache_loc: torch.Tensor
     seq_lens_sum: int
     seq_lens_cpu: Optional[torch.Tensor] = None
-    seq_lens_max_hint: Optional[int] = None          # advisory, see ModelWorkerBatch
     return_logprob: bool = False
     top_logprobs_nums: Optional[List[int]] = None
     token_ids_logprobs: Optional[List[List[int]]] = None
+    # logprob post-processing switches (read by the logits processor: llama.py compute_logprobs)
+    temp_scaled_logprobs: bool = False
+    temperature: torch.Tensor = None
+    top_p_normalized_logprobs: bool = False
+    top_p: torch.Tensor = None
     positions: torch.Tensor = None
     extend_num_tokens: Optional[int] = None
     extend_seq_lens: Optional[torch.Tensor] = None
@@ -146,20 +153,33 @@ class ForwardBatch:
     req_to_token_pool: Any = None
     token_to_kv_pool: Any = None
     attn_backend: Any = None
+    # DP attention (inert here: the reference's dp_size flag is inert too)
     global_num_tokens_cpu: Optional[List[int]] = None
     global_num_tokens_gpu: Optional[torch.Tensor] = None
+    global_num_tokens_for_logprob_cpu: Optional[List[int]] = None
+    global_num_tokens_for_logprob_gpu: Optional[torch.Tensor] = None
+    dp_local_start_pos: Optional[torch.Tensor] = None
+    dp_local_num_tokens: Optional[torch.Tensor] = None
+    gathered_buffer: Optional[torch.Tensor] = None
     can_run_dp_cuda_graph: bool = False
     spec_info: Any = None
     spec_algorithm: Any = None
     capture_hidden_mode: CaptureHiddenMode = None
     padded_static_len: int = -1
     mrope_positions: torch.Tensor = None
-    encoder_states: Optional[torch.Tensor] = None
+    # ---- not in the reference (kept behind its fields)
+    seq_lens_max_hint: Optional[int] = None          # advisory, see ModelWorkerBatch
+    encoder_states: Optional[torch.Tensor] = None    # see ModelWorkerBatch
 
     @classmethod
     def init_new(cls, batch: ModelWorkerBatch, model_runner) -> "ForwardBatch":
         """forward_info.py:179-287 (decode: positions = clamp(seq_lens - 1); extend: positions and
-        extend_start_loc from the HIP twin of compute_position_triton)."""
+        extend_start_loc from the HIP twin of compute_position_triton).
+
+        Provenance: this is glue whose statement order is dictated by the field contract - which ModelWorkerBatch
+        field lands in which ForwardBatch field, and what is derived when - so it follows the reference's init_new
+        assignment by assignment, minus its DP-attention buffers, mrope and toppings branches (out of scope), and
+        with the two positions helpers replaced by the HIP entry points."""
         device = model_runner.device
         ret = cls(
             forward_mode=batch.forward_mode, batch_size=len(batch.seq_lens), input_ids=batch.input_ids,
@@ -178,6 +198,8 @@ class ForwardBatch:
             encoder_states=batch.encoder_states,
             extend_input_logprob_token_ids_gpu=(None if batch.extend_input_logprob_token_ids is None else
                                                 batch.extend_input_logprob_token_ids.to(device, non_blocking=True)))
+        if batch.global_num_tokens is not None:
+            raise NotImplementedError("DP attention (global_num_tokens) is out of scope of this path")
         if ret.forward_mode.is_idle():
             ret.positions = torch.empty((0,), device=device)
             return ret
@@ -202,6 +224,24 @@ class ForwardBatch:
             ret.extend_seq_lens_cpu = batch.extend_seq_lens
             ret.extend_logprob_start_lens_cpu = batch.extend_logprob_start_lens
         return ret
+
+    def merge_mm_inputs(self):
+        """forward_info.py:289-311: the batch's multimodal inputs folded into the first one (None: text only)"""
+        have = [x for x in (self.mm_inputs or []) if x is not None]
+        if not have:
+            return None
+        for other in have[1:]:
+            have[0].merge(other)
+        return have[0]
+
+    def contains_image_inputs(self) -> bool:
+        return any(x is not None and x.contains_image_inputs() for x in (self.mm_inputs or []))
+
+    def contains_audio_inputs(self) -> bool:
+        return any(x is not None and x.contains_audio_inputs() for x in (self.mm_inputs or []))
+
+    def contains_mm_inputs(self) -> bool:
+        return self.contains_audio_inputs() or self.contains_image_inputs()
 
 
 def compute_position(extend_prefix_lens: torch.Tensor, extend_seq_lens: torch.Tensor,

@@ -311,9 +311,9 @@ class LogitsProcessor(nn.Module):
         # logits_processor.py:292-306, 432-460: optional temperature scaling / top-p normalisation of the input logprobs
         info = fb.sampling_info
         lens = torch.tensor(pruned_lens, device=dev)
-        if getattr(fb, "temp_scaled_logprobs", False) and info is not None:
+        if fb.temp_scaled_logprobs and info is not None:
             input_logits = input_logits / torch.repeat_interleave(info.temperatures.view(-1), lens).view(-1, 1)
-        if getattr(fb, "top_p_normalized_logprobs", False) and info is not None and bool((info.top_ps != 1.0).any()):
+        if fb.top_p_normalized_logprobs and info is not None and bool((info.top_ps != 1.0).any()):
             from .sampler import top_p_normalize_probs
             probs = torch.softmax(input_logits, dim=-1)
             logprobs = torch.log(top_p_normalize_probs(probs, torch.repeat_interleave(info.top_ps, lens)))

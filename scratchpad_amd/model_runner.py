@@ -301,6 +301,7 @@ class HipGraphRunner:
         self.encoder_lens = (torch.zeros((self.max_bs,), dtype=torch.int32, device=dev)
                              if self.is_encoder_decoder else None)
         self.pool = None
+        self.stream = None
         self.capture()
 
     def can_run(self, forward_batch: ForwardBatch) -> bool:
@@ -311,12 +312,11 @@ class HipGraphRunner:
         model = self.model_runner.model
         if self.is_encoder_decoder:
             model.capture_mode = True      # cross-attention is always part of the captured step
-        import contextlib
-        ca = getattr(dist_.get_tp_group(), "ca_comm", None)
         try:
-            # captured steps keep the library all-reduce (parallel_state.py:293-302 toggles its
-            # communicators the same way under graph_capture)
-            with (ca.capture() if ca is not None else contextlib.nullcontext()):
+            # cuda_graph_runner.py:295-329: capture on the group's capture stream; graph_capture() also enters the
+            # custom all-reduce's capture() when that slot is filled (parallel_state.py:257-302)
+            with dist_.graph_capture() as graph_capture_context:
+                self.stream = graph_capture_context.stream
                 for bs in reversed(self.capture_bs):
                     graph, out = self.capture_one_batch_size(bs)
                     self.graphs[bs] = graph
@@ -360,7 +360,7 @@ class HipGraphRunner:
         # of another thread during a capture is an error ("operation not permitted when stream is
         # capturing") and takes the process group down - found by
         # tests/test_gpu_tensor_parallel.py::test_rccl_all_reduce_inside_a_hip_graph_single_rank
-        with torch.cuda.graph(graph, pool=self.pool, capture_error_mode="thread_local"):
+        with torch.cuda.graph(graph, pool=self.pool, stream=self.stream, capture_error_mode="thread_local"):
             out = run_once()
         self.pool = graph.pool()
         return graph, out

@@ -101,9 +101,18 @@ class ReqToTokenPool:
         self._journal = []
 
     def write(self, indices, values) -> None:
-        self.req_to_token[indices] = values
+        """one of the two below, by ``use_records`` (the reference re-points the attribute in __init__, pool.py:28-31)"""
         if self.use_records:
-            self._journal.append((indices, values))
+            self.write_with_records(indices, values)
+        else:
+            self.write_without_records(indices, values)
+
+    def write_without_records(self, indices, values) -> None:
+        self.req_to_token[indices] = values
+
+    def write_with_records(self, indices, values) -> None:
+        self.req_to_token[indices] = values
+        self._journal.append((indices, values))
 
     def get_write_records(self) -> List[Tuple]:
         out, self._journal = self._journal, []
@@ -262,7 +271,8 @@ class TokenToKVPoolAllocator:
 
 
 class MHATokenToKVPool(KVCache):
-    """memory/pool.py:258-424 (16/32-bit float pools; the fp8-as-uint8 branch is not built)."""
+    """memory/pool.py:258-424: fp32 / fp16 / bf16 pools, and the fp8 e5m2 pool stored as uint8 (274-280, 401-412;
+    DESIGN 4.7); e4m3 raises."""
 
     def __init__(self, size: int, page_size: int, dtype: torch.dtype, head_num: int, head_dim: int,
                  layer_num: int, device: str, enable_memory_saver: bool = False):
@@ -317,12 +327,17 @@ class MHATokenToKVPool(KVCache):
                 self._v_arena.numel() * self._v_arena.element_size())
 
     def get_contiguous_buf_infos(self):
-        """pool.py:329-346: (data pointers, byte lengths, bytes per token) of the K buffers then the V buffers.  With
-        the interleaved arena a buffer is a strided view: its byte length is the span it covers and an item is one
-        token's row at stride 2 x that (the transfer engine upstream copies [ptr + token * item_stride, + item_len))."""
-        bufs = self.k_buffer + self.v_buffer
-        span = lambda b: (b.shape[0] - 1) * b.stride(0) * b.element_size() + b[0].nbytes
-        return ([b.data_ptr() for b in bufs], [span(b) for b in bufs], [b[0].nbytes for b in bufs])
+        """pool.py:329-346: (data pointers, byte lengths, bytes per token) of buffers in which token ``i`` lives at
+        ``ptr + i * item_len`` - the contract the transfer engines upstream copy by.  Separate arenas: the K buffers
+        then the V buffers, as the reference lists them.  Interleaved arena (the default): ONE buffer per layer whose
+        item is the token's K row followed by its V row (2 x Hkv x D elements) - never overlapping K / V regions with
+        an item length that is not the stride."""
+        if self.interleave_kv:
+            bufs = [self._kv_arena[i] for i in range(self.layer_num)]
+        else:
+            bufs = self.k_buffer + self.v_buffer
+        assert all(b.is_contiguous() for b in bufs)
+        return ([b.data_ptr() for b in bufs], [b.nbytes for b in bufs], [b[0].nbytes for b in bufs])
 
     def get_flat_data(self, indices):
         return torch.stack([self._k_arena[:, indices], self._v_arena[:, indices]])

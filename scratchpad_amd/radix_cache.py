@@ -334,10 +334,15 @@ class ChunkCacheEntry:
 class ChunkCache(BasePrefixCache):
     """memory/chunk_cache.py:16-83: no sharing; only remembers a chunked request's own slots."""
 
-    def __init__(self, req_to_token_pool: ReqToTokenPool, token_to_kv_pool_allocator: TokenToKVPoolAllocator):
+    def __init__(self, req_to_token_pool: ReqToTokenPool, token_to_kv_pool: Optional[TokenToKVPoolAllocator] = None,
+                 token_to_kv_pool_allocator: Optional[TokenToKVPoolAllocator] = None):
+        # the slot allocator under either name: chunk_cache.py:17-24 declares `token_to_kv_pool`, the reference's
+        # own scheduler passes `token_to_kv_pool_allocator=` (scheduler.py:342-345)
         self.disable = True
         self.req_to_token_pool = req_to_token_pool
-        self.token_to_kv_pool_allocator = token_to_kv_pool_allocator
+        self.token_to_kv_pool_allocator = token_to_kv_pool_allocator if token_to_kv_pool_allocator is not None else token_to_kv_pool
+        if self.token_to_kv_pool_allocator is None:
+            raise TypeError("ChunkCache needs the KV slot allocator (token_to_kv_pool / token_to_kv_pool_allocator)")
         self.reset()
 
     def reset(self):

@@ -9,8 +9,9 @@ req_to_token[req, seq_len-1] = slot), ``mix_with_running`` (1073-1101) and
 ``retract_decode`` (1103-1211) and ``filter_batch`` / ``merge_batch`` (1309-1397).  Admission
 policy, grammars, penalizers and detokenisation stay with the reference's scheduler (out of scope).
 """
-from dataclasses import dataclass, field
-from typing import List, Optional
+import threading
+from dataclasses import dataclass
+from typing import Any, List, Optional, Set, Tuple, Union
 
 import torch
 
@@ -19,71 +20,200 @@ from .forward_info import CaptureHiddenMode, ForwardMode, ModelWorkerBatch
 from .pool import ReqToTokenPool, TokenToKVPoolAllocator
 from .radix_cache import BasePrefixCache, ChunkCache
 
-_bid = 0
+bid = 0
 
 
-@dataclass
+class BaseFinishReason:
+    """scheduler/schedule_batch.py:33-90: why a request stopped (``to_json`` is what the detokenizer side reads)."""
+    type = "base"
+
+    def __init__(self, is_error: bool = False):
+        self.is_error = is_error
+
+    def _payload(self) -> dict:
+        return {}
+
+    def to_json(self):
+        return {"type": self.type, **self._payload()}
+
+
+class FINISH_MATCHED_TOKEN(BaseFinishReason):
+    type = "stop"
+
+    def __init__(self, matched: Union[int, List[int]]):
+        super().__init__()
+        self.matched = matched
+
+    def _payload(self):
+        return {"matched": self.matched}
+
+
+class FINISH_MATCHED_STR(FINISH_MATCHED_TOKEN):
+    def __init__(self, matched: str):
+        super().__init__(matched)
+
+
+class FINISH_LENGTH(BaseFinishReason):
+    type = "length"
+
+    def __init__(self, length: int):
+        super().__init__()
+        self.length = length
+
+    def _payload(self):
+        return {"length": self.length}
+
+
+class FINISH_ABORT(BaseFinishReason):
+    type = "abort"
+
+    def __init__(self, message="Unknown error", status_code=None, err_type=None):
+        super().__init__(is_error=True)
+        self.message, self.status_code, self.err_type = message, status_code, err_type
+
+    def _payload(self):
+        return {"message": self.message, "status_code": self.status_code, "err_type": self.err_type}
+
+
 class Req:
-    """The fields of scheduler/schedule_batch.py:Req that the producers below read."""
-    rid: str
-    origin_input_ids: List[int]
-    output_ids: List[int] = field(default_factory=list)
-    prefix_indices: Optional[torch.Tensor] = None   # cached KV slots (radix-cache hit), int
-    req_pool_idx: Optional[int] = None
-    last_node: object = None                         # prefix-cache node the request holds a lock on
-    fill_ids_override: Optional[List[int]] = None    # chunked prefill: the tokens of this round
-    extend_input_len_override: Optional[int] = None  # set by mix_with_running (1 for a running request)
-    finished_reason: object = None
-    sampling_params: object = None                   # sampler.SamplingParams (None = greedy)
-    is_retracted: bool = False
-    # encoder-decoder models: the first num_image_tokens ids of origin_input_ids are the image pad
-    # ids (mllama.py pad_input_ids 803-816; MultimodalInputs.num_image_tokens)
-    num_image_tokens: Optional[int] = None
-    # MultimodalInputs of the request (mm_items with pixel_values / aspect_ratio_id / aspect_ratio_mask)
-    multimodal_inputs: object = None
-    # log-prob requests (schedule_batch.py:296-298, 369-387): logprob_start_len is an index into origin_input_ids;
-    # extend_logprob_start_len is the same, relative to this round's extend part (set by prepare_for_extend)
-    return_logprob: bool = False
-    logprob_start_len: int = 0
-    top_logprobs_num: int = 0
-    token_ids_logprob: Optional[List[int]] = None
-    extend_logprob_start_len: int = 0
+    """scheduler/schedule_batch.py:287-593, the constructor form and the attributes the producers below (and the
+    reference's scheduler around them) read.  Parameters up to ``eos_token_ids`` are the reference's, in its order;
+    the keyword-only ones behind them lay a request out directly (tests, benches)."""
+
+    def __init__(self, rid: str, origin_input_text: str = "", origin_input_ids: Tuple[int] = (), sampling_params=None,
+                 return_logprob: bool = False, top_logprobs_num: int = 0, token_ids_logprob: Optional[List[int]] = None,
+                 stream: bool = False, origin_input_ids_unpadded: Optional[Tuple[int]] = None,
+                 topping_path: Optional[str] = None, input_embeds=None, session_id: Optional[str] = None,
+                 custom_logit_processor: Optional[str] = None, return_hidden_states: bool = False,
+                 eos_token_ids: Optional[Set[int]] = None, *, output_ids: Optional[List[int]] = None,
+                 prefix_indices=None, num_image_tokens: Optional[int] = None, multimodal_inputs=None,
+                 logprob_start_len: int = 0):
+        self.rid = rid
+        self.origin_input_text = origin_input_text
+        self.origin_input_ids = origin_input_ids
+        self.origin_input_ids_unpadded = origin_input_ids_unpadded if origin_input_ids_unpadded else origin_input_ids
+        self.output_ids: List[int] = [] if output_ids is None else output_ids
+        self.session_id, self.input_embeds = session_id, input_embeds
+        self.sampling_params = sampling_params           # sampler.SamplingParams; None = greedy
+        self.custom_logit_processor = custom_logit_processor
+        self.return_hidden_states = return_hidden_states
+        self.topping_path = topping_path
+        self.req_pool_idx: Optional[int] = None
+        # finishing (check_finished)
+        self.tokenizer = None
+        self.finished_reason = None
+        self.to_abort, self.to_abort_message = False, "Unknown error"
+        self.stream = stream
+        self.eos_token_ids = eos_token_ids
+        self.decoded_text = ""
+        self.grammar = None
+        # prefix-cache hand-off: cached KV slots (radix-cache hit) and the node the request holds a lock on
+        self.prefix_indices = [] if prefix_indices is None else prefix_indices
+        self.last_node = None
+        self.last_node_global = None
+        self.fill_ids_override: Optional[List[int]] = None       # chunked prefill: the tokens of this round
+        self.extend_input_len_override: Optional[int] = None    # pinned by the scheduler (1 for a running request)
+        self.is_chunked = 0
+        self.is_retracted = False
+        self.cached_tokens = self.already_computed = 0
+        # encoder-decoder models: the first num_image_tokens ids of origin_input_ids are the image pad ids
+        # (mllama.py pad_input_ids 803-816; MultimodalInputs.num_image_tokens)
+        self.num_image_tokens = num_image_tokens
+        self.multimodal_inputs = multimodal_inputs
+        # log-prob requests (schedule_batch.py:369-387): logprob_start_len is an index into origin_input_ids;
+        # extend_logprob_start_len is the same, relative to this round's extend part (set by prepare_for_extend)
+        self.return_logprob = return_logprob
+        self.logprob_start_len = logprob_start_len
+        self.top_logprobs_num = top_logprobs_num
+        self.token_ids_logprob = token_ids_logprob
+        self.extend_logprob_start_len = 0
+        self.temp_scaled_logprobs = self.top_p_normalized_logprobs = False
+
+    def __repr__(self):
+        return f"Req(rid={self.rid}, input_ids={self.origin_input_ids}, output_ids={self.output_ids})"
+
+    @property
+    def seqlen(self):
+        return len(self.origin_input_ids) + len(self.output_ids)
 
     @property
     def fill_ids(self) -> List[int]:
         if self.fill_ids_override is not None:
             return self.fill_ids_override
-        return self.origin_input_ids + self.output_ids
+        return list(self.origin_input_ids) + self.output_ids
 
     @fill_ids.setter
     def fill_ids(self, ids: Optional[List[int]]):
         self.fill_ids_override = ids
 
+    def extend_image_inputs(self, image_inputs):
+        if self.multimodal_inputs is None:
+            self.multimodal_inputs = image_inputs
+        else:
+            self.multimodal_inputs.merge(image_inputs)
+
     def finished(self) -> bool:
         return self.finished_reason is not None
 
-    def init_next_round_input(self, tree_cache: Optional[BasePrefixCache] = None):
-        """schedule_batch.py:472-510: look the prompt up in the prefix cache; at least one token
-        is always left to compute so the step produces logits."""
+    def adjust_max_prefix_ids(self):
+        """schedule_batch.py:494-511: a cached prefix always leaves one token to compute (the step must produce
+        logits), and may not swallow positions whose input logprobs are asked for."""
+        self.fill_ids_override = None
+        ids = self.fill_ids
+        limit = len(ids) - 1
+        if self.return_logprob:
+            limit = min(limit, self.logprob_start_len)
+        return ids[:max(limit, 0)]
+
+    def init_next_round_input(self, tree_cache: Optional[BasePrefixCache] = None, enable_hierarchical_cache=False):
+        """schedule_batch.py:472-492: look the prompt up in the prefix cache."""
         self.fill_ids_override = None
         self.extend_input_len_override = None
-        ids = self.origin_input_ids + self.output_ids
         if tree_cache is not None:
-            # adjust_max_prefix_ids, schedule_batch.py:494-510: a cached prefix may not swallow positions whose
-            # input logprobs are asked for (they need this round's hidden states)
-            limit = len(ids) - 1
-            if self.return_logprob:
-                limit = min(limit, self.logprob_start_len)
-            self.prefix_indices, self.last_node = tree_cache.match_prefix(rid=self.rid, key=ids[:max(limit, 0)])
+            if enable_hierarchical_cache:
+                raise NotImplementedError("hierarchical (host-backed) prefix cache: out of scope (SURVEY section 8)")
+            self.prefix_indices, self.last_node = tree_cache.match_prefix(rid=self.rid, key=self.adjust_max_prefix_ids())
+
+    def check_finished(self):
+        """schedule_batch.py:525-571: length, then stop tokens (sampling params / request / tokenizer), then stop strings."""
+        if self.finished():
+            return
+        if self.to_abort:
+            self.finished_reason = FINISH_ABORT(message=self.to_abort_message)
+            return
+        params = self.sampling_params
+        max_new = getattr(params, "max_new_tokens", None)
+        if max_new is not None and len(self.output_ids) >= max_new:
+            self.finished_reason = FINISH_LENGTH(length=max_new)
+            return
+        last = self.output_ids[-1]
+        if not getattr(params, "ignore_eos", False):
+            stops = set(getattr(params, "stop_token_ids", None) or ()) | set(self.eos_token_ids or ())
+            if self.tokenizer is not None:
+                stops.add(self.tokenizer.eos_token_id)
+                stops |= set(getattr(self.tokenizer, "additional_stop_token_ids", None) or ())
+            if last in stops:
+                self.finished_reason = FINISH_MATCHED_TOKEN(matched=last)
+                return
+        stop_strs = getattr(params, "stop_strs", None) or ()
+        if stop_strs:
+            tail = self.tokenizer.decode(self.output_ids[-(params.stop_str_max_len + 1):])
+            for s in stop_strs:
+                if s in tail or s in self.decoded_text:
+                    self.finished_reason = FINISH_MATCHED_STR(matched=s)
+                    return
 
     def reset_for_retract(self):
         """schedule_batch.py:573-584"""
-        self.prefix_indices = None
+        self.prefix_indices = []
         self.last_node = None
         self.fill_ids_override = None
+        self.extend_input_len_override = None
         self.req_pool_idx = None
         self.extend_logprob_start_len = 0
         self.is_retracted = True
+        self.is_chunked = 0
+        self.already_computed = 0
 
     @property
     def extend_input_len(self) -> int:
@@ -102,38 +232,92 @@ class Req:
         return 0 if self.prefix_indices is None else len(self.prefix_indices)
 
 
+@dataclass
 class ScheduleBatch:
-    def __init__(self, reqs: List[Req], req_to_token_pool: ReqToTokenPool,
-                 token_to_kv_pool_allocator: TokenToKVPoolAllocator, device: str,
-                 is_encoder_decoder: bool = False, tree_cache: Optional[BasePrefixCache] = None):
-        self.is_encoder_decoder = is_encoder_decoder
-        self.tree_cache = tree_cache
-        # None = every request greedy; sampler.SamplingBatchInfo.from_schedule_batch(batch, vocab) otherwise
-        self.sampling_info = None
-        self.encoder_cached = self.encoder_lens = self.encoder_lens_cpu = None
-        self.encoder_out_cache_loc = None
-        self.reqs = reqs
-        self.req_to_token_pool = req_to_token_pool
-        self.token_to_kv_pool_allocator = token_to_kv_pool_allocator
-        self.device = device
-        self.forward_mode: Optional[ForwardMode] = None
-        self.input_ids = self.req_pool_indices = self.seq_lens = self.out_cache_loc = None
-        self.output_ids = None
-        self.seq_lens_sum = 0
-        self.seq_lens_max = 0          # host-side upper bound of max(seq_lens): advisory (ModelWorkerBatch.seq_lens_max_hint)
-        self.extend_num_tokens = None
-        self.prefix_lens = self.extend_lens = None
-        # per-batch flags / per-request logprob requests the reference keeps on the batch
-        # (schedule_batch.py:618-640): carried through merge_batch / mix_with_running as it does
-        self.return_logprob = any(r.return_logprob for r in reqs)          # init_new, schedule_batch.py:693
-        self.extend_input_logprob_token_ids: Optional[torch.Tensor] = None
-        self.top_logprobs_nums: Optional[List[int]] = None
-        self.token_ids_logprobs: Optional[List[Optional[List[int]]]] = None
-        self.extend_logprob_start_lens: List[int] = []
-        self.has_stream = self.has_grammar = self.return_hidden_states = False
+    """scheduler/schedule_batch.py:595-680: the reference's fields in the reference's order (so its keyword and
+    positional constructions bind), then the two this build adds.  Fields that only feed out-of-scope subsystems
+    (DP attention, speculative decoding, custom logit processors) are inert."""
+    reqs: List[Req]
+    req_to_token_pool: ReqToTokenPool = None
+    token_to_kv_pool_allocator: TokenToKVPoolAllocator = None
+    tree_cache: BasePrefixCache = None
+    model_config: Any = None
+    forward_mode: ForwardMode = None
+    enable_overlap: bool = False
+    batch_is_full: bool = False
+    launch_done: Optional[threading.Event] = None
+    # None = every request greedy; sampler.SamplingBatchInfo.from_schedule_batch(batch, vocab) otherwise
+    sampling_info: Any = None
+    next_batch_sampling_info: Any = None
+    input_ids: torch.Tensor = None
+    input_embeds: torch.Tensor = None
+    req_pool_indices: torch.Tensor = None
+    seq_lens: torch.Tensor = None
+    out_cache_loc: torch.Tensor = None
+    output_ids: torch.Tensor = None
+    seq_lens_sum: int = None
+    global_num_tokens: Optional[List[int]] = None
+    global_num_tokens_for_logprob: Optional[List[int]] = None
+    can_run_dp_cuda_graph: bool = False
+    # per-batch flags / per-request logprob requests: carried through merge_batch / mix_with_running
+    return_logprob: bool = False
+    top_logprobs_nums: Optional[List[int]] = None
+    token_ids_logprobs: Optional[List[List[int]]] = None
+    temp_scaled_logprobs: bool = False
+    top_p_normalized_logprobs: bool = False
+    prefix_lens: List[int] = None
+    extend_lens: List[int] = None
+    extend_num_tokens: int = None
+    decoding_reqs: List[Req] = None
+    extend_logprob_start_lens: List[int] = None
+    extend_input_logprob_token_ids: Optional[torch.Tensor] = None
+    encoder_cached: Optional[List[bool]] = None
+    encoder_lens: Optional[torch.Tensor] = None
+    encoder_lens_cpu: Optional[List[int]] = None
+    encoder_out_cache_loc: Optional[torch.Tensor] = None
+    has_stream: bool = False
+    has_grammar: bool = False
+    device: str = "cuda"
+    spec_algorithm: Any = None
+    spec_info: Optional[Any] = None
+    enable_custom_logit_processor: bool = False
+    return_hidden_states: bool = False
+    # ---- not in the reference
+    # None: taken from model_config.is_encoder_decoder, as the reference reads it (schedule_batch.py:1274, 1334)
+    is_encoder_decoder: Optional[bool] = None
+    # host-side upper bound of max(seq_lens), kept like seq_lens_sum: advisory (ModelWorkerBatch.seq_lens_max_hint)
+    seq_lens_max: int = 0
+
+    def __post_init__(self):
+        if self.is_encoder_decoder is None:
+            self.is_encoder_decoder = bool(getattr(self.model_config, "is_encoder_decoder", False))
+        if self.seq_lens_sum is None:
+            self.seq_lens_sum = 0
+        if self.extend_logprob_start_lens is None:
+            self.extend_logprob_start_lens = []
+        # a batch built directly (tests, benches) gets the flag init_new derives, schedule_batch.py:693
+        self.return_logprob = self.return_logprob or any(r.return_logprob for r in self.reqs)
+
+    @classmethod
+    def init_new(cls, reqs: List[Req], req_to_token_pool: ReqToTokenPool,
+                 token_to_kv_pool_allocator: TokenToKVPoolAllocator, tree_cache: BasePrefixCache, model_config,
+                 enable_overlap: bool, spec_algorithm, enable_custom_logit_processor: bool = False):
+        """schedule_batch.py:682-709.  (The last flag has a default here only: the reference's own idle-batch call,
+        scheduler.py:1711-1719, leaves it out.)"""
+        return cls(reqs=reqs, req_to_token_pool=req_to_token_pool, token_to_kv_pool_allocator=token_to_kv_pool_allocator,
+                   tree_cache=tree_cache, model_config=model_config, enable_overlap=enable_overlap,
+                   return_logprob=any(r.return_logprob for r in reqs),
+                   has_stream=any(getattr(r, "stream", False) for r in reqs),
+                   has_grammar=any(getattr(r, "grammar", None) for r in reqs),
+                   device=req_to_token_pool.device, spec_algorithm=spec_algorithm,
+                   enable_custom_logit_processor=enable_custom_logit_processor,
+                   return_hidden_states=any(getattr(r, "return_hidden_states", False) for r in reqs))
 
     def batch_size(self):
         return len(self.reqs)
+
+    def is_empty(self):
+        return len(self.reqs) == 0
 
     def alloc_req_slots(self, num_reqs: int):
         idx = self.req_to_token_pool.alloc(num_reqs)
@@ -142,16 +326,18 @@ class ScheduleBatch:
                                "`--max-running-requests`.")
         return idx
 
-    def alloc_token_slots(self, num_tokens: int):
+    def alloc_token_slots(self, num_tokens: int, backup_state: bool = False):
+        """schedule_batch.py:728-752; ``backup_state``: also return the allocator's free list as it was before."""
         if self.tree_cache is not None and self.token_to_kv_pool_allocator.available_size() < num_tokens:
             self.tree_cache.evict(num_tokens)
+        state = self.token_to_kv_pool_allocator.backup_state() if backup_state else None
         out = self.token_to_kv_pool_allocator.alloc(num_tokens)
         if out is None:
             evictable = 0 if self.tree_cache is None else self.tree_cache.evictable_size()
             raise RuntimeError(f"Out of memory. Try to lower your batch size.\n"
                                f"Try to allocate {num_tokens} tokens.\n"
                                f"Avaliable tokens: {self.token_to_kv_pool_allocator.available_size() + evictable}\n")
-        return out
+        return (out, state) if backup_state else out
 
     def prepare_for_extend(self):
         self.forward_mode = ForwardMode.EXTEND
@@ -255,7 +441,7 @@ class ScheduleBatch:
         """schedule_batch.py:1213-1215"""
         self.encoder_cached = [True] * len(self.reqs)
 
-    def mix_with_running(self, running_batch: "ScheduleBatch", enable_overlap: bool = False):
+    def mix_with_running(self, running_batch: "ScheduleBatch", enable_overlap: Optional[bool] = None):
         """Chunked prefill + running decodes in one extend batch: the decode rows become extend rows
         of length 1 (schedule_batch.py:1073-1101).  Everything per-request that lives on the batch -
         sampling parameters, encoder lengths, pending output ids - is merged through ``merge_batch``
@@ -271,7 +457,7 @@ class ScheduleBatch:
         self.forward_mode = ForwardMode.MIXED
         running_bs = running_batch.batch_size()
         for req in running_batch.reqs:
-            req.fill_ids = req.origin_input_ids + req.output_ids
+            req.fill_ids = list(req.origin_input_ids) + req.output_ids
             req.extend_input_len = 1
         input_ids = torch.cat([self.input_ids, running_batch.input_ids])
         out_cache_loc = torch.cat([self.out_cache_loc, running_batch.out_cache_loc])
@@ -279,7 +465,7 @@ class ScheduleBatch:
         self.input_ids = input_ids
         self.out_cache_loc = out_cache_loc
         # with the overlap scheduler output_ids lags one step behind (schedule_batch.py:1088-1089)
-        delta = 0 if enable_overlap else -1
+        delta = 0 if (self.enable_overlap if enable_overlap is None else enable_overlap) else -1
         self.prefix_lens = self.prefix_lens + [len(r.origin_input_ids) + len(r.output_ids) + delta
                                                for r in running_batch.reqs]
         self.extend_lens = self.extend_lens + [1] * running_bs
@@ -290,7 +476,21 @@ class ScheduleBatch:
                 own_ids = torch.zeros(kept_own, dtype=torch.int64)
             self.extend_input_logprob_token_ids = torch.cat([own_ids.cpu(), torch.zeros(running_bs, dtype=torch.int64)])
 
-    def prepare_for_decode(self):
+    def prepare_for_idle(self):
+        """schedule_batch.py:1217-1228 (an idle batch has no rows: its sampling info stays "all greedy" = None)"""
+        self.forward_mode = ForwardMode.IDLE
+        self.input_ids = torch.empty(0, dtype=torch.int64, device=self.device)
+        self.seq_lens = torch.empty(0, dtype=torch.int64, device=self.device)
+        self.out_cache_loc = torch.empty(0, dtype=torch.int64, device=self.device)
+        self.req_pool_indices = torch.empty(0, dtype=torch.int32, device=self.device)
+        self.seq_lens_sum = self.seq_lens_max = 0
+        self.extend_num_tokens = 0
+
+    def prepare_for_decode(self, topping_manager=None):
+        """schedule_batch.py:1230-1308.  ``topping_manager``: the reference's LoRA/delta manager; an ENABLED one
+        re-orders the batch by adapter - toppings are out of scope, so that is refused rather than ignored."""
+        if topping_manager is not None and getattr(topping_manager, "enabled", False):
+            raise NotImplementedError("toppings (LoRA / delta adapters) are out of scope of this path")
         self.forward_mode = ForwardMode.DECODE
         bs = len(self.reqs)
         self.input_ids = self.output_ids
@@ -317,9 +517,14 @@ class ScheduleBatch:
             self.tree_cache.evict(need)
         return self.token_to_kv_pool_allocator.available_size() >= need
 
-    def retract_decode(self, retract_decode_steps: int = 20):
+    def retract_decode(self, server_args=20):
         """schedule_batch.py:1123-1211: give back the slots of the requests with the fewest output
-        tokens (ties: longest prompt) until the rest can run ``retract_decode_steps`` more steps."""
+        tokens (ties: longest prompt) until the rest can run ``retract_decode_steps`` more steps.
+        ``server_args``: the reference's ServerArgs (``.retract_decode_steps`` is read) or the step count itself.
+        Returns (retracted requests, the new token-ratio estimate) as the reference does."""
+        if getattr(server_args, "speculative_algorithm", None):
+            raise NotImplementedError("Speculative decoding is not supported yet.")
+        retract_decode_steps = int(getattr(server_args, "retract_decode_steps", server_args))
         order = sorted(range(len(self.reqs)),
                        key=lambda i: (len(self.reqs[i].output_ids), -len(self.reqs[i].origin_input_ids)),
                        reverse=True)
@@ -347,12 +552,17 @@ class ScheduleBatch:
                 self.tree_cache.evict(max(0, residual))
             req.reset_for_retract()
         self.filter_batch(keep_indices=order)
-        return retracted
+        decoded = sum(len(r.output_ids) for r in self.reqs)
+        budget = sum(getattr(r.sampling_params, "max_new_tokens", 0) or 0 for r in self.reqs)
+        ratio = min(1.0, (decoded + retract_decode_steps * len(self.reqs)) / budget) if budget else 1.0
+        return retracted, ratio
 
-    def filter_batch(self, keep_indices: Optional[List[int]] = None):
-        """schedule_batch.py:1309-1359"""
+    def filter_batch(self, chunked_req_to_exclude: Optional[Req] = None, keep_indices: Optional[List[int]] = None):
+        """schedule_batch.py:1310-1359: keep the unfinished requests (and not the chunked request the scheduler
+        is about to re-queue, scheduler.py:803), or exactly ``keep_indices``."""
         if keep_indices is None:
-            keep_indices = [i for i, r in enumerate(self.reqs) if not r.finished()]
+            keep_indices = [i for i, r in enumerate(self.reqs)
+                            if not r.finished() and r is not chunked_req_to_exclude]
         if len(keep_indices) == 0:
             self.reqs = []
             return
@@ -380,6 +590,8 @@ class ScheduleBatch:
             self.token_ids_logprobs = [self.token_ids_logprobs[i] for i in keep_indices]
         else:
             self.top_logprobs_nums = self.token_ids_logprobs = None
+        self.has_stream = any(getattr(r, "stream", False) for r in self.reqs)
+        self.has_grammar = any(getattr(r, "grammar", None) for r in self.reqs)
         if self.sampling_info is not None:
             self.sampling_info.filter_batch(keep_indices, keep)
 
@@ -429,19 +641,24 @@ class ScheduleBatch:
         self.return_hidden_states |= other.return_hidden_states
 
     def get_model_worker_batch(self) -> ModelWorkerBatch:
-        global _bid
-        _bid += 1
+        global bid
+        bid += 1
         if self.forward_mode.is_decode_or_idle():
             extend_seq_lens = extend_prefix_lens = None
         else:
             extend_seq_lens, extend_prefix_lens = self.extend_lens, self.prefix_lens
         return ModelWorkerBatch(
-            bid=_bid, forward_mode=self.forward_mode, input_ids=self.input_ids,
+            bid=bid, forward_mode=self.forward_mode, input_ids=self.input_ids,
             req_pool_indices=self.req_pool_indices, seq_lens=self.seq_lens,
             out_cache_loc=self.out_cache_loc, seq_lens_sum=self.seq_lens_sum,
             seq_lens_max_hint=self.seq_lens_max or None,
             extend_num_tokens=self.extend_num_tokens, extend_seq_lens=extend_seq_lens,
-            extend_prefix_lens=extend_prefix_lens, capture_hidden_mode=CaptureHiddenMode.NULL,
+            extend_prefix_lens=extend_prefix_lens,
+            capture_hidden_mode=(CaptureHiddenMode.FULL if self.return_hidden_states else CaptureHiddenMode.NULL),
+            global_num_tokens=self.global_num_tokens, global_num_tokens_for_logprob=self.global_num_tokens_for_logprob,
+            can_run_dp_cuda_graph=self.can_run_dp_cuda_graph, input_embeds=self.input_embeds,
+            toppings_paths=[getattr(r, "topping_path", None) for r in self.reqs],
+            spec_algorithm=self.spec_algorithm, spec_info=self.spec_info, launch_done=self.launch_done,
             encoder_cached=self.encoder_cached, encoder_lens=self.encoder_lens,
             encoder_lens_cpu=self.encoder_lens_cpu, encoder_out_cache_loc=self.encoder_out_cache_loc,
             multimodal_inputs=[r.multimodal_inputs for r in self.reqs],
@@ -450,3 +667,14 @@ class ScheduleBatch:
             extend_logprob_start_lens=(None if self.forward_mode.is_decode_or_idle() else self.extend_logprob_start_lens),
             extend_input_logprob_token_ids=(None if self.forward_mode.is_decode_or_idle()
                                             else self.extend_input_logprob_token_ids))
+
+    def copy(self):
+        """schedule_batch.py:1461-1472: only the fields process_batch_result reads"""
+        return ScheduleBatch(reqs=self.reqs, model_config=self.model_config, forward_mode=self.forward_mode,
+                             out_cache_loc=self.out_cache_loc, return_logprob=self.return_logprob,
+                             decoding_reqs=self.decoding_reqs, spec_algorithm=self.spec_algorithm,
+                             enable_custom_logit_processor=self.enable_custom_logit_processor,
+                             device=self.device, is_encoder_decoder=self.is_encoder_decoder)
+
+    def __str__(self):
+        return f"ScheduleBatch(forward_mode={self.forward_mode.name if self.forward_mode else 'None'}, #req={len(self.reqs)})"

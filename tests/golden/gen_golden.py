@@ -1035,12 +1035,155 @@ def gen_input_logprobs():
     _save("input_logprobs", **out)
 
 
+def gen_api_surface():
+    """The CALL SURFACE of the reference's seams for this path, as data: dataclass field names / order / defaults,
+    parameter names / order / kinds / defaults of the seam classes' public methods (inspect on the imported reference),
+    and the call FORMS (positional count + keyword names) its own callers use on them (an ast walk over the caller
+    files: scheduler.py, tp_worker*.py, model_runner.py, cuda_graph_runner.py, the attention backends and layers).
+    Names, counts and default reprs only - no source text.  tests/test_api_surface.py binds every form on ours."""
+    import ast
+    import dataclasses
+    import inspect
+    import json
+
+    import scratchpad.distributed.communication_op as comm
+    import scratchpad.distributed.parallel_state as ps
+    import scratchpad.memory.chunk_cache as cc
+    import scratchpad.memory.pool as pool
+    import scratchpad.memory.radix_cache as rc
+    import scratchpad.model_executor.custom_op as cop
+    import scratchpad.model_executor.forward_info as fi
+    import scratchpad.nn.attention.backend as be
+    import scratchpad.nn.attention.radix_attention as ra
+    import scratchpad.scheduler.schedule_batch as sb
+
+    def default_repr(v):
+        if v is inspect.Parameter.empty or v is dataclasses.MISSING:
+            return None
+        if v is None or isinstance(v, (bool, int, float, str)):
+            return repr(v)
+        return "<" + type(v).__name__ + ">"
+
+    def params(fn):
+        out = []
+        for p in inspect.signature(fn).parameters.values():
+            if p.name in ("self", "cls"):
+                continue
+            out.append({"name": p.name, "kind": p.kind.name, "required": p.default is inspect.Parameter.empty
+                        and p.kind not in (p.VAR_POSITIONAL, p.VAR_KEYWORD), "default": default_repr(p.default)})
+        return out
+
+    def fields(cls):
+        return [{"name": f.name, "required": f.default is dataclasses.MISSING and f.default_factory is dataclasses.MISSING,
+                 "default": default_repr(f.default)} for f in dataclasses.fields(cls)]
+
+    def methods(cls, only=None):
+        out = {}
+        for name, member in cls.__dict__.items():
+            if name.startswith("_") and name != "__init__":
+                continue
+            if only is not None and name not in only:
+                continue
+            kind = "method"
+            if isinstance(member, classmethod):
+                member, kind = member.__func__, "classmethod"
+            elif isinstance(member, staticmethod):
+                member, kind = member.__func__, "staticmethod"
+            elif isinstance(member, property):
+                out[name] = {"kind": "property", "params": []}
+                continue
+            if not inspect.isfunction(member):
+                continue
+            member = inspect.unwrap(member)
+            out[name] = {"kind": kind, "params": params(member)}
+        return out
+
+    classes = {
+        "AttentionBackend": be.AttentionBackend, "RadixAttention": ra.RadixAttention, "CustomOp": cop.CustomOp,
+        "KVCache": pool.KVCache, "MHATokenToKVPool": pool.MHATokenToKVPool, "ReqToTokenPool": pool.ReqToTokenPool,
+        "TokenToKVPoolAllocator": pool.TokenToKVPoolAllocator, "ScheduleBatch": sb.ScheduleBatch, "Req": sb.Req,
+        "ForwardBatch": fi.ForwardBatch, "ForwardMode": fi.ForwardMode, "CaptureHiddenMode": fi.CaptureHiddenMode,
+        "RadixCache": rc.RadixCache, "ChunkCache": cc.ChunkCache,
+    }
+    surface = {"dataclasses": {n: fields(c) for n, c in (("ForwardBatch", fi.ForwardBatch),
+                                                         ("ModelWorkerBatch", sb.ModelWorkerBatch),
+                                                         ("ScheduleBatch", sb.ScheduleBatch))},
+               "enums": {n: {m.name: int(m.value) for m in c} for n, c in (("ForwardMode", fi.ForwardMode),
+                                                                         ("CaptureHiddenMode", fi.CaptureHiddenMode))},
+               "methods": {n: methods(c) for n, c in classes.items()},
+               "functions": {}}
+    surface["methods"]["GroupCoordinator"] = methods(ps.GroupCoordinator, only=("all_reduce", "all_gather", "graph_capture"))
+    for mod, names in ((comm, ("tensor_model_parallel_all_reduce", "tensor_model_parallel_all_gather")),
+                       (ps, ("graph_capture", "get_tp_group", "get_tensor_model_parallel_world_size",
+                             "get_tensor_model_parallel_rank"))):
+        for n in names:
+            surface["functions"][n] = params(inspect.unwrap(getattr(mod, n)))
+
+    # ---- call forms: every `<receiver>.<method>(...)` in the caller files whose method name belongs to a seam class
+    seam_methods = set()
+    for n in ("AttentionBackend", "RadixAttention", "KVCache", "MHATokenToKVPool", "ReqToTokenPool",
+              "TokenToKVPoolAllocator", "ScheduleBatch", "Req", "GroupCoordinator", "RadixCache", "ChunkCache", "ForwardBatch"):
+        seam_methods |= {m for m in surface["methods"][n] if m != "__init__"}
+    seam_methods |= set(surface["functions"])
+    callers = ["scheduler/scheduler.py", "scheduler/schedule_batch.py", "scheduler/schedule_policy.py",
+               "managers/tp_worker.py", "managers/tp_worker_client.py",
+               "model_executor/model_runner.py", "model_executor/cuda_graph_runner.py", "model_executor/forward_info.py",
+               "nn/attention/radix_attention.py", "nn/attention/triton_backend.py", "nn/attention/flashinfer_backend.py",
+               "nn/models/llama/llama.py", "nn/models/llama/mllama.py", "nn/layers/linear.py",
+               "nn/layers/logits_processor.py", "nn/layers/vocab_parallel_embedding.py", "memory/radix_cache.py",
+               "memory/chunk_cache.py"]
+    ctor_names = {"RadixAttention", "ScheduleBatch", "ModelWorkerBatch", "ForwardBatch", "ReqToTokenPool",
+                  "TokenToKVPoolAllocator", "MHATokenToKVPool", "RadixCache", "ChunkCache", "Req"}
+
+    def receiver_of(node):
+        """last name of the receiver expression: self.last_batch.filter_batch -> 'last_batch'"""
+        if isinstance(node, ast.Attribute):
+            return node.attr
+        if isinstance(node, ast.Name):
+            return node.id
+        if isinstance(node, ast.Call):
+            return receiver_of(node.func) + "()"
+        if isinstance(node, ast.Subscript):
+            return receiver_of(node.value) + "[]"
+        return type(node).__name__
+
+    forms = []
+    for rel in callers:
+        path = os.path.join(_ref_loader.REF, rel)
+        if not os.path.exists(path):
+            continue
+        tree = ast.parse(open(path).read())
+        for node in ast.walk(tree):
+            if not isinstance(node, ast.Call):
+                continue
+            f = node.func
+            if isinstance(f, ast.Attribute) and f.attr in seam_methods:
+                recv, meth = receiver_of(f.value), f.attr
+            elif isinstance(f, ast.Name) and (f.id in ctor_names or f.id in surface["functions"]):
+                recv, meth = None, f.id
+            else:
+                continue
+            forms.append({"file": rel, "line": node.lineno, "receiver": recv, "method": meth,
+                          "n_positional": sum(1 for a in node.args if not isinstance(a, ast.Starred)),
+                          "star_args": any(isinstance(a, ast.Starred) for a in node.args),
+                          "keywords": [k.arg for k in node.keywords if k.arg is not None],
+                          "star_kwargs": any(k.arg is None for k in node.keywords)})
+    forms.sort(key=lambda d: (d["file"], d["line"], d["method"]))
+    surface["call_forms"] = forms
+    path = os.path.join(HERE, "api_surface.json")
+    with open(path, "w") as fh:
+        json.dump(surface, fh, indent=1, sort_keys=False)
+        fh.write("\n")
+    print(f"wrote {path}: {sum(len(v) for v in surface['methods'].values())} methods, {len(forms)} call forms")
+
+
+
 GENERATORS = {
     "rmsnorm": gen_rmsnorm, "silu_mul": gen_silu_mul, "rotary": gen_rotary, "kv_pool": gen_kv_pool,
     "positions": gen_positions, "decode_attention": gen_decode, "extend_attention": gen_extend,
     "tiny_llama": gen_tiny_llama, "tiny_mllama": gen_tiny_mllama, "radix_cache": gen_radix_cache,
     "sampling": gen_sampling, "mllama_vision": gen_mllama_vision, "input_logprobs": gen_input_logprobs,
-    "prefill_attention": gen_prefill_attention,
+    "prefill_attention": gen_prefill_attention, "api_surface": gen_api_surface,
 }
 
 if __name__ == "__main__":

@@ -190,8 +190,8 @@ def test_tiny_llama_with_fp8_kv_cache(dtype, bar):
     wd = {k: v.to(dtype) for k, v in w.items()}
     okv = ollama.OracleKV(shape, 96, 4, 64, dtype=torch.uint8)
     gen = torch.Generator().manual_seed(9)
-    reqs = [Req(str(i), torch.randint(0, shape.vocab, (n,), generator=gen).tolist()) for i, n in enumerate((9, 5))]
-    sb = ScheduleBatch(reqs, mr.req_to_token_pool, mr.token_to_kv_pool_allocator, mr.device)
+    reqs = [Req(str(i), "", torch.randint(0, shape.vocab, (n,), generator=gen).tolist(), None) for i, n in enumerate((9, 5))]
+    sb = ScheduleBatch(reqs, mr.req_to_token_pool, mr.token_to_kv_pool_allocator, device=mr.device)
     sb.prepare_for_extend()
     out, nxt = worker.forward_batch_generation(sb.get_model_worker_batch())
     okv.req_to_token.copy_(mr.req_to_token_pool.req_to_token.cpu())

@@ -83,8 +83,8 @@ def test_real_width_layers_against_fp32_and_same_dtype_oracle(case, dtype):
     w16 = {k: v.detach().cpu() for k, v in mr.model.named_parameters()}
     w32 = {k: v.float() for k, v in w16.items()}
     gen = torch.Generator().manual_seed(11)
-    reqs = [Req(str(i), torch.randint(0, vocab, (n,), generator=gen).tolist()) for i, n in enumerate(lens)]
-    sb = ScheduleBatch(reqs, mr.req_to_token_pool, mr.token_to_kv_pool_allocator, mr.device)
+    reqs = [Req(str(i), "", torch.randint(0, vocab, (n,), generator=gen).tolist(), None) for i, n in enumerate(lens)]
+    sb = ScheduleBatch(reqs, mr.req_to_token_pool, mr.token_to_kv_pool_allocator, device=mr.device)
     sb.prepare_for_extend()
     out, _ = worker.forward_batch_generation(sb.get_model_worker_batch())
     hip = [out.next_token_logits.float().cpu()]

@@ -64,10 +64,10 @@ def test_tiny_mllama_matches_reference_logits(graph_bs):
         toks = ids[off:off + text[b]]
         off += text[b]
         if enc[b]:
-            reqs.append(Req(str(b), [0] * enc[b] + toks, num_image_tokens=enc[b]))   # image pad ids first
+            reqs.append(Req(str(b), "", [0] * enc[b] + toks, None, num_image_tokens=enc[b]))   # image pad ids first
         else:
-            reqs.append(Req(str(b), toks))
-    sb = ScheduleBatch(reqs, mr.req_to_token_pool, mr.token_to_kv_pool_allocator, dev, is_encoder_decoder=True)
+            reqs.append(Req(str(b), "", toks, None))
+    sb = ScheduleBatch(reqs, mr.req_to_token_pool, mr.token_to_kv_pool_allocator, device=dev, is_encoder_decoder=True)
     sb.prepare_for_extend()
     assert sb.extend_lens == text and sb.encoder_lens_cpu == enc and sb.encoder_cached == [False, True, False]
     assert np.array_equal(sb.out_cache_loc.cpu().numpy(), g["out_cache_loc"])
@@ -158,8 +158,8 @@ def test_image_request_end_to_end_through_the_vision_tower():
     ids_a = mr.model.pad_input_ids(text_a, mm)
     enc = mm.num_image_tokens
     assert enc == vsh.max_num_tiles * vsh.num_patches and ids_a[:enc] == [3] * enc
-    reqs = [Req("img", ids_a, num_image_tokens=enc, multimodal_inputs=mm), Req("txt", text_b)]
-    sb = ScheduleBatch(reqs, mr.req_to_token_pool, mr.token_to_kv_pool_allocator, mr.device, is_encoder_decoder=True)
+    reqs = [Req("img", "", ids_a, None, num_image_tokens=enc, multimodal_inputs=mm), Req("txt", "", text_b, None)]
+    sb = ScheduleBatch(reqs, mr.req_to_token_pool, mr.token_to_kv_pool_allocator, device=mr.device, is_encoder_decoder=True)
     sb.prepare_for_extend()
     assert sb.encoder_lens_cpu == [enc, 0] and sb.extend_lens == [6, 4] and sb.encoder_cached == [False, True]
     out, nxt = worker.forward_batch_generation(sb.get_model_worker_batch())

@@ -4,6 +4,8 @@ decodes), checked step by step against the CPU oracle fed with the SAME slots/ta
 
 This is the continuous-batching trace in miniature: slot allocation, req_to_token writes and the
 KV pool contents must agree bit-exactly in their indices; logits within the fp32 bar."""
+from types import SimpleNamespace
+
 import pytest
 import torch
 
@@ -44,7 +46,7 @@ def test_extend_decode_mixed_trace_matches_oracle():
 
     # ---- 1. prefill of two requests; the second reuses the first 4 tokens' KV of a shared prompt
     shared = torch.randint(0, shape.vocab, (4,), generator=gen).tolist()
-    warm = ScheduleBatch([Req("warm", shared)], mr.req_to_token_pool, mr.token_to_kv_pool_allocator, dev)
+    warm = ScheduleBatch([Req("warm", "", shared, None)], mr.req_to_token_pool, mr.token_to_kv_pool_allocator, device=dev)
     warm.prepare_for_extend()
     out, _ = worker.forward_batch_generation(warm.get_model_worker_batch())
     mirror_tables()
@@ -55,9 +57,9 @@ def test_extend_decode_mixed_trace_matches_oracle():
     prefix_slots = warm.out_cache_loc.clone()          # what RadixCache.match_prefix would return
     mr.req_to_token_pool.free(warm.reqs[0].req_pool_idx)
 
-    r0 = Req("r0", torch.randint(0, shape.vocab, (7,), generator=gen).tolist())
-    r1 = Req("r1", shared + torch.randint(0, shape.vocab, (5,), generator=gen).tolist(), prefix_indices=prefix_slots)
-    sb = ScheduleBatch([r0, r1], mr.req_to_token_pool, mr.token_to_kv_pool_allocator, dev)
+    r0 = Req("r0", "", torch.randint(0, shape.vocab, (7,), generator=gen).tolist(), None)
+    r1 = Req("r1", "", shared + torch.randint(0, shape.vocab, (5,), generator=gen).tolist(), None, prefix_indices=prefix_slots)
+    sb = ScheduleBatch([r0, r1], mr.req_to_token_pool, mr.token_to_kv_pool_allocator, device=dev)
     sb.prepare_for_extend()
     assert sb.prefix_lens == [0, 4] and sb.extend_lens == [7, 5] and sb.extend_num_tokens == 12
     assert sb.seq_lens_max == int(sb.seq_lens.max()) == 9 and sb.get_model_worker_batch().seq_lens_max_hint == 9
@@ -91,8 +93,8 @@ def test_extend_decode_mixed_trace_matches_oracle():
 
     # ---- 3. MIXED: a new prompt is prefilled in the same batch as the two running decodes
     sb.prepare_for_decode()
-    newr = Req("r2", torch.randint(0, shape.vocab, (6,), generator=gen).tolist())
-    mix = ScheduleBatch([newr], mr.req_to_token_pool, mr.token_to_kv_pool_allocator, dev)
+    newr = Req("r2", "", torch.randint(0, shape.vocab, (6,), generator=gen).tolist(), None)
+    mix = ScheduleBatch([newr], mr.req_to_token_pool, mr.token_to_kv_pool_allocator, device=dev)
     mix.prepare_for_extend()
     for r, tok in zip(sb.reqs, sb.input_ids.tolist()):
         r.output_ids.append(tok)
@@ -112,9 +114,8 @@ def test_extend_decode_mixed_trace_matches_oracle():
         r.output_ids.append(tok)
     mix.output_ids = out.next_token_logits.argmax(-1)
     mix.prepare_for_decode()
-    lp = Req("r3", torch.randint(0, shape.vocab, (5,), generator=gen).tolist(), return_logprob=True, logprob_start_len=1,
-             top_logprobs_num=2)
-    mix2 = ScheduleBatch([lp], mr.req_to_token_pool, mr.token_to_kv_pool_allocator, dev)
+    lp = Req("r3", "", torch.randint(0, shape.vocab, (5,), generator=gen).tolist(), None, return_logprob=True, logprob_start_len=1, top_logprobs_num=2)
+    mix2 = ScheduleBatch([lp], mr.req_to_token_pool, mr.token_to_kv_pool_allocator, device=dev)
     mix2.prepare_for_extend()
     assert mix2.extend_input_logprob_token_ids.tolist() == lp.origin_input_ids[2:] + [0]
     mix2.mix_with_running(mix)
@@ -137,12 +138,12 @@ def test_out_of_memory_is_reported_like_the_reference():
     from scratchpad_amd.schedule_batch import Req, ScheduleBatch
     g, pfx, shape, w = smoke_impl.load_case("a")
     mr = smoke_impl.make_runner(shape, w, torch.float32)
-    big = ScheduleBatch([Req("x", list(range(50))), Req("y", list(range(50)))], mr.req_to_token_pool,
-                        mr.token_to_kv_pool_allocator, mr.device)
+    big = ScheduleBatch([Req("x", "", list(range(50)), None), Req("y", "", list(range(50)), None)], mr.req_to_token_pool,
+                        mr.token_to_kv_pool_allocator, device=mr.device)
     with pytest.raises(RuntimeError, match="Out of memory"):
         big.prepare_for_extend()          # 100 tokens > the 96-slot pool
-    many = ScheduleBatch([Req(str(i), [1]) for i in range(9)], mr.req_to_token_pool,
-                         mr.token_to_kv_pool_allocator, mr.device)
+    many = ScheduleBatch([Req(str(i), "", [1], None) for i in range(9)], mr.req_to_token_pool,
+                         mr.token_to_kv_pool_allocator, device=mr.device)
     with pytest.raises(RuntimeError, match="max-running-requests"):
         many.prepare_for_extend()
 
@@ -165,8 +166,8 @@ def test_overlap_worker_matches_synchronous_worker():
     def run(overlap):
         mr = smoke_impl.make_runner(shape, w, torch.float32)
         worker = TpModelWorkerClient(mr) if overlap else TpModelWorker(mr)
-        sb = ScheduleBatch([Req(str(i), list(p)) for i, p in enumerate(prompts)], mr.req_to_token_pool,
-                           mr.token_to_kv_pool_allocator, mr.device)
+        sb = ScheduleBatch([Req(str(i), "", list(p), None) for i, p in enumerate(prompts)], mr.req_to_token_pool,
+                           mr.token_to_kv_pool_allocator, device=mr.device)
         sb.prepare_for_extend()
         tokens = []
         _, nxt = worker.forward_batch_generation(sb.get_model_worker_batch())
@@ -220,10 +221,10 @@ def test_radix_cache_prefix_reuse_chunked_prefill_and_retraction():
     rand = lambda n: torch.randint(0, shape.vocab, (n,), generator=gen).tolist()
 
     def batch(reqs):
-        return ScheduleBatch(reqs, r2t, alloc, dev, tree_cache=tree)
+        return ScheduleBatch(reqs, r2t, alloc, device=dev, tree_cache=tree)
 
     # A: plain prefill + 2 decode steps, then finish -> the tree owns prompt + first output token
-    a = Req("a", rand(12))
+    a = Req("a", "", rand(12), None)
     a.init_next_round_input(tree)
     assert a.prefix_len == 0 and a.last_node is tree.root_node
     tree.inc_lock_ref(a.last_node)
@@ -242,8 +243,8 @@ def test_radix_cache_prefix_reuse_chunked_prefill_and_retraction():
     assert alloc.available_size() + tree.total_size() == 96 and r2t.available_size() == 4
 
     # B shares A's first 8 prompt tokens; C repeats A's prompt + its first output (full hit - 1)
-    b = Req("b", a.origin_input_ids[:8] + rand(5))
-    c = Req("c", a.origin_input_ids + a.output_ids[:1])
+    b = Req("b", "", a.origin_input_ids[:8] + rand(5), None)
+    c = Req("c", "", a.origin_input_ids + a.output_ids[:1], None)
     for r in (b, c):
         r.init_next_round_input(tree)
         tree.inc_lock_ref(r.last_node)
@@ -261,9 +262,10 @@ def test_radix_cache_prefix_reuse_chunked_prefill_and_retraction():
     # retraction: equal output counts and prompt lengths -> the later request (C) is retracted first
     sb.output_ids = out.next_token_logits.argmax(-1)
     before = alloc.available_size()
-    retracted = sb.retract_decode(retract_decode_steps=1)
+    retracted, new_ratio = sb.retract_decode(SimpleNamespace(retract_decode_steps=1, speculative_algorithm=None, page_size=1))
+    assert new_ratio == 1.0                            # (no max_new_tokens budget on these requests)
     assert [r.rid for r in retracted] == ["c"] and [r.rid for r in sb.reqs] == ["b"]
-    assert c.req_pool_idx is None and c.prefix_indices is None and c.is_retracted
+    assert c.req_pool_idx is None and len(c.prefix_indices) == 0 and c.is_retracted
     assert alloc.available_size() == before + 1      # C's single own slot; its prefix stays cached
     assert sb.seq_lens.tolist() == [13] and sb.check_decode_mem()
 
@@ -271,7 +273,7 @@ def test_radix_cache_prefix_reuse_chunked_prefill_and_retraction():
     b.output_ids = [int(sb.output_ids[0])]
     tree.cache_finished_req(b)
     d_ids = b.origin_input_ids[:10] + rand(6)
-    d = Req("d", d_ids)
+    d = Req("d", "", d_ids, None)
     d.init_next_round_input(tree)
     assert d.prefix_len == 10
     tree.inc_lock_ref(d.last_node)
@@ -295,7 +297,7 @@ def test_radix_cache_prefix_reuse_chunked_prefill_and_retraction():
     tree.cache_finished_req(d)
     cached_before = tree.total_size()
     hog = alloc.alloc(alloc.available_size() - 20)      # leave 20 free slots for a 30-token prompt
-    e = Req("e", rand(30))
+    e = Req("e", "", rand(30), None)
     e.init_next_round_input(tree)
     tree.inc_lock_ref(e.last_node)
     se = batch([e])

@@ -96,9 +96,30 @@ def test_kv_pool_layout_and_guards(interleave, monkeypatch):
     assert torch.equal(other.get_value_buffer(2)[idx], pool.get_value_buffer(2)[idx])
     other.transfer_per_layer(torch.tensor([1]), torch.stack([kb[3:4], vb[3:4]]), 1)
     assert torch.equal(other.get_key_buffer(1)[1], kb[3]) and torch.equal(other.get_value_buffer(1)[1], vb[3])
+    # memory/pool.py:329-346: the transfer engines upstream address token i of buffer b at ptrs[b] + i * items[b]; walk
+    # that contract with ctypes over every listed buffer and compare with the views the kernels use
+    import ctypes
     ptrs, lens, items = pool.get_contiguous_buf_infos()
-    assert len(ptrs) == 6 and items == [256] * 6
-    assert lens[0] == (10 * k.stride(0) + 128) * 2
+    rows = {}
+    for b, (ptr, n, item) in enumerate(zip(ptrs, lens, items)):
+        assert n == 11 * item
+        for tok in (0, 3, 10):
+            raw = (ctypes.c_uint16 * (item // 2)).from_address(ptr + tok * item)
+            rows[b, tok] = torch.frombuffer(bytearray(raw), dtype=torch.bfloat16).clone()
+    regions = sorted((p_, p_ + n) for p_, n in zip(ptrs, lens))
+    assert all(a[1] <= b_[0] for a, b_ in zip(regions, regions[1:])), "listed buffers must not overlap"
+    if interleave:
+        assert len(ptrs) == 3 and items == [512] * 3                  # one K|V pair per token per layer
+        for l in range(3):
+            for tok in (0, 3, 10):
+                assert torch.equal(rows[l, tok][:128], pool.get_key_buffer(l)[tok].flatten())
+                assert torch.equal(rows[l, tok][128:], pool.get_value_buffer(l)[tok].flatten())
+    else:
+        assert len(ptrs) == 6 and items == [256] * 6                  # K buffers, then V buffers, as upstream
+        for l in range(3):
+            for tok in (0, 3, 10):
+                assert torch.equal(rows[l, tok], pool.get_key_buffer(l)[tok].flatten())
+                assert torch.equal(rows[3 + l, tok], pool.get_value_buffer(l)[tok].flatten())
     with pytest.raises(NotImplementedError):
         MHATokenToKVPool(10, 16, torch.bfloat16, 2, 64, 1, "cpu")
     with pytest.raises(RuntimeError, match="no CPU fallback"):   # the store itself is HIP-only
@@ -311,7 +332,7 @@ def test_mixed_batch_merges_sampling_info_like_the_reference():
     def batches(prefill_params, running_params):
         r2t = ReqToTokenPool(8, 16, "cpu")
         alloc = TokenToKVPoolAllocator(32, torch.float32, "cpu", None)
-        new = ScheduleBatch([Req("n0", [1, 2, 3, 4], sampling_params=prefill_params)], r2t, alloc, "cpu")
+        new = ScheduleBatch([Req("n0", "", [1, 2, 3, 4], prefill_params)], r2t, alloc, device="cpu")
         new.forward_mode = ForwardMode.EXTEND
         new.input_ids = torch.tensor([1, 2, 3, 4])
         new.out_cache_loc = torch.tensor([10, 11, 12, 13])
@@ -319,8 +340,8 @@ def test_mixed_batch_merges_sampling_info_like_the_reference():
         new.seq_lens = torch.tensor([4])
         new.seq_lens_sum, new.extend_num_tokens = 4, 4
         new.prefix_lens, new.extend_lens = [0], [4]
-        run = ScheduleBatch([Req("r0", [5, 6], output_ids=[7], sampling_params=running_params[0]),
-                             Req("r1", [8], output_ids=[9, 9], sampling_params=running_params[1])], r2t, alloc, "cpu")
+        run = ScheduleBatch([Req("r0", "", [5, 6], running_params[0], output_ids=[7]),
+                             Req("r1", "", [8], running_params[1], output_ids=[9, 9])], r2t, alloc, device="cpu")
         run.forward_mode = ForwardMode.DECODE
         run.input_ids = torch.tensor([7, 9])
         run.out_cache_loc = torch.tensor([20, 21])

@@ -108,15 +108,14 @@ def _schedule(c, r2t, alloc, device):
     reqs = []
     for i, (n, pre, chunk_end, start, k) in enumerate(c["spec"].tolist()):
         prompt = c[f"r{i}_prompt"].tolist()
-        r = Req(str(i), prompt, return_logprob=True, top_logprobs_num=k,
-                token_ids_logprob=c[f"r{i}_ids"].tolist() if bool(c["has_ids"][i]) else None)
+        r = Req(str(i), "", prompt, None, return_logprob=True, top_logprobs_num=k, token_ids_logprob=c[f"r{i}_ids"].tolist() if bool(c["has_ids"][i]) else None)
         r.logprob_start_len = n - 1 if start < 0 else start
         if chunk_end >= 0:
             r.fill_ids = prompt[:chunk_end]
         if pre:
             r.prefix_indices = alloc.alloc(pre)
         reqs.append(r)
-    sb = ScheduleBatch(reqs, r2t, alloc, device)
+    sb = ScheduleBatch(reqs, r2t, alloc, device=device)
     sb.prepare_for_extend()
     return sb
 
@@ -139,7 +138,7 @@ def test_schedule_batch_bookkeeping_matches_the_reference(monkeypatch):
         if len(sb.reqs) > 2:
             sb.output_ids = None
             sb.seq_lens = sb.seq_lens.clone()
-            sb.filter_batch([0, 2])
+            sb.filter_batch(keep_indices=[0, 2])
             assert sb.top_logprobs_nums == [c["spec"][0, 4], c["spec"][2, 4]]
 
 
@@ -152,11 +151,11 @@ def test_prefix_match_stops_at_the_logprob_start():
             self.key = key
             return torch.arange(len(key)), None
     cache = Cache()
-    r = Req("a", list(range(10)), return_logprob=True)
+    r = Req("a", "", list(range(10)), None, return_logprob=True)
     r.logprob_start_len = 3
     r.init_next_round_input(cache)
     assert cache.key == [0, 1, 2] and r.prefix_len == 3
-    r = Req("b", list(range(10)))
+    r = Req("b", "", list(range(10)), None)
     r.init_next_round_input(cache)
     assert len(cache.key) == 9
 
@@ -206,12 +205,12 @@ def test_model_step_with_input_logprobs_against_oracle(dtype):
     worker = TpModelWorker(mr)
     gen = torch.Generator().manual_seed(5)
     prompts = [torch.randint(0, shape.vocab, (n,), generator=gen).tolist() for n in (9, 6, 5)]
-    reqs = [Req("0", prompts[0], return_logprob=True, top_logprobs_num=3),
-            Req("1", prompts[1], return_logprob=True, token_ids_logprob=[5, 17]),
-            Req("2", prompts[2])]
+    reqs = [Req("0", "", prompts[0], None, return_logprob=True, top_logprobs_num=3),
+            Req("1", "", prompts[1], None, return_logprob=True, token_ids_logprob=[5, 17]),
+            Req("2", "", prompts[2], None)]
     reqs[1].logprob_start_len = 2
     reqs[2].logprob_start_len = len(prompts[2]) - 1
-    sb = ScheduleBatch(reqs, mr.req_to_token_pool, mr.token_to_kv_pool_allocator, mr.device)
+    sb = ScheduleBatch(reqs, mr.req_to_token_pool, mr.token_to_kv_pool_allocator, device=mr.device)
     sb.prepare_for_extend()
     assert sb.extend_logprob_start_lens == [0, 2, 4]
     out, next_ids = worker.forward_batch_generation(sb.get_model_worker_batch())
@@ -244,8 +243,8 @@ def test_model_step_with_input_logprobs_against_oracle(dtype):
     for r in sb.reqs:
         mr.req_to_token_pool.free(r.req_pool_idx)
     mr.token_to_kv_pool_allocator.free(sb.out_cache_loc)
-    plain = ScheduleBatch([Req(str(10 + i), p) for i, p in enumerate(prompts)], mr.req_to_token_pool,
-                          mr.token_to_kv_pool_allocator, mr.device)
+    plain = ScheduleBatch([Req(str(10 + i), "", p, None) for i, p in enumerate(prompts)], mr.req_to_token_pool,
+                          mr.token_to_kv_pool_allocator, device=mr.device)
     plain.prepare_for_extend()
     out2, ids2 = worker.forward_batch_generation(plain.get_model_worker_batch())
     assert out2.input_token_logprobs is None

@@ -30,7 +30,7 @@ def decode_bench(bs, steps=24, warmup=4, enc_len=6404, text_len=64, graph=True):
     alloc = mr.token_to_kv_pool_allocator
     alloc.free_slots = (torch.randperm(alloc.size, generator=gen) + 1).to(torch.int64).to(dev)
     batch = ScheduleBatch([Req(rid=str(i), origin_input_ids=[], num_image_tokens=enc_len) for i in range(bs)],
-                          mr.req_to_token_pool, alloc, dev, is_encoder_decoder=True)
+                          mr.req_to_token_pool, alloc, device=dev, is_encoder_decoder=True)
     rows = batch.alloc_req_slots(bs)
     batch.req_pool_indices = torch.tensor(rows, dtype=torch.int64, device=dev)
     batch.seq_lens = torch.full((bs,), text_len, dtype=torch.int64, device=dev)
