@@ -22,6 +22,20 @@ SP_FP8_E5M2 = 3
 _FP8_POOL_DTYPES = (torch.uint8, torch.float8_e5m2)
 
 
+def _kv_layout(k_buffer: torch.Tensor, v_buffer: torch.Tensor, what: str, same_stride: bool = True) -> None:
+    """The pool views every kernel assumes: [P+1, Hkv, D] with the heads of a token contiguous (stride(1) == D,
+    stride(2) == 1) and - where the ABI carries ONE token stride for both sides - the same token stride on K and V.
+    MHATokenToKVPool's views satisfy this under either arena layout; anything else would gather garbage silently."""
+    for name, b in (("k_buffer", k_buffer), ("v_buffer", v_buffer)):
+        if b.dim() != 3 or b.stride(2) != 1 or b.stride(1) != b.shape[2] or b.stride(0) < b.shape[1] * b.shape[2]:
+            raise RuntimeError(f"{what}: {name} must be [tokens, Hkv, D] with contiguous heads per token, got shape "
+                               f"{tuple(b.shape)} strides {tuple(b.stride())}")
+    if k_buffer.shape[:2] != v_buffer.shape[:2]:
+        raise RuntimeError(f"{what}: K and V pools disagree: {tuple(k_buffer.shape)} vs {tuple(v_buffer.shape)}")
+    if same_stride and v_buffer.stride(0) != k_buffer.stride(0):
+        raise RuntimeError(f"{what}: K and V pools need the same token stride ({k_buffer.stride(0)} vs {v_buffer.stride(0)})")
+
+
 def _kv_dt(buf: torch.Tensor, q: torch.Tensor, what: str) -> int:
     """dtype code of a KV pool buffer next to 16/32-bit q: the same type, or an e5m2 byte pool."""
     if buf.dtype == q.dtype:
@@ -225,6 +239,7 @@ def rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: torch.Te
             raise RuntimeError("fused KV store needs a 2-D row-contiguous value")
         if out_cache_loc.dtype != torch.int64:
             out_cache_loc = out_cache_loc.to(torch.int64)
+        _kv_layout(k_buffer, v_buffer, "rotary_embedding (fused KV store)")
         kv_stride, v_stride = k_buffer.stride(0), value.stride(0)
     _check(load().sp_rotary_embedding(
         positions.data_ptr(), query.data_ptr(), key.data_ptr(), cos_sin_cache.data_ptr(), T, Hq, Hkv,
@@ -249,6 +264,7 @@ def kv_store(k_buffer: torch.Tensor, v_buffer: torch.Tensor, loc: torch.Tensor,
     if loc.dtype != torch.int64:
         loc = loc.to(torch.int64)
     loc = loc.contiguous()
+    _kv_layout(k_buffer, v_buffer, "kv_store", same_stride=False)
     Hkv, D, Dv = k_buffer.shape[1], k_buffer.shape[2], v_buffer.shape[2]
     _check(load().sp_kv_store(k_buffer.data_ptr(), v_buffer.data_ptr(), loc.data_ptr(), k2.data_ptr(),
                               v2.data_ptr(), T, Hkv, D, Dv, k2.stride(0), v2.stride(0),
@@ -271,6 +287,7 @@ def kv_store_fp8(k_buffer: torch.Tensor, v_buffer: torch.Tensor, loc: torch.Tens
     if v2.stride(-1) != 1:
         v2 = v2.contiguous()
     loc = loc.to(torch.int64).contiguous()
+    _kv_layout(k_buffer, v_buffer, "kv_store_fp8", same_stride=False)
     Hkv, D = k_buffer.shape[1], k_buffer.shape[2]
     if v_buffer.shape[2] != D:
         raise RuntimeError("kv_store_fp8: v_head_dim must equal head_dim")
@@ -401,6 +418,7 @@ def decode_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
     if q.stride(2) != 1 or q.stride(1) != D or out.stride(2) != 1 or out.stride(1) != D:
         raise RuntimeError("decode_attention: q/out must be [bs, Hq, D] with contiguous heads")
     kv_dt = _kv_dt(k_buffer, q, "decode_attention")
+    _kv_layout(k_buffer, v_buffer, "decode_attention")
     if v_buffer.dtype != k_buffer.dtype:
         raise RuntimeError("decode_attention: K and V pools must share a dtype")
     req, seq, idx64 = _idx_pair(req_pool_indices, seq_lens)
@@ -440,6 +458,7 @@ def extend_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
     if q.stride(2) != 1 or q.stride(1) != D or out.stride(2) != 1 or out.stride(1) != D:
         raise RuntimeError("extend_attention: q/out must be [T, Hq, D] with contiguous heads")
     kv_dt = _kv_dt(k_buffer, q, "extend_attention")
+    _kv_layout(k_buffer, v_buffer, "extend_attention")
     if v_buffer.dtype != k_buffer.dtype:
         raise RuntimeError("extend_attention: K and V pools must share a dtype")
     if extend_seq_lens.dtype != torch.int32 or extend_start_loc.dtype != torch.int32:

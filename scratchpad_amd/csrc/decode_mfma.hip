@@ -119,6 +119,9 @@ struct DmCfg {
 // v_perm_b32 per two elements, exact), and the tile math runs in fp16 whatever the model dtype is
 // (bf16 q is converted once per workgroup; P is rounded to fp16); the output keeps the model dtype.
 // HBM bytes per context token halve; everything after the LDS tile is unchanged.
+#ifndef SP_DECODE_FUSED_MERGE
+#define SP_DECODE_FUSED_MERGE 1   // A/B switch (round 5): 0 compiles the in-kernel split merge out
+#endif
 template <typename Tag, int D, bool HPW, bool KV8>
 #ifndef SP_DEC_WAVES
 #define SP_DEC_WAVES 3
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
   // split partials: plain stores for the merge kernel; write-through (sc1) through a buffer descriptor when this
   // kernel merges them itself (a.fuse_groups > 0) - written through, they need no release fence before the arrival
   // count (cdna_hip_programming.md Guideline 16, R1; the host keeps the workspace below 2 GiB for the 32-bit offsets)
-  const bool fuse = a.fuse_groups > 0;
+  const bool fuse = SP_DECODE_FUSED_MERGE && a.fuse_groups > 0;
   const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.part_o, 0, fuse ? (int)((int64_t)a.max_slots * a.Hq * (D + 1) * 4) : 0, 0x00020000);
   const int nlive = min(nsplit, a.max_slots - slot0);     // splits of this request that run (all, unless the plan was cut)

@@ -3,6 +3,10 @@ rows against the oracle (the oracle itself cannot run these sizes in test time):
 
   config 2  Llama-3-8B head shape, bs = 256 decode, contexts U[128, 4096], random slot permutation
   config 3  Llama-3-8B head shape, bs = 64 ragged prefill, prompt lengths U[128, 4096]
+  config 4  Llama-3-70B at TP = 8, one rank's head shape (Hq 8 / Hkv 1), bs = 128 decode, contexts U[128, 4096]
+
+The decode cases run the form that SHIPS: split plan + separate merge launch, K/V as the two strided views of one
+interleaved [P+1, 2, Hkv, D] arena, non-temporal gathers at the library's default.
 
 16-bit outputs are held to the error model of helpers.attn_error_units (units of u * (|ref| + A))."""
 import pytest
@@ -24,14 +28,19 @@ def nat():
     return _native
 
 
-def big_pool(seed, lens, dtype, extra=64):
-    """K/V pools and a fragmented req_to_token for the given context lengths, generated on the GPU."""
+def big_pool(seed, lens, dtype, extra=64, hkv=HKV):
+    """K/V pools and a fragmented req_to_token for the given context lengths, generated on the GPU.  The pool is
+    what MHATokenToKVPool._create_buffers makes for one layer by default: ONE arena [P+1, 2, Hkv, D] (a token's K row
+    and V row adjacent) whose two strided views are the K and the V buffer the kernels are handed."""
     g = torch.Generator(device=DEV).manual_seed(seed)
     gc = torch.Generator().manual_seed(seed)
     total = sum(lens)
     P = total + extra
-    kb = torch.empty(P + 1, HKV, D, dtype=dtype, device=DEV).normal_(0, 1, generator=g)
-    vb = torch.empty(P + 1, HKV, D, dtype=dtype, device=DEV).normal_(0, 1, generator=g)
+    arena = torch.empty(P + 1, 2, hkv, D, dtype=dtype, device=DEV)
+    arena[:, 0].copy_(torch.empty(P + 1, hkv, D, dtype=dtype, device=DEV).normal_(0, 1, generator=g))
+    arena[:, 1].copy_(torch.empty(P + 1, hkv, D, dtype=dtype, device=DEV).normal_(0, 1, generator=g))
+    kb, vb = arena[:, 0], arena[:, 1]
+    assert kb.stride(0) == vb.stride(0) == 2 * hkv * D and not kb.is_contiguous()
     perm = (torch.randperm(P, generator=gc) + 1).to(torch.int32)
     bs = len(lens)
     r2t = torch.zeros(bs, max(lens) + 8, dtype=torch.int32)
@@ -42,6 +51,16 @@ def big_pool(seed, lens, dtype, extra=64):
     return kb, vb, r2t.to(DEV)
 
 
+def relocate(kb, vb, r2t, gen):
+    """every row of the pool (and the table) moved to another slot, in a second interleaved arena"""
+    P1, hkv = kb.shape[0], kb.shape[1]
+    perm = torch.randperm(P1 - 1, generator=gen).to(DEV) + 1
+    perm = torch.cat([torch.zeros(1, dtype=torch.int64, device=DEV), perm])
+    arena2 = torch.empty(P1, 2, hkv, D, dtype=kb.dtype, device=DEV)
+    arena2[perm, 0], arena2[perm, 1] = kb, vb
+    return arena2[:, 0], arena2[:, 1], perm[r2t.long()].to(torch.int32)
+
+
 def oracle_rows(q_rows, kb, vb, r2t, req_rows, seq_rows, abs_v=False):
     """fp32 oracle for single query rows: row i attends to the first seq_rows[i] keys of request req_rows[i]."""
     v = vb.float().cpu()
@@ -50,59 +69,72 @@ def oracle_rows(q_rows, kb, vb, r2t, req_rows, seq_rows, abs_v=False):
 
 
 def run_decode(nat, q, kb, vb, r2t, req, seq, chunk, plan=True):
-    bs = q.shape[0]
+    """THE SHIPPED FORM (HipAttnBackend's default): a split plan built once per step (the kernels read the split size
+    from it), the matrix-core kernel writing split partials, and the separate merge launch; non-temporal gathers as
+    the library defaults them.  plan=False: the plan-less static (request, split) grid."""
+    bs, hq = q.shape[0], q.shape[1]
     max_len = int(seq.max())
-    ws = torch.empty(nat.decode_workspace_bytes(bs, HQ, D, max_len, chunk), dtype=torch.uint8, device=DEV)
+    ws = torch.empty(nat.decode_workspace_bytes(bs, hq, D, max_len, chunk), dtype=torch.uint8, device=DEV)
     o = torch.full_like(q, float("nan"))
     pl = None
     if plan:
-        pl = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, fuse_groups=kb.shape[1]) // 4, dtype=torch.int32, device=DEV)
-        nat.decode_plan(pl, seq, max_len, chunk, fuse_groups=kb.shape[1])         # as HipAttnBackend: fused split merge
-    nat.decode_attention(o, q, kb, vb, r2t, req, seq, SCALE, 0.0, max_len, chunk, ws, None, pl,
-                         plan_fuse_groups=kb.shape[1] if plan else 0)
+        pl = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk) // 4, dtype=torch.int32, device=DEV)
+        nat.decode_plan(pl, seq, max_len, chunk)
+    nat.decode_attention(o, q, kb, vb, r2t, req, seq, SCALE, 0.0, max_len, chunk, ws, None, pl)
     return o
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f16"])
-def test_config2_decode_bs256_full_size(nat, dt):
+def full_size_decode_checks(nat, dt, bs, hq, hkv, rows, what):
+    """contexts U[128, 4096] seed 0 (bench.py's), random slot permutation, interleaved arena; (a) spot rows against
+    the fp32 oracle, (b) split invariance, (c) slot relocation bit-exact, (d) request-order invariance bit-exact"""
     dtype = DTYPES[dt]
     gen = torch.Generator().manual_seed(0)
-    bs = 256
-    lens = torch.randint(128, 4097, (bs,), generator=gen).tolist()       # bench.py's contexts (seed 0)
-    lens[3], lens[200] = 4096, 128
-    kb, vb, r2t = big_pool(2, lens, dtype)
-    q = torch.randn(bs, HQ, D, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)).to(dtype)
+    lens = torch.randint(128, 4097, (bs,), generator=gen).tolist()
+    lens[3], lens[bs - 56] = 4096, 128
+    kb, vb, r2t = big_pool(2, lens, dtype, hkv=hkv)
+    q = torch.randn(bs, hq, D, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)).to(dtype)
     req = torch.arange(bs, device=DEV)
     seq = torch.tensor(lens, device=DEV)
     o512 = run_decode(nat, q, kb, vb, r2t, req, seq, 512)
     assert torch.isfinite(o512.float()).all()
-    # (a) 8 spot rows against the fp32 oracle, error model without a max-scaled allowance
-    rows = [0, 3, 17, 64, 129, 200, 254, 255]
+    # (a) spot rows against the fp32 oracle, error model without a max-scaled allowance
     ref = oracle_rows(q[rows], kb, vb, r2t, rows, [lens[i] for i in rows])
     aref = oracle_rows(q[rows], kb, vb, r2t, rows, [lens[i] for i in rows], abs_v=True)
-    assert_attn_close(o512[rows], ref, aref, dtype, what=f"config 2 bs=256 {dt}: 8 rows vs oracle")
+    assert_attn_close(o512[rows], ref, aref, dtype, what=f"{what} {dt}: {len(rows)} rows vs oracle")
     # (b) split invariance at full size: the split size changes the partial sums, not the softmax; each
     # result is within the model of the oracle rows, and the two roundings differ by at most 2 units
     # (768: the split cap HipAttnBackend ships since round 4; 4096: every request in ONE split - what the backend
-    # picks for near-uniform batches - so no partials and no merge at all)
+    # picks for near-uniform batches - so no partials and no merge at all; 256 also runs plan-less)
+    u = {torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8}[dtype]
     for chunk in (64, 256, 768, 4096):
-        oc = run_decode(nat, q, kb, vb, r2t, req, seq, chunk, plan=chunk != 256)
-        assert_attn_close(oc[rows], ref, aref, dtype, what=f"config 2 {dt}: chunk {chunk} rows vs oracle")
+        oc = run_decode(nat, q, kb, vb, r2t, req, seq, chunk)
+        assert_attn_close(oc[rows], ref, aref, dtype, what=f"{what} {dt}: chunk {chunk} rows vs oracle")
         diff = (oc.float() - o512.float()).abs()
-        u = {torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8}[dtype]
         assert float(diff.max()) <= 2.5 * u * float(vb.float().abs().max()), f"chunk {chunk} vs 512: {float(diff.max()):.3e}"
+        if chunk == 256:
+            assert torch.equal(run_decode(nat, q, kb, vb, r2t, req, seq, chunk, plan=False), oc), "plan-less grid"
     # (c) KV page indexing is bit-exact: relocate every row of the pool (and the table) - same bits
-    P1 = kb.shape[0]
-    perm = torch.randperm(P1 - 1, generator=gen).to(DEV) + 1
-    perm = torch.cat([torch.zeros(1, dtype=torch.int64, device=DEV), perm])
-    kb2, vb2 = torch.empty_like(kb), torch.empty_like(vb)
-    kb2[perm], vb2[perm] = kb, vb
-    r2t2 = perm[r2t.long()].to(torch.int32)
+    kb2, vb2, r2t2 = relocate(kb, vb, r2t, gen)
     assert torch.equal(run_decode(nat, q, kb2, vb2, r2t2, req, seq, 512), o512)
     # (d) request-order invariance: a permuted batch gives the permuted rows, bit for bit
     order = torch.randperm(bs, generator=gen).to(DEV)
     o_perm = run_decode(nat, q[order].contiguous(), kb, vb, r2t, req[order].contiguous(), seq[order].contiguous(), 512)
     assert torch.equal(o_perm, o512[order])
+    # (e) the layout is not part of the result: the same rows in two separate contiguous K / V buffers - same bits
+    assert torch.equal(run_decode(nat, q, kb.contiguous(), vb.contiguous(), r2t, req, seq, 512), o512)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_config2_decode_bs256_full_size(nat, dt):
+    """config 2: Llama-3-8B heads, bs 256 - the HPW branch of decode_mfma_kernel (a wave per kv head)"""
+    full_size_decode_checks(nat, dt, 256, HQ, HKV, [0, 3, 17, 64, 129, 200, 254, 255], "config 2 bs=256")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_config4_rank_shape_decode_bs128_full_size(nat, dt):
+    """config 4's per-rank shape (Llama-3-70B at TP = 8: Hq 8 / Hkv 1, bs 128): the non-HPW branch of
+    decode_mfma_kernel - the 4 waves share one head's keys and merge (m, l, O) through LDS behind two barriers"""
+    full_size_decode_checks(nat, dt, 128, 8, 1, [0, 3, 17, 64, 72, 100, 126, 127], "config 4 rank shape bs=128")
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])

@@ -84,3 +84,29 @@ def test_ops_refuse_host_tensors():
         _native.rmsnorm(torch.zeros(2, 64), torch.ones(64), 1e-5)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _native.silu_and_mul(torch.zeros(2, 64))
+
+
+def test_kv_pool_views_are_checked_before_a_launch():
+    """the ABI carries ONE token stride for K and V and assumes contiguous heads per token; the wrappers
+    refuse anything else instead of gathering garbage (host-side check, no launch)."""
+    import torch
+    from scratchpad_amd import _native
+    from scratchpad_amd.pool import MHATokenToKVPool
+    for interleave in (True, False):
+        old = MHATokenToKVPool.interleave_kv
+        MHATokenToKVPool.interleave_kv = interleave
+        try:
+            pool = MHATokenToKVPool(10, 1, torch.bfloat16, 2, 64, 2, "cpu")
+        finally:
+            MHATokenToKVPool.interleave_kv = old
+        _native._kv_layout(pool.get_key_buffer(1), pool.get_value_buffer(1), "test")          # both layouts pass
+    k = torch.zeros(11, 2, 64)
+    with pytest.raises(RuntimeError, match="same token stride"):
+        _native._kv_layout(k, torch.zeros(11, 4, 64)[:, :2], "test")
+    _native._kv_layout(k, torch.zeros(11, 4, 64)[:, :2], "test", same_stride=False)           # the store takes two strides
+    with pytest.raises(RuntimeError, match="contiguous heads"):
+        _native._kv_layout(k, torch.zeros(11, 64, 2).transpose(1, 2), "test")
+    with pytest.raises(RuntimeError, match="contiguous heads"):
+        _native._kv_layout(torch.zeros(11, 2, 128)[:, :, :64], k, "test")
+    with pytest.raises(RuntimeError, match="disagree"):
+        _native._kv_layout(k, torch.zeros(12, 2, 64), "test")
