@@ -1005,9 +1005,8 @@ def main():
         alg = attention_algorithmic_bytes(cfg, sums[-1], args.bs, kv_elem)     # the replayed step's lengths
         achieved = alg / (avg_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(alg, args)
-        fused = bool(mr.attn_backend._fuse(args.bs))
         roofline = {"bound": "hbm",
-                    "kernel": "decode_mfma_kernel (merges its splits: no merge launch)" if fused else "decode_mfma_kernel+decode_merge_kernel",
+                    "kernel": "decode_mfma_kernel+decode_merge_kernel",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "traffic_source": traffic_src,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 6
+#define SP_ABI_VERSION 7
 #define SP_API __attribute__((visibility("default")))
 
 typedef enum { SP_F32 = 0, SP_F16 = 1, SP_BF16 = 2, SP_FP8_E5M2 = 3 /* KV pool only */ } sp_dtype;
@@ -60,7 +60,8 @@ SP_API const char* sp_status_string(int status);
  * tokens; the two forms agree bit for bit), "ar_fused_blocks", "skinny_nt".  Nothing on the call path reads the environment.  Returns
  * SP_ERR_INVALID_ARG for an unknown key.                                                          */
 SP_API int sp_debug_set(const char* key, int value);
-/* Read-only counterpart (ABI 6): "w64_descriptor_patched" (1 = the build's descriptor patch was applied, the
+/* Read-only counterpart (ABI 6): "w64_descriptor_patched" (1 = extend_w64.hip was built in stages with its kernels'
+ * register allocation fixed at assembly level - scratchpad_amd/build.py compile_w64 - and the
  * 4-wave x 64-row extend kernels may launch; anything else: sp_extend_attention keeps to the 8-wave kernel),
  * "extend_last_kernel" (what the last sp_extend_attention call launched: 1 = 8-wave matrix-core kernel, 2 = 4-wave
  * x 64-row kernel, 3 = its persistent form, 4 = row streams on the decode kernel, 0 = none yet).  -1: unknown key. */
@@ -143,12 +144,12 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  *
  * Split-KV geometry (ABI 4).  A request is cut into splits of `chunk` keys; split c of request b writes
  * its partial (o, log-sum-exp) to SLOT slot0[b] + c of the workspace ([Hq, max_slots, D] + [Hq, max_slots]
- * floats) and one merge wave per (request, head) combines them - in a second launch, or (ABI 6, plans built
- * with fuse_groups > 0) inside the attention kernel: the workgroup whose partials arrive last for a (request,
- * kv head) combines them, in the same order and to the same bits as the merge launch.
+ * floats) and one merge wave per (request, head) combines them in a second launch.  (ABI 6 could also merge inside
+ * the attention kernel through arrival counters in the plan; measured slower wherever graphs replay, removed in
+ * ABI 7: a plan is read-only for the launches that use it, so launches on several streams may share one.)
  *   - Without a plan the grid is the static (request, split) rectangle: slot0[b] = b * num_splits,
  *     num_splits = ceil(max_seq_len / chunk), max_slots is ignored (= batch_size * num_splits).
- *   - With a `plan` (sp_decode_plan: [count, chunk, needed, keys | slot0[bs] | (b, c) x max_slots | counters], built once per step from
+ *   - With a `plan` (sp_decode_plan: [count, chunk, needed, keys | slot0[bs] | (b, c) x max_slots], built once per step from
  *     the same seq_lens and shared by all layers - the counterpart of flashinfer's begin_forward()/plan,
  *     flashinfer_backend.py:623-670, and of TritonAttnBackend.init_forward_metadata,
  *     triton_backend.py:48-68) the launch covers `max_slots` work items, the kernels read the split size
@@ -162,13 +163,6 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  *     batches); a plan never changes the result, only which workgroup computes which split.
  * workspace: sp_decode_attention_workspace_bytes(max_slots, ...); plan: sp_decode_plan_bytes().
  *
- * `fuse_groups` (sp_decode_plan_bytes / sp_decode_plan) > 0 appends fuse_groups arrival counters per request to the
- * plan, zeroed by every sp_decode_plan; pass the largest num_kv_heads of the layers that will use the plan, and
- * the same value as `plan_fuse_groups` to sp_decode_attention, which then merges inside the matrix-core kernel
- * (16-bit dtypes; other dtypes and workspaces of 2 GiB or more keep the merge launch).  The counters make a plan
- * single-stream: launches that share a plan must be ordered on one stream, and a launch that was aborted leaves
- * them dirty until the next sp_decode_plan.  0 = no counters, separate merge launch.
- *
  * Overflow (ABI 6).  The plan's word 2 holds the number of items the lengths NEED; when it exceeds `max_slots`
  * (the caller's bound on sum(seq_lens) was too small) the surplus splits are not computed and the affected
  * output rows are wrong or unwritten.  Nothing on the device reports this by itself: the caller reads plan[2]
@@ -178,8 +172,8 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  * When a launch's K + V bytes (that sum x 2 x num_kv_heads x head_dim x element size) reach a threshold
  * (sp_debug_set("decode_nt_min_mb", n); 0 = always, -1 = never, -2 = the default) the matrix-core kernel gathers K/V rows with
  * NON-TEMPORAL loads: rows read once per step no longer displace the rest of the step's data from the caches.  It is plan
- * data, so a captured launch follows each step's own size; results are the same bits either way; plan-less launches
- * use plain loads.
+ * data, so a captured launch follows each step's own size; results are the same bits either way.  A plan-less launch
+ * has no key count: it streams only when the threshold is 0 ("always", the default).
  *
  * `kv_dtype` = `dtype`, or SP_FP8_E5M2 for a uint8 pool written by sp_kv_store_fp8 (16-bit q
  * only; kv_buffer_stride then counts bytes): the kernels widen e5m2 to half exactly and compute
@@ -191,10 +185,9 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  * k / k_scale and v / v_scale, so logits are multiplied by k_scale and the output by v_scale.    */
 SP_API int64_t sp_decode_plan_slots(int batch_size, int64_t kv_tokens, int64_t max_seq_len, int chunk);
 SP_API size_t sp_decode_attention_workspace_bytes(int64_t max_slots, int num_q_heads, int v_head_dim);
-SP_API size_t sp_decode_plan_bytes(int batch_size, int64_t max_slots, int fuse_groups);
+SP_API size_t sp_decode_plan_bytes(int batch_size, int64_t max_slots);
 SP_API int sp_decode_plan(int32_t* plan, size_t plan_bytes, const void* seq_lens, int idx64,
-                   int batch_size, int64_t max_seq_len, int chunk, int64_t max_slots, int fuse_groups,
-                   void* stream);
+                   int batch_size, int64_t max_seq_len, int chunk, int64_t max_slots, void* stream);
 SP_API int sp_decode_attention(void* out, const void* q, const void* k_buffer, const void* v_buffer,
                         const int32_t* req_to_token, int64_t req_to_token_stride,
                         const void* req_pool_indices, const void* seq_lens, const void* kv_start,
@@ -202,7 +195,7 @@ SP_API int sp_decode_attention(void* out, const void* q, const void* k_buffer, c
                         int head_dim, int64_t q_stride, int64_t out_stride,
                         int64_t kv_buffer_stride, float sm_scale, float logit_cap, float k_scale,
                         float v_scale, int64_t max_seq_len, int chunk, int64_t max_slots, void* workspace,
-                        size_t workspace_bytes, const int32_t* plan, int plan_fuse_groups, int dtype,
+                        size_t workspace_bytes, const int32_t* plan, int dtype,
                         int kv_dtype, void* stream);
 
 /* ---- Ragged extend (prefill) attention: replaces extend_attention_fwd (nn/attention/

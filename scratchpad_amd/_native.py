@@ -66,11 +66,11 @@ SIGNATURES = {
     "sp_clamp_position": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "sp_decode_plan_slots": (_i64, [_i32, _i64, _i64, _i32]),
     "sp_decode_attention_workspace_bytes": (_sz, [_i64, _i32, _i32]),
-    "sp_decode_plan_bytes": (_sz, [_i32, _i64, _i32]),
-    "sp_decode_plan": (_i32, [_vp, _sz, _vp, _i32, _i32, _i64, _i32, _i64, _i32, _vp]),
+    "sp_decode_plan_bytes": (_sz, [_i32, _i64]),
+    "sp_decode_plan": (_i32, [_vp, _sz, _vp, _i32, _i32, _i64, _i32, _i64, _vp]),
     "sp_decode_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32,
                                    _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _i64, _i32, _i64,
-                                   _vp, _sz, _vp, _i32, _i32, _i32, _vp]),
+                                   _vp, _sz, _vp, _i32, _i32, _vp]),
     "sp_extend_attention_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32]),
     "sp_extend_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp,
                                    _i32, _i64, _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32, _f32, _f32,
@@ -119,7 +119,7 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.sp_abi_version() != 6:
+    if lib.sp_abi_version() != 7:
         raise RuntimeError("libscratchpad_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -365,19 +365,17 @@ def decode_workspace_bytes(bs: int, Hq: int, Dv: int, max_seq_len: int, chunk: i
 PLAN_HEADER_WORDS = 4          # [items listed, chunk, items the lengths need, keys the step gathers per kv head]
 
 
-def decode_plan_bytes(bs: int, max_seq_len: int, chunk: int, max_slots: Optional[int] = None,
-                      fuse_groups: int = 0) -> int:
+def decode_plan_bytes(bs: int, max_seq_len: int, chunk: int, max_slots: Optional[int] = None) -> int:
     if max_slots is None:
         max_slots = decode_plan_slots(bs, max_seq_len, chunk)
-    return int(load().sp_decode_plan_bytes(bs, max_slots, fuse_groups))
+    return int(load().sp_decode_plan_bytes(bs, max_slots))
 
 
 def decode_plan(plan: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int, chunk: int,
-                max_slots: Optional[int] = None, fuse_groups: int = 0) -> None:
-    """Fill `plan` (int32: [count, chunk, needed, keys | slot0[bs] | (request, split) x max_slots | counters]) for this
+                max_slots: Optional[int] = None) -> None:
+    """Fill `plan` (int32: [count, chunk, needed, keys | slot0[bs] | (request, split) x max_slots]) for this
     step's lengths.  `max_slots`: the item / partial-slot capacity the launches using this plan are given (default:
-    the static bound bs * ceil(max_seq_len / chunk)).  `fuse_groups` > 0 (the layers' kv head count): the plan
-    carries arrival counters and decode_attention(plan_fuse_groups=...) merges the splits inside the kernel.
+    the static bound bs * ceil(max_seq_len / chunk)).
     plan[2] > max_slots afterwards means the capacity was too small (see decode_plan_overflow)."""
     _gpu(plan, seq_lens)
     if plan.dtype != torch.int32 or seq_lens.dtype not in (torch.int32, torch.int64):
@@ -387,7 +385,7 @@ def decode_plan(plan: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int, ch
         max_slots = decode_plan_slots(seq_lens.shape[0], max_seq_len, chunk)
     _check(load().sp_decode_plan(plan.data_ptr(), plan.numel() * 4, seq_lens.data_ptr(),
                                  int(seq_lens.dtype == torch.int64), seq_lens.shape[0], max_seq_len,
-                                 chunk, max_slots, fuse_groups, _stream()), "sp_decode_plan")
+                                 chunk, max_slots, _stream()), "sp_decode_plan")
 
 
 def decode_plan_overflow(header, max_slots: int) -> Optional[str]:
@@ -407,12 +405,10 @@ def decode_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
                      logit_cap: float, max_seq_len: int, chunk: int, workspace: torch.Tensor,
                      kv_start: Optional[torch.Tensor] = None,
                      plan: Optional[torch.Tensor] = None, k_scale: Optional[float] = None,
-                     v_scale: Optional[float] = None, max_slots: Optional[int] = None,
-                     plan_fuse_groups: int = 0) -> None:
+                     v_scale: Optional[float] = None, max_slots: Optional[int] = None) -> None:
     """q, out: [bs, Hq, D] (row stride free); buffers [P+1, Hkv, D].  k_scale / v_scale: the
     scales the store divided by (None = 1).  With a plan: `max_slots` = the capacity the plan was built
-    for, `chunk` = the smallest split size the plan may carry (the kernels read the actual one from it),
-    `plan_fuse_groups` = the fuse_groups the plan was built with (0: separate merge launch)."""
+    for, `chunk` = the smallest split size the plan may carry (the kernels read the actual one from it)."""
     _gpu(out, q, k_buffer, v_buffer, req_to_token, req_pool_indices, seq_lens, workspace, kv_start, plan)
     bs, Hq, D = q.shape
     if q.stride(2) != 1 or q.stride(1) != D or out.stride(2) != 1 or out.stride(1) != D:
@@ -432,7 +428,7 @@ def decode_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
         k_buffer.shape[1], D, q.stride(0), out.stride(0), k_buffer.stride(0), sm_scale, logit_cap,
         1.0 if k_scale is None else float(k_scale), 1.0 if v_scale is None else float(v_scale),
         max_seq_len, chunk, max_slots, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
-        _ptr(plan), int(plan_fuse_groups) if plan is not None else 0, _dt(q), kv_dt, _stream()), "sp_decode_attention")
+        _ptr(plan), _dt(q), kv_dt, _stream()), "sp_decode_attention")
 
 
 def extend_workspace_bytes(num_tokens: int, bs: int, Hq: int, D: int, dtype: torch.dtype) -> int:

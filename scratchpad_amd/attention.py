@@ -105,41 +105,13 @@ class HipAttnBackend(AttentionBackend):
     Constructed with a ``model_runner`` like the reference's backends (reads ``model_config``,
     ``tp_size``, ``token_to_kv_pool``, ``req_to_token_pool``, ``device``)."""
 
-    # work items (request x split x head-group) we want per launch: one per CU.  Measured sweep
-    # (tools/bench_decode_attn.py, bs 1-128 x ctx 1024/4096): fewer, longer workgroups win as soon
-    # as every CU has one - the per-workgroup prologue (index -> gather -> first tile) is amortised
-    # over more tiles - e.g. bs 32 x 1024: chunk 256 (256 items) 28.5 us vs chunk 64 (1024) 34.1 us.
-    # MAX_CHUNK caps the split (load balance of ragged batches).  512 until round 4; re-measured then in the model
-    # (profiles/r04_decode_variants.txt section 5, same box, 512 -> 1024): headline 13.11 / 12.98 -> 13.08 / 12.93 k
-    # tokens/s (noise), ctx 1024 18.68 -> 19.48 k (+4.3 %, attention 212 -> 196 us), ctx 4096 +1.6 %, 70B rank shape
-    # +1.2 % (attention 40.6 -> 38.8 us), bs 128 +1.0 %, fp8 KV +2.0 %, bs 64 -1.5 %; 2048 is worse again (ctx 2048
-    # -2 %, bs 32 x ctx 4096 -5 %).  Then 1024 -> 768 (the cap need not be a power of two; sections 5c / 5d, one box
-    # each): headline 13.12 / 13.13 -> 13.14 / 13.20 k (attention 391 -> 388 us), bs 128 +1.4 %, bs 64 +1.0 %, 70B rank
-    # shape +0.9 % (attention 37.8 -> 36.7 us), fp8 KV +0.9 %; 640 and 896 are worse at the headline (12.97 / 13.07 k
-    # against 13.11).  Tuned on contexts U[128, 4096]; near-uniform batches do not use it (_plan_chunk).
-    # TARGET_ITEMS 128 measured 2 - 11 % slower on bs 8 - 64 x ctx 1024 / 4096, 512 within +-1.5 % of 256.
-    # SP_DECODE_MAX_CHUNK / SP_DECODE_MIN_CHUNK / SP_DECODE_TARGET_ITEMS override them for such A/B runs (MIN_CHUNK 32 / 16 measured equal or slower
-    # at bs 1 - 8: 3.952 / 3.965 / 4.004 ms per step at bs 1; 4.126 / 4.238 / 4.240 at bs 1 x ctx 4096).
-    TARGET_ITEMS = int(os.environ.get("SP_DECODE_TARGET_ITEMS", "256"))
-    MIN_CHUNK, MAX_CHUNK = int(os.environ.get("SP_DECODE_MIN_CHUNK", "64")), int(os.environ.get("SP_DECODE_MAX_CHUNK", "768"))
-    # graph replay: work items / partial slots a captured launch of bucket bs covers (the launch geometry is
-    # a function of this number only; the split size travels in the step's plan).  max(1024, 8 bs) + bs keeps
-    # 512-key splits up to a mean context of 4096 per request and lets the splits grow beyond that, so the
-    # scratch does not scale with the model's context length (131072-token contexts: the same 38 MB)
+    # Launch-planning constants; the measurements behind each value are in profiles/NOTES.md ("attention.py constants").
+    TARGET_ITEMS = int(os.environ.get("SP_DECODE_TARGET_ITEMS", "256"))     # work items per launch: about one per CU
+    MIN_CHUNK = int(os.environ.get("SP_DECODE_MIN_CHUNK", "64"))            # smallest split (keys)
+    MAX_CHUNK = int(os.environ.get("SP_DECODE_MAX_CHUNK", "768"))           # split cap: load balance of ragged batches
+    # graph replay: a captured launch of bucket bs covers max(FLOOR, PER_REQ x bs) + bs work items / partial slots
     GRAPH_SLOTS_FLOOR, GRAPH_SLOTS_PER_REQ = 1024, 8
-    # LlamaAttention may hand rotary + KV store to the backend as one kernel (sp_rotary_embedding
-    # with pool arguments); set False to keep the reference's two-step order
-    fused_rope_kv_store = True
-    # the decode kernel can merge its split partials itself (plans with arrival counters: no merge launch; ABI 6).
-    # Measured in round 4 and NOT the default (profiles/r04_decode_variants.txt): the workgroup that stores a partial
-    # has to see its stores acknowledged and then its arrival count returned before it may leave - two memory round
-    # trips with the workgroup's slot held - and the last arriver's fence + merge runs on one workgroup where the merge
-    # launch spreads over the chip.  Under HIP-graph replay (a kernel boundary is cheap there) the step is slower
-    # fused at every batch size tried: bs 1 4.14 vs 4.00 ms, bs 8 4.68 vs 4.55, bs 256 20.03 vs 19.4 - 19.7 (attention
-    # 0.404 vs 0.386 - 0.395 ms per layer); only back-to-back eager launches of a few dozen workgroups gain (bs 1:
-    # 17.0 vs 20.0 us).  SP_DECODE_FUSE_MERGE=1 forces it on, "auto" = for batches of at most FUSE_MAX_BS requests.
-    fused_split_merge = os.environ.get("SP_DECODE_FUSE_MERGE", "0")
-    FUSE_MAX_BS = 8
+    fused_rope_kv_store = True      # rotary + KV store as one kernel; False keeps the reference's two-step order
     # True: every plan's overflow word is read back right after it is built (one device sync per step: tests,
     # debugging).  False: the 16-byte header is copied to pinned memory asynchronously and checked when the
     # NEXT plan is built, or by check_plans() - an understated seq_lens_sum raises one step late instead of never
@@ -171,8 +143,6 @@ class HipAttnBackend(AttentionBackend):
         self._graph_plans = None
         self._extend_plan = None       # int32 work list of the current extend step (sp_extend_plan)
         self.replay_max_hint = None    # set by HipGraphRunner.replay for the next replay hook call
-        # arrival counters every plan carries (their use is decided per launch: _fuse)
-        self._plan_groups = self.num_kv_head if str(self.fused_split_merge) not in ("0", "False") else 0
         self._plan_checks = []         # (pinned header copy, event, max_slots) of plans not yet checked
         self._plan_hosts = []          # pinned buffers + events to reuse
 
@@ -250,10 +220,10 @@ class HipAttnBackend(AttentionBackend):
             else:                          # graph replay: the captured launch's capacity is fixed
                 slots = max_slots
                 chunk = self._fit_chunk(chunk, bs, kv_tokens, max_len, slots)
-            need = _native.decode_plan_bytes(bs, max_len, chunk, slots, self._plan_groups) // 4
+            need = _native.decode_plan_bytes(bs, max_len, chunk, slots) // 4
             if plans[i].numel() < need:
                 plans[i] = torch.empty(need, dtype=torch.int32, device=self.device)
-            _native.decode_plan(plans[i], lens, max_len, chunk, slots, self._plan_groups)
+            _native.decode_plan(plans[i], lens, max_len, chunk, slots)
             self._watch_plan(plans[i], slots)
             # third field: the smallest split size this plan buffer may carry when the launch runs - the
             # step's own chunk (eager), MIN_CHUNK under graph replay (a later step's plan may use any size)
@@ -291,12 +261,6 @@ class HipAttnBackend(AttentionBackend):
         self._plan_checks = pending
         if err:
             raise RuntimeError(err)
-
-    def _fuse(self, bs: int) -> bool:
-        """whether a decode launch of `bs` requests merges its splits inside the attention kernel.  A function of the
-        batch size alone, so that a graph bucket's captured launches and every step's plan agree."""
-        mode = str(self.fused_split_merge)
-        return self._plan_groups > 0 and (mode in ("1", "True") or (mode == "auto" and bs <= self.FUSE_MAX_BS))
 
     def _windows(self, bs, seq_lens, seq_lens_sum, encoder_lens, encoder_sum):
         """(lens, bound on their sum) of the three kv windows of a decode step"""
@@ -366,7 +330,7 @@ class HipAttnBackend(AttentionBackend):
         self._graph_ws = torch.empty(_native.decode_workspace_bytes(max_bs, self.num_head, self.v_head_dim,
                                                                     self.cuda_graph_max_seq_len, self.MIN_CHUNK, slots),
                                      dtype=torch.uint8, device=self.device)
-        n = _native.decode_plan_bytes(max_bs, self.cuda_graph_max_seq_len, self.MIN_CHUNK, slots, self._plan_groups) // 4
+        n = _native.decode_plan_bytes(max_bs, self.cuda_graph_max_seq_len, self.MIN_CHUNK, slots) // 4
         self._graph_plans = [torch.empty(n, dtype=torch.int32, device=self.device) for _ in range(3)]
         self._graph_max_bs = max_bs
         if self.sliding_window_size is not None:
@@ -525,6 +489,5 @@ class HipAttnBackend(AttentionBackend):
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), kb, vb,
             forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices, seq_lens,
             layer.scaling, layer.logit_cap, max_len, chunk, ws, kv_start, plan,
-            k_scale=k_scale, v_scale=v_scale, max_slots=slots,
-            plan_fuse_groups=self._plan_groups if self._fuse(q.shape[0]) and layer.tp_k_head_num <= self._plan_groups else 0)
+            k_scale=k_scale, v_scale=v_scale, max_slots=slots)
         return o

@@ -25,30 +25,22 @@ struct DecodeArgs {
   float* part_o;    // [Hq, max_slots, D]   slot of (request b, split c): slot0[b] + c (a request's splits are adjacent)
   float* part_lse;  // [Hq, max_slots]      (log2 domain)
   int kv8;              // 1: the pool holds fp8 e5m2 bytes (kv_stride in bytes); 16-bit q/out only
-  // optional, from sp_decode_plan: [count, chunk, needed, keys | slot0[bs] | (b, c) x max_slots | arrival counters].
+  // optional, from sp_decode_plan: [count, chunk, needed, keys | slot0[bs] | (b, c) x max_slots].
   // The CHUNK is part of the plan (device memory), so a captured launch follows whatever split size the step's
   // plan was built with; slot0[b] = first partial slot of request b (exclusive scan of its split count);
   // needed = the item count BEFORE the cut at max_slots (needed > count: the host's bound on sum(seq_lens) was
   // broken and items were dropped - the host checks this word, see sp_decode_plan); keys = sum of the (clamped)
-  // lengths, i.e. the key rows this step's launches gather per kv head.
+  // lengths, i.e. the key rows this step's launches gather per kv head.  Read-only for every launch that uses it.
   const int32_t* plan;
-  // > 0: the plan carries fuse_groups arrival counters per request behind its items (zeroed by sp_decode_plan, reset
-  // by the last arriver): the matrix-core kernel merges a request's splits itself - the workgroup (wave, where a wave
-  // owns its heads) whose partials arrive last combines them - and no merge kernel is launched.  0: separate merge.
-  int fuse_groups;
   // K/V gathers of the matrix-core kernel are NON-TEMPORAL loads when the step reads at least this many keys in total
   // (plan[3], written by sp_decode_plan): a stream that is read once and is larger than the caches then no longer
   // displaces everything else in them, at the price of about a microsecond of latency per dependent round of gathers,
-  // which only a launch of several rounds of workgroups hides.  0 = always, INT_MAX = never; plan-less launches: never
-  // (unless 0).
+  // which only a launch of several rounds of workgroups hides.  0 = always (the default), INT_MAX = never; a plan-less
+  // launch has no key count and streams only when the threshold is 0.
   int nt_min_keys;
 };
 
 static constexpr int kPlanHdr = 4;   // int32 words in front of slot0[]
-
-__device__ __forceinline__ int32_t* decode_plan_counters(const DecodeArgs& a) {
-  return const_cast<int32_t*>(a.plan) + kPlanHdr + a.bs + 2 * (int64_t)a.max_slots;
-}
 
 // (request, split) of work item `item`, the split size, and the request's first partial slot
 __device__ __forceinline__ bool decode_item(const DecodeArgs& a, int item, int& b, int& c, int& chunk, int& slot0) {
@@ -71,8 +63,7 @@ __device__ __forceinline__ bool decode_item(const DecodeArgs& a, int item, int& 
 // Combine the split partials of U (request, q head) pairs by their log2-sum-exp: one wave, lane = output elements
 // lane, lane + 64 (D = 128).  The partials of up to 16 splits (log-sum-exp and the lane's output elements) are
 // loaded in one go - a single memory round trip instead of a max pass followed by a dependent accumulate pass -
-// and merged online across groups of 16.  Shared by decode_merge_kernel and by the fused merge of
-// decode_mfma_kernel, so that both produce the same bits (every product-sum is an explicit fma).
+// and merged online across groups of 16 (every product-sum is an explicit fma).
 // Partials are laid out [Hq][slot][D]: a request's splits are consecutive slots, so one (request, head)'s partials
 // are one contiguous run (with [slot][Hq][D] the merge read 512-byte pieces 16 KiB apart: 10.5 us instead of 6.8).
 template <typename Tag, int D, int U>

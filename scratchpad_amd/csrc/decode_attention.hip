@@ -288,8 +288,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeArgs a) {
 }
 
 // one wave per (request, q head): combine the split partials by their log2-sum-exp (decode_merge_rows).  The launch
-// is latency-bound at small batch (9 us for a few KB); the matrix-core kernel does this itself when the plan
-// carries arrival counters (DecodeArgs::fuse_groups).
+// is latency-bound at small batch (7 - 9 us for a few KB).
 template <typename Tag, int D>
 __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
   const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -311,22 +310,19 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
 // plan[2] = the number the lengths NEED (> plan[0]: items were cut at max_items because the host's bound on
 // sum(seq_lens) does not hold - an error the host reports, sp_decode_plan), plan[3] = 0,
 // plan[4 + b] = first partial slot of request b (exclusive scan of its split count), the items (b, c) from
-// plan[4 + bs], and behind the max_items item pairs bs x fuse_groups arrival counters, zeroed here, for the
-// attention kernel's own merge of the splits.  One workgroup; requests in tiles of 256 with a running offset.  Items are
+// plan[4 + bs].  One workgroup; requests in tiles of 256 with a running offset.  Items are
 // emitted longest-first: all full splits, then the ragged last splits in four length classes (longest
 // quarter first), so the launch ends on its shortest items.  The chunk travels IN the plan: the
 // attention and merge kernels read it from there, so one captured launch serves any split size.
 __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ plan,
                                                            const void* __restrict__ seq_lens,
                                                            int idx64, int bs, int chunk, int max_len,
-                                                           int max_items, int fuse_groups) {
+                                                           int max_items) {
   __shared__ int s_scan[256];
   __shared__ int s_base;
   __shared__ unsigned long long s_keys;
   if (threadIdx.x == 0) s_keys = 0;
   int32_t* items = plan + kPlanHdr + bs;
-  int32_t* counters = items + 2 * (int64_t)max_items;
-  for (int i = threadIdx.x; i < bs * fuse_groups; i += 256) counters[i] = 0;
   // pass -1: slot0[b]; pass 0: full splits; passes 1..4: ragged tails by length class
   for (int pass = -1; pass < 5; ++pass) {
     if (pass <= 0) {
@@ -484,11 +480,11 @@ int run_decode(const DecodeArgs& a, int head_dim, int group, int dtype, hipStrea
   if (a.kv8) {                       // fp8 pool: matrix-core kernel only
     if (a.Hq / a.Hkv > 16) return SP_ERR_UNSUPPORTED;
     const int rc = run_decode_mfma(a, head_dim, dtype, st);
-    return rc == SP_OK && a.fuse_groups == 0 ? run_decode_merge(a, head_dim, dtype, st) : rc;
+    return rc == SP_OK ? run_decode_merge(a, head_dim, dtype, st) : rc;
   }
   if (group > 8 || decode_kernel_choice(a.Hq / a.Hkv, dtype) == 2) {   // groups 9..16: matrix-core kernel only
     const int rc = run_decode_mfma(a, head_dim, dtype, st);
-    if (rc == SP_OK) return a.fuse_groups == 0 ? run_decode_merge(a, head_dim, dtype, st) : SP_OK;   // fused: the kernel merged
+    if (rc == SP_OK) return run_decode_merge(a, head_dim, dtype, st);
     if (rc != SP_ERR_UNSUPPORTED) return rc;
   }
   SP_DISPATCH_DTYPE(dtype, return (dispatch_dim<Tag>(a, head_dim, group, st)));
@@ -535,21 +531,19 @@ extern "C" SP_API int sp_debug_decode_occupancy(int head_dim, int group, int dty
   return decode_occupancy(head_dim, group, dtype);
 }
 
-extern "C" size_t sp_decode_plan_bytes(int batch_size, int64_t max_slots, int fuse_groups) {
+extern "C" size_t sp_decode_plan_bytes(int batch_size, int64_t max_slots) {
   if (batch_size <= 0 || max_slots <= 0) return 16;
-  if (fuse_groups < 0) fuse_groups = 0;
-  return (size_t)(kPlanHdr + (int64_t)batch_size + 2 * max_slots + (int64_t)batch_size * fuse_groups) * sizeof(int32_t);
+  return (size_t)(kPlanHdr + (int64_t)batch_size + 2 * max_slots) * sizeof(int32_t);
 }
 
 extern "C" int sp_decode_plan(int32_t* plan, size_t plan_bytes, const void* seq_lens, int idx64,
                               int batch_size, int64_t max_seq_len, int chunk, int64_t max_slots,
-                              int fuse_groups, void* stream) {
+                              void* stream) {
   SP_CHECK_ARG(plan && seq_lens && batch_size >= 0 && chunk >= 4 && chunk % 4 == 0);
   SP_CHECK_ARG(max_seq_len >= 0 && max_seq_len <= 0x7fffffffLL && max_slots > 0 && max_slots <= 0x3fffffffLL);
-  SP_CHECK_ARG(fuse_groups >= 0 && (int64_t)batch_size * fuse_groups <= 0x3fffffffLL);
-  if (plan_bytes < sp_decode_plan_bytes(batch_size, max_slots, fuse_groups)) return SP_ERR_WORKSPACE;
+  if (plan_bytes < sp_decode_plan_bytes(batch_size, max_slots)) return SP_ERR_WORKSPACE;
   decode_plan_kernel<<<dim3(1), 256, 0, (hipStream_t)stream>>>(plan, seq_lens, idx64, batch_size,
-                                                               chunk, (int)max_seq_len, (int)max_slots, fuse_groups);
+                                                               chunk, (int)max_seq_len, (int)max_slots);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
@@ -562,7 +556,7 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
                                    int64_t q_stride, int64_t out_stride, int64_t kv_buffer_stride,
                                    float sm_scale, float logit_cap, float k_scale, float v_scale,
                                    int64_t max_seq_len, int chunk, int64_t max_slots, void* workspace,
-                                   size_t workspace_bytes, const int32_t* plan, int plan_fuse_groups, int dtype,
+                                   size_t workspace_bytes, const int32_t* plan, int dtype,
                                    int kv_dtype, void* stream) {
   SP_CHECK_ARG(out && q && k_buffer && v_buffer && req_to_token && req_pool_indices && seq_lens);
   SP_CHECK_ARG(batch_size >= 0 && num_q_heads > 0 && num_kv_heads > 0 && head_dim > 0);
@@ -606,18 +600,12 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
   a.chunk = chunk; a.num_splits = (int)S; a.max_slots = (int)max_slots; a.plan = plan; a.kv8 = kv8 ? 1 : 0;
   a.hh_shift = decode_heads_per_load_shift(num_kv_heads, head_dim, dtype, &a.head_groups);
   a.part_o = nullptr; a.part_lse = nullptr;
-  // the kernel merges the splits itself when the plan carries one arrival counter per (request, kv head) - what
-  // sp_decode_plan was given as fuse_groups; the partials are then addressed through a buffer descriptor (32-bit offsets)
-  SP_CHECK_ARG(plan_fuse_groups >= 0 && (plan_fuse_groups == 0 || (plan && plan_fuse_groups >= num_kv_heads)));
-  a.fuse_groups = plan ? plan_fuse_groups : 0;
   {
     // bytes of K + V one key row costs this launch (all its kv heads)
     const int64_t key_bytes = 2LL * num_kv_heads * head_dim * (kv8 ? 1 : eb);
     a.nt_min_keys = g_decode_nt_min_mb < 0 ? 0x7fffffff
                                            : (int)(((int64_t)g_decode_nt_min_mb << 20) / key_bytes);   // (< 2^31: mb is an int)
   }
-  if (a.fuse_groups > 0 &&
-      sp_decode_attention_workspace_bytes(max_slots, num_q_heads, head_dim) >= 0x7fffffffULL) a.fuse_groups = 0;
   if (S > 1) {
     const size_t need = sp_decode_attention_workspace_bytes(max_slots, num_q_heads, head_dim);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) return SP_ERR_WORKSPACE;

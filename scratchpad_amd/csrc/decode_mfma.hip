@@ -119,9 +119,6 @@ struct DmCfg {
 // v_perm_b32 per two elements, exact), and the tile math runs in fp16 whatever the model dtype is
 // (bf16 q is converted once per workgroup; P is rounded to fp16); the output keeps the model dtype.
 // HBM bytes per context token halve; everything after the LDS tile is unchanged.
-#ifndef SP_DECODE_FUSED_MERGE
-#define SP_DECODE_FUSED_MERGE 1   // A/B switch (round 5): 0 compiles the in-kernel split merge out
-#endif
 template <typename Tag, int D, bool HPW, bool KV8>
 #ifndef SP_DEC_WAVES
 #define SP_DEC_WAVES 3
@@ -341,16 +338,10 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
     }
   }
   };
+  // (a plan-less launch has no key count to compare: it streams only when the threshold is "always", the default)
   const bool nt = a.plan ? a.plan[3] >= a.nt_min_keys : a.nt_min_keys == 0;
   if (nt) key_loop(std::true_type{}); else key_loop(std::false_type{});
 
-  // split partials: plain stores for the merge kernel; write-through (sc1) through a buffer descriptor when this
-  // kernel merges them itself (a.fuse_groups > 0) - written through, they need no release fence before the arrival
-  // count (cdna_hip_programming.md Guideline 16, R1; the host keeps the workspace below 2 GiB for the 32-bit offsets)
-  const bool fuse = SP_DECODE_FUSED_MERGE && a.fuse_groups > 0;
-  const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)a.part_o, 0, fuse ? (int)((int64_t)a.max_slots * a.Hq * (D + 1) * 4) : 0, 0x00020000);
-  const int nlive = min(nsplit, a.max_slots - slot0);     // splits of this request that run (all, unless the plan was cut)
   if constexpr (HPW) {
     // ---- this wave owns heads hk*G .. hk*G+G-1: normalise and write straight from registers
     //      (lane (col, kq) holds d = 16db + 4kq .. +3 of head col)
@@ -369,48 +360,13 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
         }
       } else {
         const int64_t pi = (int64_t)h * a.max_slots + (slot0 + c);
-        const float lse = m_run + __builtin_amdgcn_logf(l_run);
-        if (fuse) {
-          const int off = (int)((pi * D + 4 * kq) * 4);
+        float* pp = a.part_o + pi * D + 4 * kq;
 #pragma unroll
-          for (int db = 0; db < DBLK; ++db) {
-            u32x4 w;
-            w[0] = as_u32(oacc[db][0] * inv); w[1] = as_u32(oacc[db][1] * inv);
-            w[2] = as_u32(oacc[db][2] * inv); w[3] = as_u32(oacc[db][3] * inv);
-            __builtin_amdgcn_raw_buffer_store_b128(w, prs, off + 64 * db, 0, 16);
-          }
-          if (kq == 0)
-            __builtin_amdgcn_raw_buffer_store_b32(as_u32(lse), prs, (int)(((int64_t)a.max_slots * a.Hq * D + pi) * 4), 0, 16);
-        } else {
-          float* pp = a.part_o + pi * D + 4 * kq;
-#pragma unroll
-          for (int db = 0; db < DBLK; ++db)
-            *(float4*)(pp + 16 * db) = make_float4(oacc[db][0] * inv, oacc[db][1] * inv,
-                                                   oacc[db][2] * inv, oacc[db][3] * inv);
-          if (kq == 0) a.part_lse[pi] = lse;
-        }
+        for (int db = 0; db < DBLK; ++db)
+          *(float4*)(pp + 16 * db) = make_float4(oacc[db][0] * inv, oacc[db][1] * inv,
+                                                 oacc[db][2] * inv, oacc[db][3] * inv);
+        if (kq == 0) a.part_lse[pi] = m_run + __builtin_amdgcn_logf(l_run);
       }
-    }
-    if (!fuse || nsplit == 1) return;
-    // ---- fused merge, per wave (a wave owns its kv head outright): drain this wave's write-through partials, count
-    //      the wave in; the wave whose count completes the request's splits of this kv head combines them - in the
-    //      merge kernel's order, with its code - and resets the counter for the next launch on the stream
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    int32_t* ctr = decode_plan_counters(a) + (int64_t)b * a.fuse_groups + hk;
-    int old = 0;
-    if (lane == 0) old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    old = __builtin_amdgcn_readfirstlane(old);
-    if (old != nlive - 1) return;
-    if (lane == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // this CU's L1 may hold the slots' lines of an earlier launch
-    int g = 0;
-    for (; g + 2 <= G; g += 2) {
-      const int hs[2] = {hk * G + g, hk * G + g + 1};
-      decode_merge_rows<Tag, D, 2>(a, b, hs, lane, nlive, slot0);
-    }
-    if (g < G) {
-      const int hs[1] = {hk * G + g};
-      decode_merge_rows<Tag, D, 1>(a, b, hs, lane, nlive, slot0);
     }
     return;
   }
@@ -447,45 +403,9 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
       E::store(a.out, (int64_t)b * a.o_stride + (int64_t)h * D + d, o * a.out_scale);
     } else {
       const int64_t pi = (int64_t)h * a.max_slots + (slot0 + c);
-      const float lse = M + __builtin_amdgcn_logf(L);
-      if (fuse) {
-        __builtin_amdgcn_raw_buffer_store_b32(as_u32(o), prs, (int)((pi * D + d) * 4), 0, 16);
-        if (d == 0)
-          __builtin_amdgcn_raw_buffer_store_b32(as_u32(lse), prs, (int)(((int64_t)a.max_slots * a.Hq * D + pi) * 4), 0, 16);
-      } else {
-        a.part_o[pi * D + d] = o;
-        if (d == 0) a.part_lse[pi] = lse;
-      }
+      a.part_o[pi * D + d] = o;
+      if (d == 0) a.part_lse[pi] = M + __builtin_amdgcn_logf(L);
     }
-  }
-  if (!fuse || nsplit == 1) return;
-  // ---- fused merge, per workgroup: every wave drains its write-through partials, the barrier collects the waves,
-  //      one lane counts the workgroup in and tells the others (through the LDS area the waves have left) whether
-  //      its partials were the request's last for this kv head
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int32_t* ctr = decode_plan_counters(a) + (int64_t)b * a.fuse_groups + hk;
-  int* s_last = (int*)lds;
-  if (threadIdx.x == 0) {
-    const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = old == nlive - 1;
-    if (last) {
-      __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the invalidate has completed before the barrier opens
-    }
-    *s_last = last;
-  }
-  __syncthreads();
-  if (!*s_last) return;
-  int g = wave;
-  for (; g + WAVES < G; g += 2 * WAVES) {
-    const int hs[2] = {hk * G + g, hk * G + g + WAVES};
-    decode_merge_rows<Tag, D, 2>(a, b, hs, lane, nlive, slot0);
-  }
-  if (g < G) {
-    const int hs[1] = {hk * G + g};
-    decode_merge_rows<Tag, D, 1>(a, b, hs, lane, nlive, slot0);
   }
 }
 
@@ -512,7 +432,8 @@ static int launch_dm(const DecodeArgs& a, hipStream_t st) {
 }
 
 // 16-bit dtypes, D in {64,128}, G <= 16.  Launches the attention kernel only; the caller runs the
-// split merge (shared with the VALU path).
+// split merge (shared with the VALU path).  (An in-kernel merge by arrival counters existed in round 4, ABI 6: it
+// measured slower under graph replay at every batch size and was removed in round 5 - profiles/NOTES.md.)
 int run_decode_mfma(const DecodeArgs& a, int head_dim, int dtype, hipStream_t st) {
   const int G = a.Hq / a.Hkv;
   if (G > 16 || (dtype != SP_BF16 && dtype != SP_F16)) return SP_ERR_UNSUPPORTED;

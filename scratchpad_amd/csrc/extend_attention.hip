@@ -154,7 +154,7 @@ extern "C" int sp_debug_set(const char* key, int value) {
   return SP_ERR_INVALID_ARG;
 }
 
-// read-only counterpart: "w64_descriptor_patched" (1 = tools/patch_w64_descriptor.py has sized the 4-wave x 64-row
+// read-only counterpart: "w64_descriptor_patched" (1 = the staged build, build.py compile_w64, has sized the 4-wave x 64-row
 // kernels' register allocation in this library: they may launch), "extend_last_kernel" (see extend_api.h);
 // -1 for an unknown key
 extern "C" int sp_debug_get(const char* key) {
@@ -255,7 +255,7 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
   if (chunk > 0x7ffffff0LL) return SP_ERR_INVALID_ARG;
   a.chunk = (int)chunk; a.num_splits = 1; a.max_len = (int)chunk; a.max_slots = (int)num_tokens;
   a.hh_shift = decode_heads_per_load_shift(num_kv_heads, head_dim, dtype, &a.head_groups);
-  a.part_o = nullptr; a.part_lse = nullptr; a.plan = nullptr; a.kv8 = 0; a.fuse_groups = 0; a.nt_min_keys = 0x7fffffff;
+  a.part_o = nullptr; a.part_lse = nullptr; a.plan = nullptr; a.kv8 = 0; a.nt_min_keys = 0x7fffffff;
   g_extend_last_kernel = 4;
   return run_decode(a, head_dim, G, dtype, st);
 }

@@ -101,7 +101,7 @@ def oracle_logits(name, dtype):
 
 def run_w64_smoke():
     """One D = 128 launch of the 4-wave x 64-row extend kernels - the ones whose register allocation
-    tools/patch_w64_descriptor.py sizes in the linked library - against oracle.ops.extend_attention: a toolchain that
+    the staged build (build.py compile_w64 + tools/w64_asm.py) allocates in descriptor and metadata - against oracle.ops.extend_attention: a toolchain that
     laid their registers out differently than the kernels' text assumes shows up HERE (the tiny model above has
     D = 64 and never launches them).  Both forms: one workgroup per item, and persistent with a plan."""
     from scratchpad_amd import _native

@@ -32,10 +32,9 @@ def decode_kernel(request, nat):
     nat.debug_set("decode_kernel", 0)
 
 
-def run_decode(nat, p, scale, cap=0.0, chunk=64, max_len=None, kv_start=None, idx_dtype=None,
-               use_plan=True, fuse=True):
-    """use_plan + fuse (what HipAttnBackend does): the plan carries arrival counters and the matrix-core kernel merges
-    its splits itself; fuse=False or no plan: the separate merge launch"""
+def run_decode(nat, p, scale, cap=0.0, chunk=64, max_len=None, kv_start=None, idx_dtype=None, use_plan=True):
+    """use_plan (what HipAttnBackend does): the per-step split plan + the separate merge launch; without: the static
+    (request, split) grid"""
     q = p["q"]
     bs, Hq, D = q.shape
     seq, req = p["seq_lens"], p["req_pool_indices"]
@@ -46,14 +45,11 @@ def run_decode(nat, p, scale, cap=0.0, chunk=64, max_len=None, kv_start=None, id
     ws = torch.empty(nat.decode_workspace_bytes(bs, Hq, D, max_len, chunk), dtype=torch.uint8, device=DEV)
     o = torch.full_like(q, float("nan"))
     plan = None
-    groups = p["k_buffer"].shape[1] if (use_plan and fuse) else 0
     if use_plan:   # the per-step split plan the backend builds in init_forward_metadata
-        plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, fuse_groups=groups) // 4, dtype=torch.int32, device=DEV)
-        nat.decode_plan(plan, seq, max_len, chunk, fuse_groups=groups)
+        plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk) // 4, dtype=torch.int32, device=DEV)
+        nat.decode_plan(plan, seq, max_len, chunk)
     nat.decode_attention(o, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], req, seq, scale, cap,
-                         max_len, chunk, ws, kv_start, plan, plan_fuse_groups=groups)
-    if groups:   # the last arriver of every (request, kv head) has put its counter back to zero
-        assert int(plan[4 + bs + 2 * nat.decode_plan_slots(bs, max_len, chunk):].abs().sum()) == 0
+                         max_len, chunk, ws, kv_start, plan)
     return o
 
 
@@ -754,22 +750,19 @@ def test_decode_plan_fuzz_planned_equals_static_bit_for_bit(nat, seed):
         slots = nat.decode_plan_slots(bs, max_len, chunk, kv_tokens=int(lens.sum()))
         nsplit = (lens + chunk - 1) // chunk
         ws2 = torch.empty(nat.decode_workspace_bytes(bs, Hq, D, max_len, chunk, slots), dtype=torch.uint8, device=DEV)
-        # groups = 0: the merge launch; groups = Hkv: the attention kernel merges (launched three times on one plan:
-        # the arrival counters are put back by the last arriver, as between the layers of a step)
-        for groups in (0, Hkv):
-            plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, slots, groups) // 4, dtype=torch.int32, device=DEV)
-            nat.decode_plan(plan, s_, max_len, chunk, slots, groups)
-            host = plan.cpu()
-            assert int(host[0]) == int(host[2]) == int(nsplit.sum()) <= slots and int(host[1]) == chunk
-            assert int(host[3]) == int(lens.sum())
-            assert torch.equal(host[4:4 + bs].long(), torch.cumsum(nsplit, 0) - nsplit)
-            for rep in range(3 if groups else 1):
-                ws2.fill_(0x7f)                                # stale partials of "another layer"
-                o_plan = torch.zeros_like(q)
-                nat.decode_attention(o_plan, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], r_, s_, 0.09, 0.0,
-                                     max_len, chunk, ws2, k0, plan, max_slots=slots, plan_fuse_groups=groups)
-                assert torch.isfinite(o_plan.float()).all() and torch.equal(o_plan, o_static), (seed, idx_dtype, groups, rep)
-            assert int(plan[4 + bs + 2 * slots:].abs().sum()) == 0, "arrival counters are back at zero"
+        plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, slots) // 4, dtype=torch.int32, device=DEV)
+        nat.decode_plan(plan, s_, max_len, chunk, slots)
+        host = plan.cpu()
+        assert int(host[0]) == int(host[2]) == int(nsplit.sum()) <= slots and int(host[1]) == chunk
+        assert int(host[3]) == int(lens.sum())
+        assert torch.equal(host[4:4 + bs].long(), torch.cumsum(nsplit, 0) - nsplit)
+        for rep in range(2):                               # launch after launch on one plan, as the layers of a step
+            ws2.fill_(0x7f)                                # stale partials of "another layer"
+            o_plan = torch.zeros_like(q)
+            nat.decode_attention(o_plan, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], r_, s_, 0.09, 0.0,
+                                 max_len, chunk, ws2, k0, plan, max_slots=slots)
+            assert torch.isfinite(o_plan.float()).all() and torch.equal(o_plan, o_static), (seed, idx_dtype, rep)
+        assert torch.equal(plan.cpu(), host), "a launch leaves its plan untouched (ABI 7: the plan is read-only)"
     # and against the oracle on a handful of rows (the longest, an empty one, a one-token one)
     rows = [0, int((lens == 0).nonzero()[0]), int((lens == 1).nonzero()[0]), bs - 1]
     c = cpu(p)
@@ -825,12 +818,11 @@ def test_decode_streaming_gathers_change_no_bit(nat, kv, Hq, Hkv, D):
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("Hq,Hkv,D", [(8, 1, 128), (16, 2, 128), (16, 1, 128), (32, 8, 128), (4, 4, 128), (24, 4, 64),
                                       (6, 2, 64)])
-def test_decode_fused_merge_equals_the_merge_launch_bit_for_bit(nat, dt, Hq, Hkv, D):
-    """ABI 6: with arrival counters in the plan the matrix-core kernel combines a request's split partials itself (the
-    wave - head-per-wave form, Hkv % 4 == 0 - or the workgroup whose partials arrive last).  Same order, same code as
-    the merge launch: the same bits, on ragged batches (uneven load: arrivals out of order), with more than 16 splits
-    per request (the merge's online groups), on a workspace full of another launch's partials, launch after launch
-    on one plan."""
+def test_decode_merge_of_many_splits(nat, dt, Hq, Hkv, D):
+    """The merge launch on requests of 41 and 17 splits (its online groups of 16), of one and of two splits, in a ragged
+    batch, on a workspace full of another launch's partials: the planned launch gives the bits of the static
+    (request, split) grid, launch after launch on one plan, and both kernel forms (a wave per kv head where Hkv % 4 == 0,
+    else four waves sharing a head) agree with the oracle."""
     dtype = DTYPES[dt]
     g = torch.Generator().manual_seed(Hq * 131 + Hkv)
     bs, chunk, max_len = 96, 64, 2600
@@ -840,25 +832,20 @@ def test_decode_fused_merge_equals_the_merge_launch_bit_for_bit(nat, dt, Hq, Hkv
     q, seq, req = p["q"], p["seq_lens"], p["req_pool_indices"]
     slots = nat.decode_plan_slots(bs, max_len, chunk, kv_tokens=int(lens.sum()))
     ws = torch.empty(nat.decode_workspace_bytes(bs, Hq, D, max_len, chunk, slots), dtype=torch.uint8, device=DEV)
-    outs = {}
-    for groups in (0, Hkv, Hkv + 3):                         # more counters than kv heads is allowed
-        plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, slots, groups) // 4, dtype=torch.int32, device=DEV)
-        nat.decode_plan(plan, seq, max_len, chunk, slots, groups)
-        for rep in range(4 if groups else 1):
-            ws.fill_(0x7f if rep % 2 else 0)
-            o = torch.full_like(q, float("nan"))
-            nat.decode_attention(o, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], req, seq, D ** -0.5, 0.0,
-                                 max_len, chunk, ws, None, plan, max_slots=slots, plan_fuse_groups=groups)
-            outs[(groups, rep)] = o
-        assert int(plan[4 + bs + 2 * slots:].abs().sum()) == 0
-    base = outs[(0, 0)]
-    assert torch.isfinite(base.float()).all()
-    for key, o in outs.items():
-        assert torch.equal(o, base), key
-    check_decode(base, p, D ** -0.5, dtype, f"fused merge {dt} Hq{Hq} Hkv{Hkv} D{D}")
-    with pytest.raises(RuntimeError, match="invalid"):        # fewer counters than kv heads
+    plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, slots) // 4, dtype=torch.int32, device=DEV)
+    nat.decode_plan(plan, seq, max_len, chunk, slots)
+    outs = []
+    for rep in range(3):
+        ws.fill_(0x7f if rep % 2 else 0)
+        o = torch.full_like(q, float("nan"))
         nat.decode_attention(o, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], req, seq, D ** -0.5, 0.0,
-                             max_len, chunk, ws, None, plan, max_slots=slots, plan_fuse_groups=Hkv - 1 if Hkv > 1 else -1)
+                             max_len, chunk, ws, None, plan, max_slots=slots)
+        outs.append(o)
+    base = run_decode(nat, p, D ** -0.5, chunk=chunk, max_len=max_len, use_plan=False)
+    assert torch.isfinite(base.float()).all()
+    for rep, o in enumerate(outs):
+        assert torch.equal(o, base), rep
+    check_decode(base, p, D ** -0.5, dtype, f"many splits {dt} Hq{Hq} Hkv{Hkv} D{D}")
 
 
 # ----------------------------------------------------------------------------------- extend, 4 waves x 64 rows

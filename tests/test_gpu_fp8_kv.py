@@ -122,15 +122,14 @@ def test_decode_over_fp8_pool(dtype, Hq, Hkv, D):
         ws = torch.empty(_native.decode_workspace_bytes(bs, Hq, D, max_len, chunk), dtype=torch.uint8, device=DEV)
         plan = None
         if use_plan:
-            plan = torch.empty(_native.decode_plan_bytes(bs, max_len, chunk, fuse_groups=Hkv) // 4, dtype=torch.int32, device=DEV)
-            _native.decode_plan(plan, p["seq_lens"], max_len, chunk, fuse_groups=Hkv)     # the kernel merges its splits
+            plan = torch.empty(_native.decode_plan_bytes(bs, max_len, chunk) // 4, dtype=torch.int32, device=DEV)
+            _native.decode_plan(plan, p["seq_lens"], max_len, chunk)
         o = torch.full_like(p["q"], float("nan"))
         kb, vb = p["k_buffer"], p["v_buffer"]
         if use_plan:        # what MHATokenToKVPool.get_kv_buffer hands out: float8_e5m2 views of the byte pool
             kb, vb = kb.view(torch.float8_e5m2), vb.view(torch.float8_e5m2)
         _native.decode_attention(o, p["q"], kb, vb, p["req_to_token"],
-                                 p["req_pool_indices"], p["seq_lens"], scale, 0.0, max_len, chunk, ws, None, plan,
-                                 plan_fuse_groups=Hkv if use_plan else 0)
+                                 p["req_pool_indices"], p["seq_lens"], scale, 0.0, max_len, chunk, ws, None, plan)
         assert_close(o, ref, dtype, what=f"fp8 decode chunk {chunk}", vmax=vmax)
     with pytest.raises(RuntimeError, match="does not go with"):
         _native.decode_attention(torch.empty_like(p["q"].float()), p["q"].float(), p["k_buffer"], p["v_buffer"],

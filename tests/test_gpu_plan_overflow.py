@@ -63,53 +63,3 @@ def test_understated_seq_lens_sum_raises_instead_of_returning_wrong_logits():
     with pytest.raises(RuntimeError, match="split plan overflow"):
         worker.forward_batch_generation(bad)
     worker.forward_batch_generation(_decode_batch(mr, lens, sum(lens)))
-
-
-def test_fused_split_merge_in_the_backend_gives_the_same_logits(monkeypatch):
-    """HipAttnBackend.fused_split_merge = "1" (SP_DECODE_FUSE_MERGE=1; measured slower under graph replay, hence not the
-    default): the plans carry arrival counters and every layer's decode launch merges its own splits - the logits of a
-    step with ~10 splits per request are the bits of the default (merge launch) path."""
-    from scratchpad_amd.attention import HipAttnBackend
-    from scratchpad_amd.model_runner import TpModelWorker
-    lens = [600, 130, 64, 1999]
-    outs = []
-    for mode in ("0", "1"):
-        monkeypatch.setattr(HipAttnBackend, "fused_split_merge", mode)
-        mr = _runner()
-        backend = mr.attn_backend
-        assert (backend._plan_groups > 0) == (mode == "1") and backend._fuse(len(lens)) == (mode == "1")
-        batch = _decode_batch(mr, lens, sum(lens))
-        out, _ = TpModelWorker(mr).forward_batch_generation(batch)
-        backend.check_plans()
-        outs.append(out.next_token_logits.float().cpu())
-        if mode == "1":
-            plan, slots, _ = backend.forward_metadata[3][0]
-            assert int(plan[4 + len(lens) + 2 * slots:].abs().sum()) == 0, "arrival counters back at zero after 2 layers"
-    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
-
-
-def test_near_uniform_batches_are_not_split_and_a_wrong_hint_only_costs_speed(monkeypatch):
-    """ModelWorkerBatch.seq_lens_max_hint (advisory; ScheduleBatch keeps it like seq_lens_sum): a batch whose longest
-    request is within 1.35 x of the mean and that still has a workgroup per CU unsplit gets ONE split per request (no
-    partials, nothing to merge); a missing, too-small or absurd hint changes the split size at most, never the logits
-    beyond the rounding of another summation order."""
-    from scratchpad_amd.attention import HipAttnBackend
-    from scratchpad_amd.model_runner import TpModelWorker
-    monkeypatch.setattr(HipAttnBackend, "TARGET_ITEMS", 4)          # "one workgroup per CU" scaled down to this 4-request batch
-    lens = [600, 610, 620, 605]
-    mr = _runner()
-    worker = TpModelWorker(mr)
-    backend = mr.attn_backend
-    outs, chunks = {}, {}
-    for name, hint in (("none", None), ("exact", 620), ("low", 100), ("absurd", 10 ** 7)):
-        batch = _decode_batch(mr, lens, sum(lens))
-        batch.seq_lens_max_hint = hint
-        out, _ = worker.forward_batch_generation(batch)
-        backend.check_plans()
-        outs[name] = out.next_token_logits.float().cpu()
-        chunks[name] = int(backend.forward_metadata[3][0][0][1])
-    assert chunks["exact"] == 640, "one split covers the longest request (rounded up to 64 keys)"
-    assert chunks["none"] == chunks["low"] == chunks["absurd"] <= HipAttnBackend.MAX_CHUNK
-    assert torch.equal(outs["none"], outs["low"]) and torch.equal(outs["none"], outs["absurd"])
-    scale = float(outs["none"].abs().max())
-    assert float((outs["exact"] - outs["none"]).abs().max()) <= 2e-2 * scale      # bf16 model, another summation order

@@ -45,7 +45,7 @@ def test_python_binding_covers_every_symbol():
 
 def test_abi_version_and_status_strings(lib):
     lib.sp_abi_version.restype = ctypes.c_int
-    assert lib.sp_abi_version() == 6
+    assert lib.sp_abi_version() == 7
     lib.sp_status_string.restype = ctypes.c_char_p
     assert lib.sp_status_string(0) == b"ok"
     assert b"unsupported" in lib.sp_status_string(-2)
@@ -71,10 +71,9 @@ def test_host_side_argument_validation_needs_no_gpu(lib):
     assert lib.sp_decode_attention_workspace_bytes(256 * 8, 32, 128) == 256 * 32 * 8 * 129 * 4 + 16
     assert lib.sp_decode_attention_workspace_bytes(0, 8, 64) == 16
     lib.sp_decode_plan_bytes.restype = ctypes.c_size_t
-    lib.sp_decode_plan_bytes.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int]
-    # ABI 6: a 4-word header (listed, chunk, needed, 0), slot0[bs], the item pairs, fuse_groups counters per request
-    assert lib.sp_decode_plan_bytes(256, 2304, 0) == (4 + 256 + 2 * 2304) * 4
-    assert lib.sp_decode_plan_bytes(256, 2304, 8) == (4 + 256 + 2 * 2304 + 256 * 8) * 4
+    lib.sp_decode_plan_bytes.argtypes = [ctypes.c_int, ctypes.c_int64]
+    # a 4-word header (listed, chunk, needed, keys), slot0[bs], the item pairs (ABI 7: no arrival counters behind them)
+    assert lib.sp_decode_plan_bytes(256, 2304) == (4 + 256 + 2 * 2304) * 4
 
 
 def test_ops_refuse_host_tensors():

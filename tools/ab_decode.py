@@ -4,8 +4,7 @@
 Every LIBSPEC named on the command line - FILE[@key=value,...] under scratchpad_amd/lib, the switches applied through
 sp_debug_set after loading - runs the SAME decode launch in interleaved rounds: the shipped form (split plan + separate
 merge launch, K/V as the two strided views of one interleaved [P+1, 2, Hkv, D] arena as MHATokenToKVPool makes them,
-non-temporal gathers by default), or --fuse for the in-kernel merge while it exists.  Outputs are compared bit for bit
-with the first library's.
+non-temporal gathers by default).  Outputs are compared bit for bit with the first library's.
 
   python tools/ab_decode.py libscratchpad_hip.so libscratchpad_hip_x.so [--shape headline|hkv1|bs64|...] [--chunk 768]
   shapes: headline = bs 256, Hq 32 / Hkv 8, contexts U[128,4096] seed 0;  hkv1 = bs 128, Hq 8 / Hkv 1 (config 4's rank)
@@ -46,7 +45,6 @@ def main():
     ap.add_argument("--chunk", type=int, default=768, help="split size (attention.py ships 768 on these shapes)")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--kv", default="same", choices=["same", "fp8"])
-    ap.add_argument("--fuse", action="store_true", help="in-kernel split merge (plans with arrival counters)")
     ap.add_argument("--graph-slots", action="store_true", help="the launch covers max(1024, 8 bs) + bs items, as under graph replay")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--rounds", type=int, default=7)
@@ -80,24 +78,23 @@ def main():
     eb = q.element_size()
     alg = total * 2 * Hkv * D * (1 if a.kv == "fp8" else eb) + 2 * bs * Hq * D * eb + 4 * total
     slots = (max(1024, 8 * bs) + bs) if a.graph_slots else None
-    groups = Hkv if a.fuse else 0
     nats = [load_native(lib, i) for i, lib in enumerate(a.libs)]
     ws = torch.empty(nats[0].decode_workspace_bytes(bs, Hq, D, max_len, a.chunk, slots), dtype=torch.uint8, device=dev)
     plans, outs = [], []
     for n in nats:
-        pl = torch.empty(n.decode_plan_bytes(bs, max_len, a.chunk, slots, fuse_groups=groups) // 4, dtype=torch.int32, device=dev)
-        n.decode_plan(pl, seq, max_len, a.chunk, slots, fuse_groups=groups)
+        pl = torch.empty(n.decode_plan_bytes(bs, max_len, a.chunk, slots) // 4, dtype=torch.int32, device=dev)
+        n.decode_plan(pl, seq, max_len, a.chunk, slots)
         plans.append(pl)
         outs.append(torch.full_like(q, float("nan")))
 
     def run(i):
         nats[i].decode_attention(outs[i], q, kb, vb, r2t, req, seq, D ** -0.5, 0.0, max_len, a.chunk, ws, None, plans[i],
-                                 plan_fuse_groups=groups, max_slots=slots)
+                                 max_slots=slots)
     for i in range(len(nats)):
         run(i)
     torch.cuda.synchronize()
     print(f"shape {a.shape}: bs {bs} Hq {Hq} Hkv {Hkv} D {D} {a.dtype} kv {a.kv} chunk {a.chunk} sum {total} "
-          f"{'fused merge' if a.fuse else 'plan + merge launch'} {'graph slots' if a.graph_slots else 'exact slots'}; "
+          f"plan + merge launch, {'graph slots' if a.graph_slots else 'exact slots'}; "
           f"alg bytes {alg / 1e9:.3f} GB", flush=True)
     for i in range(1, len(nats)):
         same = torch.equal(outs[i], outs[0])

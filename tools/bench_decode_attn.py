@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--lib", default="", help="diagnostic library under scratchpad_amd/lib")
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--no-plan", action="store_true")
-    ap.add_argument("--no-fuse", action="store_true", help="separate merge launch (default: the attention kernel merges)")
+    ap.add_argument("--no-fuse", action="store_true", help="(accepted for old command lines: the merge is always a separate launch)")
     ap.add_argument("--interleave", action="store_true",
                     help="one [P+1, 2, Hkv, D] arena: a token's K and V rows are adjacent (pool.py's layout)")
     ap.add_argument("--slots", type=int, default=0,
@@ -82,12 +82,10 @@ def main():
         ws = torch.empty(_native.decode_workspace_bytes(a.bs, a.Hq, a.D, max_len, chunk, slots), dtype=torch.uint8, device=dev)
         plan = None
         if not a.no_plan:
-            groups = 0 if a.no_fuse else a.Hkv
-            plan = torch.empty(_native.decode_plan_bytes(a.bs, max_len, chunk, slots, fuse_groups=groups) // 4, dtype=torch.int32, device=dev)
-            _native.decode_plan(plan, seq, max_len, chunk, slots, fuse_groups=groups)
-        groups = 0 if (a.no_fuse or a.no_plan) else a.Hkv
+            plan = torch.empty(_native.decode_plan_bytes(a.bs, max_len, chunk, slots) // 4, dtype=torch.int32, device=dev)
+            _native.decode_plan(plan, seq, max_len, chunk, slots)
         run = lambda: _native.decode_attention(o, q, kb, vb, r2t, req, seq, a.D ** -0.5, 0.0, max_len, chunk, ws, None, plan,
-                                               plan_fuse_groups=groups, max_slots=slots)
+                                               max_slots=slots)
         for _ in range(a.warmup):
             run()
         torch.cuda.synchronize()

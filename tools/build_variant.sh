@@ -10,5 +10,5 @@ mkdir -p build/variants
   -DSP_EXTEND_ONLY_HEADLINE "$@" -c scratchpad_amd/csrc/extend_mfma.hip -o build/variants/extend_mfma_$NAME.o
 OBJS=$(ls build/obj/*.o | grep -v extend_mfma.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scratchpad_amd/lib/libscratchpad_hip_$NAME.so $OBJS build/variants/extend_mfma_$NAME.o
-python3 tools/patch_w64_descriptor.py scratchpad_amd/lib/libscratchpad_hip_$NAME.so > /dev/null   # the w64 extend kernels need their descriptors sized (see that script)
+python3 tools/w64_asm.py check scratchpad_amd/lib/libscratchpad_hip_$NAME.so > /dev/null   # (build/obj/extend_w64.o comes from the staged build: build.py compile_w64)
 echo built scratchpad_amd/lib/libscratchpad_hip_$NAME.so

@@ -6,9 +6,9 @@ set -e
 cd "$(dirname "$0")/.."
 NAME=$1; shift
 mkdir -p build/variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -fvisibility=hidden -Wno-unused-value -fno-honor-nans \
-  -fno-slp-vectorize -mllvm -amdgpu-atomic-optimizer-strategy=None "$@" -c scratchpad_amd/csrc/extend_w64.hip -o build/variants/extend_w64_$NAME.o
+# the staged compile of this file (device assembly -> tools/w64_asm.py -> assembler -> host object): build.py compile_w64
+python3 -m scratchpad_amd.build --w64-object build/variants/extend_w64_$NAME.o "$@" > /dev/null
 OBJS=$(ls build/obj/*.o | grep -v extend_w64.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scratchpad_amd/lib/libscratchpad_hip_$NAME.so $OBJS build/variants/extend_w64_$NAME.o
-python3 tools/patch_w64_descriptor.py scratchpad_amd/lib/libscratchpad_hip_$NAME.so
+python3 tools/w64_asm.py check scratchpad_amd/lib/libscratchpad_hip_$NAME.so
 echo built scratchpad_amd/lib/libscratchpad_hip_$NAME.so
