@@ -573,6 +573,7 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
   const int eb = dtype == SP_F32 ? 4 : 2;
   const int vec = 16 / eb;
   SP_CHECK_ARG(q_stride % vec == 0 && kv_buffer_stride % (kv8 ? 8 : vec) == 0);
+  SP_CHECK_ARG(kv_buffer_stride > 0 && kv_buffer_stride * (kv8 ? 1 : eb) <= 0xffffffffLL);   // token stride in bytes: 32 bits
   SP_CHECK_ARG(!kv8 || (((uintptr_t)k_buffer & 7) == 0 && ((uintptr_t)v_buffer & 7) == 0));
   const int G = num_q_heads / num_kv_heads;
   // query heads per KV head: the matrix-core kernel tiles up to 16 of them as MFMA columns (16-bit

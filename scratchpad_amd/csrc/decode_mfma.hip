@@ -177,8 +177,20 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
 
   // gather mapping: lane -> (row within the wave-load, 16-byte chunk)
   const int ld_row = lane / CPR, ld_ch = lane % CPR;
-  const int64_t tok_bytes = a.kv_stride * (KV8 ? 1 : 2);
-  const int64_t head_off = (int64_t)hk * SRC_ROW_B;
+  // Address of the chunk a lane gathers from K row `slot`:  kbase[i] + slot * tok_bytes, ONE v_mad_u64_u32 (the slot is a
+  // non-negative int32 and the token stride fits 32 bits - the host checks it - so no 64 x 64-bit product, which the
+  // compiler expands into three quarter-rate multiplies: PMC, round 5: the address arithmetic was 40 % of the loop's
+  // vector instructions).  kbase[i] holds everything that does not depend on the key: pool base, head, and the source
+  // chunk, XOR-swizzled by the tile row so that the LDS image is conflict-free.  V sits at a launch-uniform distance
+  // from K (the pool's two views; one add).
+  const uint32_t tok_bytes = (uint32_t)(a.kv_stride * (KV8 ? 1 : 2));
+  const int64_t v_minus_k = a.vbuf - a.kbuf;
+  uint64_t kbase[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int R = i * RPL + ld_row;
+    kbase[i] = (uint64_t)(uintptr_t)a.kbuf + (uint64_t)hk * SRC_ROW_B + (uint64_t)((ld_ch ^ (R & (CPR - 1))) * SRC_CH_B);
+  }
   // fragment-read addresses (constant per lane)
   const int i16 = lane & 15;
   const int tr_row = 4 * kq + (i16 >> 2);          // V row this lane addresses in a tr read
@@ -188,10 +200,12 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
   const int ws = HPW ? cs : cs + wave * sub;
   const int we = min(ws + sub, ce);
 
-  // The key loop exists twice: with plain and with NON-TEMPORAL K/V gathers (DecodeArgs::nt_min_keys; the choice is
-  // uniform over the launch - plan data - and made once, here, so that each form is a loop of its own).
-  auto key_loop = [&](auto nt_c) {
+  // The key loop exists in four copies: with plain and with NON-TEMPORAL K/V gathers (DecodeArgs::nt_min_keys; the
+  // choice is uniform over the launch - plan data), with and without the logit soft-cap (a launch argument) - each
+  // choice made once, here, so that every form is a loop of its own without a branch per score.
+  auto key_loop = [&](auto nt_c, auto cap_c) {
   constexpr bool NT = decltype(nt_c)::value;
+  constexpr bool CAP = decltype(cap_c)::value;
   int nextidx = (ws + lane < we) ? idx_row[ws + lane] : 0;
   for (int ps = ws; ps < we; ps += 64) {           // pieces of <= 64 keys: one index register
     const int n = min(64, we - ps);
@@ -201,25 +215,27 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
 
     raw_t kr[NLD], vr[NLD];
     raw_t kr2[NLD], vr2[NLD];   // KV8 only: a second set (see the loop below); unused and optimised away otherwise
-    auto issue_from = [&](int tile, int idxreg, int nkeys, raw_t (&kd)[NLD], raw_t (&vd)[NLD]) {
+    auto issue_from = [&](int tile, int idxreg, raw_t (&kd)[NLD], raw_t (&vd)[NLD]) {
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
         const int key = tile * TK + i * RPL + ld_row;         // key within the piece
-        const int slot = __shfl(idxreg, key & 63, 64);
-        // source chunk is XOR-swizzled by the tile row so that the LDS image is conflict-free
-        const int R = i * RPL + ld_row;
-        const int64_t off = (key < nkeys ? (int64_t)slot : 0) * tok_bytes + head_off +
-                            ((ld_ch ^ (R & (CPR - 1))) * SRC_CH_B);
+        // (lanes of the index register past the piece's keys hold slot 0, the pool's dummy row: no select needed)
+        const uint32_t slot = (uint32_t)__shfl(idxreg, key & 63, 64);
+        // (an integer turned into a pointer is a FLAT pointer to the compiler - flat loads also count in lgkmcnt and
+        // take the aperture check: name the global address space)
+        typedef const raw_t __attribute__((address_space(1)))* gptr_t;
+        const uint64_t ka = kbase[i] + (uint64_t)slot * tok_bytes;
+        const gptr_t kp = (gptr_t)ka, vp = (gptr_t)(ka + (uint64_t)v_minus_k);
         if constexpr (NT) {
-          kd[i] = __builtin_nontemporal_load((const raw_t*)(a.kbuf + off));
-          vd[i] = __builtin_nontemporal_load((const raw_t*)(a.vbuf + off));
+          kd[i] = __builtin_nontemporal_load(kp);
+          vd[i] = __builtin_nontemporal_load(vp);
         } else {
-          kd[i] = *(const raw_t*)(a.kbuf + off);
-          vd[i] = *(const raw_t*)(a.vbuf + off);
+          kd[i] = *kp;
+          vd[i] = *vp;
         }
       }
     };
-    auto issue_to = [&](int tile, raw_t (&kd)[NLD], raw_t (&vd)[NLD]) { issue_from(tile, myidx, n, kd, vd); };
+    auto issue_to = [&](int tile, raw_t (&kd)[NLD], raw_t (&vd)[NLD]) { issue_from(tile, myidx, kd, vd); };
     auto issue = [&](int tile) { issue_to(tile, kr, vr); };
     auto stage_from = [&](const raw_t (&ks)[NLD], const raw_t (&vs)[NLD]) {
 #pragma unroll
@@ -266,7 +282,7 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float v = s[j] * qk_scale;
-        if (cap > 0.f) v = cap * tanhf(v / cap) * kLog2eM;
+        if constexpr (CAP) v = cap * tanhf(v / cap) * kLog2eM;
         x[j] = (tile * TK + 4 * kq + j < n) ? v : -INFINITY;
         mx = fmaxf(mx, x[j]);
       }
@@ -340,7 +356,11 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
   };
   // (a plan-less launch has no key count to compare: it streams only when the threshold is "always", the default)
   const bool nt = a.plan ? a.plan[3] >= a.nt_min_keys : a.nt_min_keys == 0;
-  if (nt) key_loop(std::true_type{}); else key_loop(std::false_type{});
+  if (cap > 0.f) {
+    if (nt) key_loop(std::true_type{}, std::true_type{}); else key_loop(std::false_type{}, std::true_type{});
+  } else {
+    if (nt) key_loop(std::true_type{}, std::false_type{}); else key_loop(std::false_type{}, std::false_type{});
+  }
 
   if constexpr (HPW) {
     // ---- this wave owns heads hk*G .. hk*G+G-1: normalise and write straight from registers

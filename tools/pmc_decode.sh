@@ -2,16 +2,16 @@
 # PMC traffic of the decode attention kernels for ONE workload: FETCH_SIZE and WRITE_SIZE in separate passes
 # (MI355X_MICROARCH.md, HBM / rocprofv3 PMC slots) plus a --kernel-trace --stats pass, then the traffic / algorithmic
 # ratio and the hash of the kernel sources it was measured on.
-#   bash tools/pmc_decode.sh NAME BENCH_WORKLOAD_KEY "<tools/bench_decode_attn.py shape arguments>" [fuse|nofuse]
-#   e.g.  bash tools/pmc_decode.sh hkv1 "llama3-70b-tp8-rank|bs128|ctxuniform|kvauto" "--bs 128 --Hq 8 --Hkv 1 --chunks 512" nofuse
+#   bash tools/pmc_decode.sh NAME BENCH_WORKLOAD_KEY "<tools/bench_decode_attn.py shape arguments>"
+#   e.g.  bash tools/pmc_decode.sh hkv1 "llama3-70b-tp8-rank|bs128|ctxuniform|kvauto" "--bs 128 --Hq 8 --Hkv 1 --chunks 768 --interleave"
 # -> gpurun_out/pmc_NAME/{summary.txt,decode_attn_pmc_NAME.json,kernel_stats.csv}: copy to profiles/rNN_decode_attn_pmc_NAME.*
 # (bench.py's pmc_traffic() uses the ratio only for the same BENCH_WORKLOAD_KEY and while the source hash matches).
 set -o pipefail
-NAME=$1; KEY=$2; SHAPE=$3; FUSE=${4:-nofuse}
+NAME=$1; KEY=$2; SHAPE=$3
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$NAME
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-FLAG=""; [ "$FUSE" = "nofuse" ] && FLAG="--no-fuse"
+FLAG=""
 DEC="$GRAFT_REPO_ROOT/tools/bench_decode_attn.py $SHAPE --iters 6 --warmup 3 $FLAG"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $DEC > $OUT/kt.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/f -- python3 $DEC > $OUT/f.log 2>&1 &&
