@@ -8,6 +8,7 @@ implements the flashinfer backend's encoder-decoder dispatch (cross-attention re
 [0, encoder_len); self-attention reads [encoder_len, encoder_len + seq_len)).
 """
 import os
+import threading
 from abc import ABC, abstractmethod
 from typing import TYPE_CHECKING, Optional
 
@@ -145,6 +146,7 @@ class HipAttnBackend(AttentionBackend):
         self.replay_max_hint = None    # set by HipGraphRunner.replay for the next replay hook call
         self._plan_checks = []         # (pinned header copy, event, max_slots) of plans not yet checked
         self._plan_hosts = []          # pinned buffers + events to reuse
+        self._plan_lock = threading.Lock()   # the overlap worker checks from the scheduler thread (tp_worker_client.py)
 
     # ---------------------------------------------------------------- launch planning
     def _head_groups(self, dtype: torch.dtype) -> int:
@@ -237,11 +239,13 @@ class HipAttnBackend(AttentionBackend):
         splits were dropped (wrong logits).  The header comes back through a 16-byte asynchronous copy: earlier
         plans whose copy has landed are checked here, this one at the next plan or in check_plans()."""
         self.check_plans(wait=len(self._plan_checks) >= 64)      # (a bound on the copies in flight)
-        host, ev = self._plan_hosts.pop() if self._plan_hosts else (
-            torch.empty(_native.PLAN_HEADER_WORDS, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+        with self._plan_lock:
+            host, ev = self._plan_hosts.pop() if self._plan_hosts else (
+                torch.empty(_native.PLAN_HEADER_WORDS, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
         host.copy_(plan[:_native.PLAN_HEADER_WORDS], non_blocking=True)
         ev.record()
-        self._plan_checks.append((host, ev, slots))
+        with self._plan_lock:
+            self._plan_checks.append((host, ev, slots))
         if self.strict_plan_check:
             self.check_plans(wait=True)
 
@@ -250,15 +254,19 @@ class HipAttnBackend(AttentionBackend):
         that have already completed (no synchronisation)."""
         pending = []
         err = None
-        for host, ev, slots in self._plan_checks:
+        with self._plan_lock:
+            checks, self._plan_checks = self._plan_checks, []
+        for host, ev, slots in checks:
             if wait:
                 ev.synchronize()
             elif not ev.query():
                 pending.append((host, ev, slots))
                 continue
             err = err or _native.decode_plan_overflow(host.tolist(), slots)
-            self._plan_hosts.append((host, ev))
-        self._plan_checks = pending
+            with self._plan_lock:
+                self._plan_hosts.append((host, ev))
+        with self._plan_lock:
+            self._plan_checks = pending + self._plan_checks
         if err:
             raise RuntimeError(err)
 

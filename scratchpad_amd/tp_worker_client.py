@@ -82,6 +82,12 @@ class TpModelWorkerClient:
         if launch_done is not None:
             launch_done.wait()
         copy_done.synchronize()
+        # the step's split-plan headers were copied out ahead of its forward on the same stream: they have landed.  A
+        # plan that was cut short (the scheduler understated seq_lens_sum) raises HERE, before this step's token ids
+        # are handed out - not one step later
+        backend = getattr(self.model_runner, "attn_backend", None)
+        if hasattr(backend, "check_plans"):
+            backend.check_plans(wait=False)
         return logits_output, next_token_ids.tolist()
 
     def forward_batch_generation(self, model_worker_batch: ModelWorkerBatch):

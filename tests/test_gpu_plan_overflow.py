@@ -63,3 +63,25 @@ def test_understated_seq_lens_sum_raises_instead_of_returning_wrong_logits():
     with pytest.raises(RuntimeError, match="split plan overflow"):
         worker.forward_batch_generation(bad)
     worker.forward_batch_generation(_decode_batch(mr, lens, sum(lens)))
+
+
+def test_overlap_worker_reports_the_overflow_with_the_same_steps_results():
+    """The overlap worker (tp_worker_client.py) synchronises on a step's results one step later anyway: the step's plan
+    headers, copied out ahead of its forward on the same stream, have landed by then, so a cut plan raises when THAT
+    step's token ids are resolved - before they reach the scheduler - and not with the following step."""
+    from scratchpad_amd.tp_worker_client import TpModelWorkerClient
+    mr = _runner()
+    client = TpModelWorkerClient(mr)
+    try:
+        lens = [600, 600, 600, 600]
+        client.forward_batch_generation(_decode_batch(mr, lens, sum(lens)))
+        _, ids = client.resolve_last_batch_result()
+        assert len(ids) == 4
+        client.forward_batch_generation(_decode_batch(mr, lens, 400))          # understated: 10 items for 28
+        with pytest.raises(RuntimeError, match="split plan overflow.*seq_lens_sum"):
+            client.resolve_last_batch_result()
+        client.forward_batch_generation(_decode_batch(mr, lens, sum(lens)))   # the engine goes on; reported once
+        _, ids = client.resolve_last_batch_result()
+        assert len(ids) == 4
+    finally:
+        client.close()

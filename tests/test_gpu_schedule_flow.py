@@ -136,24 +136,36 @@ def test_extend_decode_mixed_trace_matches_oracle():
     for r, tok in zip(mix2.reqs, out2.next_token_logits.argmax(-1).tolist()):
         r.output_ids.append(tok)
     mix2.output_ids = out2.next_token_logits.argmax(-1)
+    # (the engine has 4 request rows: r0 finishes here and gives its row and slots back, as the scheduler would -
+    # filter_batch + cache_finished_req of a ChunkCache, scheduler.py:803-812, chunk_cache.py:37-50)
+    from scratchpad_amd.schedule_batch import FINISH_LENGTH
+    done = mix2.reqs[2]
+    assert done.rid == "r0"
+    done.finished_reason = FINISH_LENGTH(length=len(done.output_ids))
+    done_len = int(mix2.seq_lens[2])
+    mix2.filter_batch()
+    assert [r.rid for r in mix2.reqs] == ["r3", "r2", "r1"] and mix2.top_logprobs_nums == [2, 0, 0]
+    row = mr.req_to_token_pool.req_to_token[done.req_pool_idx, :done_len]
+    mr.token_to_kv_pool_allocator.free(row.to(torch.int64))
+    mr.req_to_token_pool.free(done.req_pool_idx)
     mix2.prepare_for_decode()
-    assert mix2.return_logprob and mix2.top_logprobs_nums == [2, 0, 0, 0]
+    assert mix2.return_logprob and mix2.top_logprobs_nums == [2, 0, 0]
     plain = Req("r4", "", torch.randint(0, shape.vocab, (6,), generator=gen).tolist(), None)
     mix3 = ScheduleBatch([plain], mr.req_to_token_pool, mr.token_to_kv_pool_allocator, device=dev)
     mix3.prepare_for_extend()
     assert not mix3.return_logprob and mix3.extend_input_logprob_token_ids is None
     mix3.mix_with_running(mix2)
-    assert mix3.return_logprob and mix3.extend_lens == [6, 1, 1, 1, 1] and mix3.extend_logprob_start_lens == [0] * 5
-    assert mix3.extend_input_logprob_token_ids.tolist() == [0] * (6 + 4)
-    assert mix3.top_logprobs_nums == [0, 2, 0, 0, 0]
+    assert mix3.return_logprob and mix3.extend_lens == [6, 1, 1, 1] and mix3.extend_logprob_start_lens == [0] * 4
+    assert mix3.extend_input_logprob_token_ids.tolist() == [0] * (6 + 3)
+    assert mix3.top_logprobs_nums == [0, 2, 0, 0]
     out3, _ = worker.forward_batch_generation(mix3.get_model_worker_batch())
     mirror_tables()
     ref3 = oracle_step(shape, w, okv, "extend", mix3.input_ids.cpu(), mix3.req_pool_indices.cpu(), mix3.seq_lens.cpu(),
                        mix3.out_cache_loc.cpu(), torch.tensor(mix3.prefix_lens, dtype=torch.int32),
                        torch.tensor(mix3.extend_lens, dtype=torch.int32))
     close(out3.next_token_logits, ref3, "mixed batch, logprobs asked by a running request only: sampled rows")
-    assert out3.input_token_logprobs.shape[0] == 6 + 4 and torch.isfinite(out3.input_token_logprobs).all()
-    assert [len(v) for v in out3.input_top_logprobs_val] == [6, 1, 1, 1, 1]
+    assert out3.input_token_logprobs.shape[0] == 6 + 3 and torch.isfinite(out3.input_token_logprobs).all()
+    assert [len(v) for v in out3.input_top_logprobs_val] == [6, 1, 1, 1]
     assert [len(row) for row in out3.input_top_logprobs_val[1]] == [2] and all(len(row) == 0 for row in out3.input_top_logprobs_val[0])
     # the running request's row: its top-2 input logprobs are the two largest entries of log_softmax of ITS logits row
     want = torch.log_softmax(ref3[1].double(), -1).topk(2).values.float()
