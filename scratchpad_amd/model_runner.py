@@ -395,6 +395,31 @@ class TpModelWorker:
 
     def __init__(self, model_runner: ModelRunner):
         self.model_runner = model_runner
+        a, cfg = model_runner.server_args, model_runner.model_config
+        # the limits the scheduler reads at start-up (tp_worker.py:73-105)
+        self.max_total_num_tokens = model_runner.max_total_num_tokens
+        self.max_prefill_tokens = getattr(a, "max_prefill_tokens", 16384)
+        self.max_running_requests = model_runner.max_running_requests
+        self.max_req_len = min(cfg.context_len - 1, self.max_total_num_tokens - 1)
+        self.max_req_input_len = self.max_req_len - 5
+        self.random_seed = getattr(a, "random_seed", 0)
+        self.device = model_runner.device
+
+    # ---- the accessors the reference's Scheduler calls at start-up (scheduler.py:203-217, 333-336; tp_worker.py:107-162)
+    def get_worker_info(self):
+        mr = self.model_runner
+        return (self.max_total_num_tokens, self.max_prefill_tokens, self.max_running_requests, self.max_req_len,
+                self.max_req_input_len, self.random_seed, self.device, None,      # (global_args: server-side, not kept here)
+                mr.req_to_token_pool.size, mr.req_to_token_pool.max_context_len, mr.token_to_kv_pool.size)
+
+    def get_pad_input_ids_func(self):
+        return getattr(self.model_runner.model, "pad_input_ids", None)
+
+    def get_tp_cpu_group(self):
+        return getattr(dist_.get_tp_group(), "cpu_group", None)
+
+    def get_memory_pool(self):
+        return self.model_runner.req_to_token_pool, self.model_runner.token_to_kv_pool_allocator
 
     def forward_batch_generation(self, model_worker_batch: ModelWorkerBatch, skip_sample: bool = False):
         forward_batch = ForwardBatch.init_new(model_worker_batch, self.model_runner)

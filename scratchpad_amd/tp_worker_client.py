@@ -45,6 +45,19 @@ class TpModelWorkerClient:
     def model_runner(self):
         return self.worker.model_runner
 
+    # tp_worker_client.py:86-108: the scheduler's start-up accessors go through to the worker
+    def get_worker_info(self):
+        return self.worker.get_worker_info()
+
+    def get_pad_input_ids_func(self):
+        return self.worker.get_pad_input_ids_func()
+
+    def get_tp_cpu_group(self):
+        return self.worker.get_tp_cpu_group()
+
+    def get_memory_pool(self):
+        return self.worker.get_memory_pool()
+
     def forward_thread_func(self):
         try:
             with torch.cuda.stream(self.forward_stream):

@@ -1113,6 +1113,12 @@ def gen_api_surface():
                "methods": {n: methods(c) for n, c in classes.items()},
                "functions": {}}
     surface["methods"]["GroupCoordinator"] = methods(ps.GroupCoordinator, only=("all_reduce", "all_gather", "graph_capture"))
+    # the worker seam (managers/tp_worker*.py): only what scheduler/scheduler.py calls on it for this path
+    import scratchpad.managers.tp_worker as tw
+    import scratchpad.managers.tp_worker_client as twc
+    worker_calls = ("get_worker_info", "get_pad_input_ids_func", "get_tp_cpu_group", "get_memory_pool", "forward_batch_generation")
+    surface["methods"]["TpModelWorker"] = methods(tw.TpModelWorker, only=worker_calls)
+    surface["methods"]["TpModelWorkerClient"] = methods(twc.TpModelWorkerClient, only=worker_calls + ("resolve_last_batch_result",))
     for mod, names in ((comm, ("tensor_model_parallel_all_reduce", "tensor_model_parallel_all_gather")),
                        (ps, ("graph_capture", "get_tp_group", "get_tensor_model_parallel_world_size",
                              "get_tensor_model_parallel_rank"))):
@@ -1122,7 +1128,8 @@ def gen_api_surface():
     # ---- call forms: every `<receiver>.<method>(...)` in the caller files whose method name belongs to a seam class
     seam_methods = set()
     for n in ("AttentionBackend", "RadixAttention", "KVCache", "MHATokenToKVPool", "ReqToTokenPool",
-              "TokenToKVPoolAllocator", "ScheduleBatch", "Req", "GroupCoordinator", "RadixCache", "ChunkCache", "ForwardBatch"):
+              "TokenToKVPoolAllocator", "ScheduleBatch", "Req", "GroupCoordinator", "RadixCache", "ChunkCache", "ForwardBatch",
+              "TpModelWorker", "TpModelWorkerClient"):
         seam_methods |= {m for m in surface["methods"][n] if m != "__init__"}
     seam_methods |= set(surface["functions"])
     callers = ["scheduler/scheduler.py", "scheduler/schedule_batch.py", "scheduler/schedule_policy.py",

@@ -28,6 +28,7 @@ import scratchpad_amd.pool as pool
 import scratchpad_amd.radix_cache as radix_cache
 import scratchpad_amd.sampler as sampler
 import scratchpad_amd.schedule_batch as schedule_batch
+import scratchpad_amd.tp_worker_client as tp_worker_client
 
 SURFACE = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "api_surface.json")))
 
@@ -40,6 +41,7 @@ OURS = {
     "CaptureHiddenMode": forward_info.CaptureHiddenMode, "ModelWorkerBatch": forward_info.ModelWorkerBatch,
     "RadixCache": radix_cache.RadixCache, "ChunkCache": radix_cache.ChunkCache,
     "GroupCoordinator": distributed.GroupCoordinator,
+    "TpModelWorker": model_runner.TpModelWorker, "TpModelWorkerClient": tp_worker_client.TpModelWorkerClient,
 }
 
 # reference methods deliberately NOT mirrored, each with its reason (anything else missing fails the test)
@@ -165,6 +167,8 @@ RECEIVERS = {
     "token_to_kv_pool": ["MHATokenToKVPool"], "tree_cache": ["RadixCache", "ChunkCache"],
     "attn_backend": ["HipAttnBackend"], "ForwardBatch": ["ForwardBatch"], "get_tp_group()": ["GroupCoordinator"],
     "sampling_info": ["SamplingBatchInfo"],
+    # scheduler.py holds either worker class in self.tp_worker (183-200): every call has to bind on both
+    "tp_worker": ["TpModelWorker", "TpModelWorkerClient"],
 }
 OURS_CALLABLE = dict(OURS, HipAttnBackend=attention.HipAttnBackend, SamplingBatchInfo=sampler.SamplingBatchInfo,
                      ModelRunner=model_runner.ModelRunner)
@@ -174,14 +178,17 @@ SELF_CLASSES = {"scheduler/schedule_batch.py": ["ScheduleBatch", "Req"], "memory
                 "nn/attention/flashinfer_backend.py": ["HipAttnBackend"], "model_executor/forward_info.py": ["ForwardBatch"],
                 "model_executor/model_runner.py": ["ModelRunner"]}
 # the same receiver NAME is a different object in these files
-RECEIVERS_BY_FILE = {("memory/chunk_cache.py", "token_to_kv_pool"): ["TokenToKVPoolAllocator"]}
+RECEIVERS_BY_FILE = {("memory/chunk_cache.py", "token_to_kv_pool"): ["TokenToKVPoolAllocator"],
+                     ("managers/tp_worker_client.py", "worker"): ["TpModelWorker"]}
+# (the synchronous worker has no resolve_last_batch_result upstream either: scheduler.py:1080, 1126, 1437 run under enable_overlap)
+ONLY_ON = {("tp_worker", "resolve_last_batch_result"): ["TpModelWorkerClient"]}
 # receivers that are not seam objects (same method NAME on something out of scope)
 NOT_SEAMS = {
     "copy": "the copy module", "grammar": "grammar objects (out of scope)", "grammar_cache": "grammar cache (out of scope)",
     "decode_wrapper": "flashinfer wrapper (third party)", "prefill_wrapper_paged": "flashinfer wrapper (third party)",
     "model": "nn.Module.forward of the model", "model_runner": "ModelRunner.forward (own seam, test_gpu_schedule_flow)",
     "mm_input": "MultimodalInputs (image processor side)", "spec_info": "speculative decoding (out of scope)",
-    "distributed": "torch.distributed", "ps": "module alias", "worker": "TpModelWorker accessor",
+    "distributed": "torch.distributed", "ps": "module alias",
 }
 # call sites that use a seam object for something the path does not have, with the reason
 SKIPPED_SITES = {
@@ -193,6 +200,7 @@ SKIPPED_SITES = {
     ("scheduler/schedule_batch.py", "self", "new_page_count_next_decode"): "page_size > 1",
     ("scheduler/scheduler.py", "req", "init_incremental_detokenize"): "detokenizer side",
     ("model_executor/forward_info.py", "self", "contains_audio_inputs"): None,    # bound below like any other
+    ("managers/tp_worker_client.py", "worker", "get_tp_group"): "upstream calls a method its own TpModelWorker does not define",
 }
 
 
@@ -205,7 +213,7 @@ def _targets(form):
     if recv == "self":
         names = SELF_CLASSES.get(form["file"], [])
     else:
-        names = RECEIVERS_BY_FILE.get((form["file"], recv), RECEIVERS.get(recv))
+        names = ONLY_ON.get((recv, meth)) or RECEIVERS_BY_FILE.get((form["file"], recv), RECEIVERS.get(recv))
     if names is None:
         return None
     found = []

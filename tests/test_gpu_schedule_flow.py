@@ -38,6 +38,12 @@ def test_extend_decode_mixed_trace_matches_oracle():
     mr = smoke_impl.make_runner(shape, w, torch.float32)
     worker = TpModelWorker(mr)
     dev = mr.device
+    # the accessors the reference's Scheduler calls at start-up (scheduler.py:203-217, 333-336)
+    info = worker.get_worker_info()
+    assert len(info) == 11 and info[0] == mr.max_total_num_tokens == 96 and info[2] == mr.max_running_requests
+    assert info[6] == dev and info[8] == mr.req_to_token_pool.size and info[10] == mr.token_to_kv_pool.size
+    assert worker.get_memory_pool() == (mr.req_to_token_pool, mr.token_to_kv_pool_allocator)
+    assert worker.get_pad_input_ids_func() is None and worker.get_tp_cpu_group() is None      # plain Llama, TP = 1
     gen = torch.Generator().manual_seed(7)
     okv = ollama.OracleKV(shape, 96, 4, 64)
 
