@@ -38,6 +38,9 @@ struct DecodeArgs {
   // which only a launch of several rounds of workgroups hides.  0 = always (the default), INT_MAX = never; a plan-less
   // launch has no key count and streams only when the threshold is 0.
   int nt_min_keys;
+  // the persistent head-per-wave kernel (decode_mfma.hip) takes planned launches of the default configuration:
+  // -1 = with as many workgroups as the chip holds (the default), n > 0 = with n workgroups, 0 = never
+  int persist;
 };
 
 static constexpr int kPlanHdr = 4;   // int32 words in front of slot0[]
@@ -135,5 +138,6 @@ int decode_heads_per_load_shift(int num_kv_heads, int head_dim, int dtype, int* 
 // test / tuning hooks behind sp_debug_set
 void set_decode_kernel(int which);
 void set_decode_nt_min_mb(int mb);
+void set_decode_persist(int n);
 
 }  // namespace sp

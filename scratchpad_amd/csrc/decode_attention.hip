@@ -470,6 +470,10 @@ void set_decode_kernel(int which) { g_decode_kernel_forced = which; }
 static constexpr int kDecodeNtMinMbDefault = 0;
 static int g_decode_nt_min_mb = kDecodeNtMinMbDefault;
 void set_decode_nt_min_mb(int mb) { g_decode_nt_min_mb = mb == -2 ? kDecodeNtMinMbDefault : mb; }
+// sp_debug_set("decode_persist", n): the persistent form of the matrix-core kernel (DecodeArgs::persist): -1 = default,
+// 0 = never (the launch-per-item kernel everywhere), n > 0 = with n workgroups
+static int g_decode_persist = -1;
+void set_decode_persist(int n) { g_decode_persist = n < 0 ? -1 : n; }
 static int decode_kernel_choice(int group, int dtype) {
   if (dtype == SP_F32 || group > 16) return 1;
   if (g_decode_kernel_forced == 1 || g_decode_kernel_forced == 2) return g_decode_kernel_forced;
@@ -604,6 +608,7 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
   {
     // bytes of K + V one key row costs this launch (all its kv heads)
     const int64_t key_bytes = 2LL * num_kv_heads * head_dim * (kv8 ? 1 : eb);
+    a.persist = g_decode_persist;
     a.nt_min_keys = g_decode_nt_min_mb < 0 ? 0x7fffffff
                                            : (int)(((int64_t)g_decode_nt_min_mb << 20) / key_bytes);   // (< 2^31: mb is an int)
   }

@@ -109,6 +109,9 @@ struct DmCfg {
   static constexpr int kMergeBytes = WAVES * 16 * (D + 2) * 4;
   static constexpr int kLdsBytes = kStageBytes > kMergeBytes ? kStageBytes : kMergeBytes;
 };
+// persistent form: LDS per wave in which split partials wait for the end of the wave's work (with the 32 KiB of tiles
+// at D = 128: 49 KiB per workgroup, three workgroups per CU)
+static constexpr int kDmParkWaveB = 4352;
 
 // HPW ("head per wave", Hkv % 4 == 0): the 4 waves take the 4 adjacent KV heads of the SAME keys - the
 // workgroup then reads whole 1 KiB token half-rows, and each wave owns its heads outright: no merge,
@@ -429,6 +432,305 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// PERSISTENT form of the head-per-wave kernel (round 5): planned launches of the default configuration (16-bit pool,
+// non-temporal gathers, no soft-cap).  The launch has as many workgroups as the chip holds at once, and each takes
+// (plan item, head quad) units one after the other WITHOUT draining its gathers in between: while a unit's last piece of
+// 64 keys is consumed, the next unit's record and first index piece are fetched, and its first tile's gathers are issued
+// where the current unit has none left to issue.  Which units a workgroup takes is STATIC - unit r * W + w in even rounds,
+// r * W + (W - 1 - w) in odd ones: dealt in serpentine order, the plan's longest-first list gives every workgroup the
+// load greedy longest-processing-time scheduling would (tools/sim_decode_split.py), whereas tickets drawn from one
+// counter cost more than they balance (same-address device-scope atomics serialise at ~50 ns apiece).  The four waves of
+// a workgroup compute the same sequence and take the four heads of each unit; they share nothing (wave-private LDS
+// tile, no barrier).
+//
+// What this form buys is WHERE the split partials go (profiles/r05_decode_split_cost.txt): fp32 partial rows written
+// to HBM in between the gathers cost ~1.8 us per MB - ten times their share of the bytes.  A wave PARKS the partial
+// rows of its units in LDS the tiles do not use (kParkWaveB per wave: 2 units at G = 4, D = 128) and writes them, in
+// whole 512-byte rows, when it has no unit left - which, the loads being level, is when the launch as a whole is
+// running out of gathers.  (Holding the rows back until EVERY workgroup is done, behind a bounded device-wide barrier,
+// was tried as well: no further gain, profiles/NOTES.md round 5.)  Units past the parking space, groups too wide to
+// park, and unsplit requests' output rows are stored at once, as in the launch-per-item kernel.
+// Same arithmetic, same order of the keys within a unit, same bits as the launch-per-item kernel.
+template <typename Tag, int D>
+__global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_pw_kernel(DecodeArgs a) {
+  typedef DmCfg<D> C;
+  typedef u32x4 raw_t;
+  constexpr int SRC_ROW_B = 2 * D, SRC_CH_B = 16;
+  constexpr int TK = C::TK, ROW_B = C::ROW_B, CPR = C::CPR, RPL = C::RPL, NLD = C::NLD;
+  constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK, TILE_B = C::TILE_B;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int G = a.Hq / a.Hkv;
+  const int col = lane & 15, kq = lane >> 4;
+  char* ldsK = lds + wave * 2 * TILE_B;
+  char* ldsV = ldsK + TILE_B;
+  const float qk_scale = a.sm_scale * kLog2eM;
+  const int ld_row = lane / CPR, ld_ch = lane % CPR;
+  const uint32_t tok_bytes = (uint32_t)(a.kv_stride * 2);
+  const int64_t v_minus_k = a.vbuf - a.kbuf;
+  const int i16 = lane & 15;
+  const int tr_row = 4 * kq + (i16 >> 2);
+
+  const int hgroups = a.Hkv / 4;
+  const int nunits = a.plan[0] * hgroups;            // (plan item, head quad) units, in the plan's longest-first order
+  const int chunk = a.plan[1];
+  const int32_t* items = a.plan + kPlanHdr + a.bs;
+  const int W = (int)gridDim.x, w = (int)blockIdx.x;
+
+  struct Unit { int b, c, seq, cs, ce, nsplit, slot0, hk; const int32_t* idx_row; };
+  // A unit's record is read with SCALAR loads written as asm: inside the loop hipcc turns these reads into vector loads
+  // (the kernel's own stores may alias them as far as it knows), each followed by s_waitcnt vmcnt(0) - drained round
+  // trips per unit with no gather in flight.  A scalar load waits on lgkmcnt only: the tile in flight stays in flight.
+  // Two dependent rounds: the item's (b, c), then everything indexed by b at once.
+  auto load_item = [&](int item, int& b, int& c) {
+    int64_t bc;
+    const int64_t* q = (const int64_t*)items + item;       // (b, c) as one 8-byte record (items is 8-byte aligned:
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bc) : "s"(q) : "memory");   // bs + 4 words in)
+    b = (int)(uint32_t)bc;
+    c = (int)(bc >> 32);
+  };
+  const void* kv_or_seq = a.kv_start ? a.kv_start : a.seq_lens;   // (a valid address either way)
+  auto load_request = [&](int b, int& slot0, int64_t& seq, int64_t& req, int64_t& kv0) {
+    const int32_t* ps = a.plan + kPlanHdr + b;
+    if (a.idx64) {
+      const int64_t *p1 = (const int64_t*)a.seq_lens + b, *p2 = (const int64_t*)a.req_idx + b, *p3 = (const int64_t*)kv_or_seq + b;
+      asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dwordx2 %1, %5, 0x0\n\ts_load_dwordx2 %2, %6, 0x0\n\t"
+                   "s_load_dwordx2 %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&s"(slot0), "=&s"(seq), "=&s"(req), "=&s"(kv0) : "s"(ps), "s"(p1), "s"(p2), "s"(p3) : "memory");
+    } else {
+      const int32_t *p1 = (const int32_t*)a.seq_lens + b, *p2 = (const int32_t*)a.req_idx + b, *p3 = (const int32_t*)kv_or_seq + b;
+      int s32, r32, k32;
+      asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\t"
+                   "s_load_dword %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&s"(slot0), "=&s"(s32), "=&s"(r32), "=&s"(k32) : "s"(ps), "s"(p1), "s"(p2), "s"(p3) : "memory");
+      seq = s32; req = r32; kv0 = k32;
+    }
+    if (!a.kv_start) kv0 = 0;
+  };
+  int round = 0;
+  // this workgroup's unit of the next round (serpentine dealing), skipping empty ones (never listed by sp_decode_plan;
+  // a cut plan); false when its list is exhausted
+  auto next_unit = [&](Unit& u) -> bool {
+    for (;;) {
+      const int T = __builtin_amdgcn_readfirstlane(round * W + ((round & 1) ? W - 1 - w : w));
+      ++round;
+      if (T >= nunits) return false;
+      const int item = T / hgroups;
+      u.hk = (T - item * hgroups) * 4 + wave;
+      load_item(item, u.b, u.c);
+      int64_t seq, req, kv0;
+      load_request(u.b, u.slot0, seq, req, kv0);
+      u.seq = (int)min(seq, (int64_t)a.max_len);
+      u.cs = u.c * chunk;
+      u.ce = min(u.cs + chunk, u.seq);
+      u.nsplit = (u.seq + chunk - 1) / chunk;
+      u.idx_row = a.r2t + req * a.r2t_stride + kv0;
+      if (u.cs < u.seq && u.slot0 + u.c < a.max_slots) return true;
+    }
+  };
+
+  Unit cur;
+  if (!next_unit(cur)) return;
+
+  uint64_t kbase[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int R = i * RPL + ld_row;
+    kbase[i] = (uint64_t)(uintptr_t)a.kbuf + (uint64_t)cur.hk * SRC_ROW_B + (uint64_t)((ld_ch ^ (R & (CPR - 1))) * SRC_CH_B);
+  }
+  u32x4 qf[KSTEPS];
+  auto load_q = [&](const Unit& u) {
+    const int hcol = min(col, G - 1);
+    const char* qp = (const char*)a.q + ((int64_t)u.b * a.q_stride + (int64_t)(u.hk * G + hcol) * D + 8 * kq) * 2;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) qf[s] = ld16(qp + s * 64);
+  };
+  load_q(cur);
+
+  f32x4_t oacc[DBLK];
+#pragma unroll
+  for (int db = 0; db < DBLK; ++db) oacc[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = kNegBigM, l_run = 0.f;
+
+  raw_t kr[NLD], vr[NLD];
+  auto issue = [&](int tile, int idxreg) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int key = tile * TK + i * RPL + ld_row;
+      const uint32_t slot = (uint32_t)__shfl(idxreg, key & 63, 64);
+      typedef const raw_t __attribute__((address_space(1)))* gptr_t;
+      const uint64_t ka = kbase[i] + (uint64_t)slot * tok_bytes;
+      kr[i] = __builtin_nontemporal_load((gptr_t)ka);
+      vr[i] = __builtin_nontemporal_load((gptr_t)(ka + (uint64_t)v_minus_k));
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int R = i * RPL + ld_row;
+      st16(ldsK + R * ROW_B + ld_ch * 16, kr[i]);
+      st16(ldsV + R * ROW_B + ld_ch * 16, vr[i]);
+    }
+  };
+  auto consume = [&](int tile, int n) {
+    f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    {
+      const int R = lane & 15;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int cg = 4 * ks + kq;
+        const u32x4 kf = ld16(ldsK + R * ROW_B + ((cg ^ (R & (CPR - 1))) * 16));
+        s = mfma_qk<Tag>(kf, qf[ks], s);
+      }
+    }
+    float x[4], mx = kNegBigM;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v = s[j] * qk_scale;
+      x[j] = (tile * TK + 4 * kq + j < n) ? v : -INFINITY;
+      mx = fmaxf(mx, x[j]);
+    }
+    mx = fmaxf(mx, xchg16m(mx));
+    mx = fmaxf(mx, xchg32m(mx));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      x[j] = __builtin_amdgcn_exp2f(x[j] - m_new);
+      psum += x[j];
+    }
+    psum += xchg16m(psum);
+    psum += xchg32m(psum);
+    l_run = l_run * alpha + psum;
+    u32x2 pf;
+    pf[0] = pack2m<Tag>(x[0], x[1]);
+    pf[1] = pack2m<Tag>(x[2], x[3]);
+#pragma unroll
+    for (int db = 0; db < DBLK; ++db) {
+      const int cg = 2 * db + ((i16 & 3) >> 1);
+      const char* vp = ldsV + tr_row * ROW_B + ((cg ^ (tr_row & (CPR - 1))) * 16) + 8 * (i16 & 1);
+      const s16x4_m vt = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_m*)vp);
+      const u32x2 vf = __builtin_bit_cast(u32x2, vt);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[db][r] *= alpha;
+      oacc[db] = mfma_pv<Tag>(vf, pf, oacc[db]);
+    }
+  };
+  // Parking space of this wave behind the tiles: records of [G rows of D floats | 16 log-sum-exps | kv head, slot]
+  const int park_rows_b = G * D * 4;
+  const int park_unit_b = park_rows_b + 64 + 16;
+  const int park_cap = kDmParkWaveB / park_unit_b;          // 2 at G = 4, D = 128; 0: the group is too wide to park
+  char* park = lds + 4 * 2 * TILE_B + wave * kDmParkWaveB;
+  int parked = 0;
+  auto flush_parked = [&]() {
+    for (int k = 0; k < parked; ++k) {
+      const char* src = park + k * park_unit_b;
+      const int hk_ = __builtin_amdgcn_readfirstlane(*(const int*)(src + park_rows_b + 64));
+      const int slot_ = __builtin_amdgcn_readfirstlane(*(const int*)(src + park_rows_b + 68));
+      for (int off = lane * 16; off < park_rows_b; off += 1024) {     // whole rows, 16 B per lane
+        const int row = off / (D * 4), within = off - row * (D * 4);
+        const int64_t pi = (int64_t)(hk_ * G + row) * a.max_slots + slot_;
+        *(u32x4*)((char*)(a.part_o + pi * D) + within) = ld16(src + off);
+      }
+      if (lane < G) a.part_lse[(int64_t)(hk_ * G + lane) * a.max_slots + slot_] = *(const float*)(src + park_rows_b + lane * 4);
+    }
+  };
+  // a unit's result: straight to the output (an unsplit request) or as a partial for the merge launch
+  auto write_unit = [&](const Unit& u) {
+    if (u.nsplit > 1 && parked < park_cap) {
+      char* dst = park + parked * park_unit_b;
+      if (col < G) {
+        const float inv = 1.0f / l_run;
+#pragma unroll
+        for (int db = 0; db < DBLK; ++db) {
+          u32x4 w;
+          w[0] = as_u32(oacc[db][0] * inv); w[1] = as_u32(oacc[db][1] * inv);
+          w[2] = as_u32(oacc[db][2] * inv); w[3] = as_u32(oacc[db][3] * inv);
+          st16(dst + col * (D * 4) + (16 * db + 4 * kq) * 4, w);
+        }
+        if (kq == 0) *(float*)(dst + park_rows_b + col * 4) = m_run + __builtin_amdgcn_logf(l_run);
+      }
+      if (lane == 0) {
+        *(int*)(dst + park_rows_b + 64) = u.hk;
+        *(int*)(dst + park_rows_b + 68) = u.slot0 + u.c;
+      }
+      ++parked;
+      return;
+    }
+    if (col >= G) return;
+    const int h = u.hk * G + col;
+    float inv = 1.0f / l_run;
+    if (u.nsplit == 1) {
+      inv *= a.out_scale;
+      char* op = (char*)a.out + ((int64_t)u.b * a.o_stride + (int64_t)h * D + 4 * kq) * 2;
+#pragma unroll
+      for (int db = 0; db < DBLK; ++db) {
+        u32x2 w;
+        w[0] = pack2m<Tag>(oacc[db][0] * inv, oacc[db][1] * inv);
+        w[1] = pack2m<Tag>(oacc[db][2] * inv, oacc[db][3] * inv);
+        *(u32x2*)(op + db * 32) = w;
+      }
+    } else {
+      const int64_t pi = (int64_t)h * a.max_slots + (u.slot0 + u.c);
+      float* pp = a.part_o + pi * D + 4 * kq;
+#pragma unroll
+      for (int db = 0; db < DBLK; ++db)
+        *(float4*)(pp + 16 * db) = make_float4(oacc[db][0] * inv, oacc[db][1] * inv, oacc[db][2] * inv, oacc[db][3] * inv);
+      if (kq == 0) a.part_lse[pi] = m_run + __builtin_amdgcn_logf(l_run);
+    }
+  };
+
+  int pos = cur.cs;
+  int curidx = (pos + lane < cur.ce) ? cur.idx_row[pos + lane] : 0;
+  issue(0, curidx);
+  for (;;) {
+    const int n = min(64, cur.ce - pos);
+    const int ntile = (n + TK - 1) / TK;
+    const bool last_piece = pos + 64 >= cur.ce;
+    Unit nxt;
+    bool have_next = false;
+    int nextidx = 0;
+    if (last_piece) {
+      have_next = next_unit(nxt);
+      if (have_next) nextidx = (nxt.cs + lane < nxt.ce) ? nxt.idx_row[nxt.cs + lane] : 0;
+    } else {
+      nextidx = (pos + 64 + lane < cur.ce) ? cur.idx_row[pos + 64 + lane] : 0;
+    }
+    for (int t = 0; t < ntile; ++t) {
+      stage();
+      if (t + 1 < ntile) {
+        issue(t + 1, curidx);
+      } else if (!last_piece) {
+        issue(0, nextidx);                          // the next piece's first tile: no drain between pieces
+      } else if (have_next) {                       // the next UNIT's first tile: no drain between units
+        const int64_t dh = (int64_t)(nxt.hk - cur.hk) * SRC_ROW_B;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) kbase[i] += (uint64_t)dh;
+        issue(0, nextidx);
+      }
+      consume(t, n);
+    }
+    if (last_piece) {
+      write_unit(cur);
+      if (!have_next) break;
+      cur = nxt;
+      load_q(cur);
+#pragma unroll
+      for (int db = 0; db < DBLK; ++db) oacc[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      m_run = kNegBigM;
+      l_run = 0.f;
+      pos = cur.cs;
+    } else {
+      pos += 64;
+    }
+    curidx = nextidx;
+  }
+  flush_parked();
+}
+
 template <typename Tag, int D, bool KV8>
 static int launch_dm_kv(const DecodeArgs& a, hipStream_t st) {
   typedef DmCfg<D> C;
@@ -436,6 +738,35 @@ static int launch_dm_kv(const DecodeArgs& a, hipStream_t st) {
   // exits at once); plan-less: the static (request, split) grid
   const int64_t items = a.plan ? (int64_t)a.max_slots : (int64_t)a.bs * a.num_splits;
   if (a.Hkv % 4 == 0 && a.o_stride % 4 == 0) {
+    if constexpr (!KV8) {
+      // the persistent form: planned launches of the default (always-streaming, no soft-cap) configuration
+      if (a.plan && a.persist && a.logit_cap <= 0.f && a.nt_min_keys == 0) {
+        constexpr int kLds = C::kStageBytes + C::WAVES * kDmParkWaveB;
+        // as many workgroups as the chip holds at once (asked of the runtime once per instantiation), or the debug value
+        static int resident = 0;
+        if (!resident) {
+          int dev = 0, per_cu = 0;
+          hipDeviceProp_t prop;
+          if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+              hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_mfma_pw_kernel<Tag, D>, 256, kLds) != hipSuccess ||
+              per_cu < 1)
+            return SP_ERR_LAUNCH;
+          resident = per_cu * prop.multiProcessorCount;
+        }
+        // ... when the step can have more units than that: the lengths bound the items by bs x ceil(max_len / chunk)
+        // as well (a graph's launch covers >= 1024 whatever the batch).  A launch of fewer units is a matter of
+        // latency, not of bandwidth, and there the launch-per-item kernel is the faster one (bs 1, 1024 keys: 34 vs 41 us).
+        const int64_t bound = (int64_t)a.bs * a.num_splits;
+        const int64_t wgs = (items < bound ? items : bound) * (a.Hkv / 4);
+        const int64_t want = a.persist > 0 ? a.persist : resident;
+        if (wgs > want || a.persist > 0) {
+          const unsigned grid = (unsigned)(wgs < want ? wgs : want);
+          decode_mfma_pw_kernel<Tag, D><<<dim3(grid), 256, kLds, st>>>(a);
+          SP_LAUNCH_CHECK();
+          return SP_OK;
+        }
+      }
+    }
     const unsigned grid = (unsigned)(items * (a.Hkv / 4));
     decode_mfma_kernel<Tag, D, true, KV8><<<dim3(grid), 256, C::kLdsBytes, st>>>(a);
   } else {

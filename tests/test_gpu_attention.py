@@ -816,6 +816,54 @@ def test_decode_streaming_gathers_change_no_bit(nat, kv, Hq, Hkv, D):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (64, 8, 128), (64, 4, 128), (8, 8, 128), (16, 4, 64), (24, 4, 64)])
+def test_decode_persistent_form_gives_the_same_bits(nat, dt, Hq, Hkv, D):
+    """The persistent form of the head-per-wave kernel (decode_mfma.hip, round 5: resident workgroups take the plan's
+    units in serpentine order and park split partials in LDS until they run out of units) against the launch-per-item
+    kernel: same bits with 3, 8, 64 workgroups (many units per wave: the parking space overflows into direct stores;
+    groups of 4 and 6 park two units per wave, 8 one, 1 seven, 16 none), with the default count, on int32 and int64
+    index tensors, behind a kv_start window, launch after launch on one plan over a workspace full of stale partials;
+    and the oracle's numbers.  sp_debug_set("decode_persist", 0) is the launch-per-item kernel everywhere."""
+    dtype = DTYPES[dt]
+    g = torch.Generator().manual_seed(Hq * 17 + Hkv + D)
+    bs, chunk, max_len = 48, 64, 1400
+    lens = torch.randint(1, 600, (bs,), generator=g)
+    lens[:6] = torch.tensor([1400, 1025, 64, 65, 1, 0])      # 22 and 17 splits, one, two, a single key, an empty row
+    start = torch.randint(0, 4, (bs,), generator=g)
+    p = paged_problem(700 + Hq + D, bs, Hq, Hkv, D, [int(l) + 4 for l in lens], dtype, DEV)
+    q, req = p["q"], p["req_pool_indices"]
+    seq = lens.to(DEV)
+    slots = nat.decode_plan_slots(bs, max_len, chunk, kv_tokens=int(lens.sum()))
+    ws = torch.empty(nat.decode_workspace_bytes(bs, Hq, D, max_len, chunk, slots), dtype=torch.uint8, device=DEV)
+    plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, slots) // 4, dtype=torch.int32, device=DEV)
+    outs = {}
+    try:
+        for idx_dtype in (torch.int32, torch.int64):
+            s_, r_, k0 = seq.to(idx_dtype), req.to(idx_dtype), start.to(DEV).to(idx_dtype)
+            nat.decode_plan(plan, s_, max_len, chunk, slots)
+            for persist in (0, 3, 8, 64, -1):
+                nat.debug_set("decode_persist", persist)
+                for rep in range(2):
+                    ws.fill_(0x7f if rep else 0xff)
+                    o = torch.zeros_like(q)
+                    nat.decode_attention(o, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], r_, s_, D ** -0.5, 0.0,
+                                         max_len, chunk, ws, k0, plan, max_slots=slots)
+                    outs[(idx_dtype, persist, rep)] = o
+    finally:
+        nat.debug_set("decode_persist", -1)
+    base = outs[(torch.int32, 0, 0)]
+    assert torch.isfinite(base.float()).all()
+    for key, o in outs.items():
+        assert torch.equal(o, base), key
+    assert float(base[5].float().abs().max()) == 0.0, "an empty row is left untouched"
+    c = cpu(p)
+    fn = lambda v: ops.decode_attention(c["q"].float(), c["k_buffer"].float(), v, c["req_to_token"],
+                                        c["req_pool_indices"], lens, D ** -0.5, 0.0, start)
+    live = [r for r in range(bs) if r != 5]
+    check_vs_oracle(base, dtype, f"persistent decode {dt} Hq{Hq} Hkv{Hkv} D{D}", c["v_buffer"].float(), fn, rows=live)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("Hq,Hkv,D", [(8, 1, 128), (16, 2, 128), (16, 1, 128), (32, 8, 128), (4, 4, 128), (24, 4, 64),
                                       (6, 2, 64)])
 def test_decode_merge_of_many_splits(nat, dt, Hq, Hkv, D):
