@@ -1006,7 +1006,9 @@ def main():
         achieved = alg / (avg_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(alg, args)
         roofline = {"bound": "hbm",
-                    "kernel": "decode_mfma_kernel+decode_merge_kernel",
+                    # (the launches carry the plan's range geometry where the backend has one: include/scratchpad_hip.h)
+                    "kernel": ("decode_mfma_range_kernel" if layer_calls[-1][1].get("ranges") else "decode_mfma_kernel")
+                    + "+decode_merge_kernel",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "traffic_source": traffic_src,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 7
+#define SP_ABI_VERSION 8
 #define SP_API __attribute__((visibility("default")))
 
 typedef enum { SP_F32 = 0, SP_F16 = 1, SP_BF16 = 2, SP_FP8_E5M2 = 3 /* KV pool only */ } sp_dtype;
@@ -163,6 +163,24 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  *     batches); a plan never changes the result, only which workgroup computes which split.
  * workspace: sp_decode_attention_workspace_bytes(max_slots, ...); plan: sp_decode_plan_bytes().
  *
+ * Range geometry (ABI 8).  A plan built with `ranges` > 0 carries a second section,
+ * [rcount, R, 0, 0 | pos[bs + 1] | start[ranges]], behind the items: the step's keys, request after request in batch
+ * order, form one line (request b at pos[b] .. pos[b] + len_b, then 16 empty positions - what a request costs a
+ * workgroup beyond its keys); the line is cut into rcount <= ranges equal pieces of R positions (R a multiple of 16,
+ * at least 64) and start[j] is the first request with a key at or after j * R (-1: piece j holds none).  A launch
+ * given the same `ranges` runs one workgroup per (piece, four kv heads): it walks its piece - the tail of one request,
+ * whole requests, the head of another - so every workgroup gathers the same number of keys whatever the lengths are,
+ * there is no split size to choose, and a request is written straight to the output unless a cut falls inside it.  A
+ * request whose keys lie in pieces jf .. jl > jf leaves its partials in slots b + jf .. b + jl (b + j grows along the
+ * line: no two (request, piece) pairs share a slot) and the merge launch combines them: the workspace then holds
+ * batch_size + ranges slots, whatever sum(seq_lens) is - the overflow below cannot happen on this path.
+ * sp_decode_ranges() is the piece count the library wants for a shape: the workgroups the chip holds at once over the
+ * head quads (384 for 8 kv heads of 128 on MI355X), or 0 where the range kernel does not apply (a byte pool, fp32,
+ * num_kv_heads % 4 != 0, groups wider than 16).  Launches it does not take (those shapes, a logit soft-cap, out rows
+ * not 8-byte aligned, sp_debug_set("decode_ranges", 0)) use the plan's (request, split) items as before: a plan
+ * always carries both.  Requires batch_size * (max_seq_len + 16) < 2^31 (else SP_ERR_INVALID_ARG from sp_decode_plan;
+ * pass ranges = 0).  Results of the two geometries differ in the last bits (another split of the same sums).
+ *
  * Overflow (ABI 6).  The plan's word 2 holds the number of items the lengths NEED; when it exceeds `max_slots`
  * (the caller's bound on sum(seq_lens) was too small) the surplus splits are not computed and the affected
  * output rows are wrong or unwritten.  Nothing on the device reports this by itself: the caller reads plan[2]
@@ -185,17 +203,18 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  * k / k_scale and v / v_scale, so logits are multiplied by k_scale and the output by v_scale.    */
 SP_API int64_t sp_decode_plan_slots(int batch_size, int64_t kv_tokens, int64_t max_seq_len, int chunk);
 SP_API size_t sp_decode_attention_workspace_bytes(int64_t max_slots, int num_q_heads, int v_head_dim);
-SP_API size_t sp_decode_plan_bytes(int batch_size, int64_t max_slots);
+SP_API int sp_decode_ranges(int num_q_heads, int num_kv_heads, int head_dim, int dtype, int kv_dtype);
+SP_API size_t sp_decode_plan_bytes(int batch_size, int64_t max_slots, int ranges);
 SP_API int sp_decode_plan(int32_t* plan, size_t plan_bytes, const void* seq_lens, int idx64,
-                   int batch_size, int64_t max_seq_len, int chunk, int64_t max_slots, void* stream);
+                   int batch_size, int64_t max_seq_len, int chunk, int64_t max_slots, int ranges, void* stream);
 SP_API int sp_decode_attention(void* out, const void* q, const void* k_buffer, const void* v_buffer,
                         const int32_t* req_to_token, int64_t req_to_token_stride,
                         const void* req_pool_indices, const void* seq_lens, const void* kv_start,
                         int idx64, int batch_size, int num_q_heads, int num_kv_heads,
                         int head_dim, int64_t q_stride, int64_t out_stride,
                         int64_t kv_buffer_stride, float sm_scale, float logit_cap, float k_scale,
-                        float v_scale, int64_t max_seq_len, int chunk, int64_t max_slots, void* workspace,
-                        size_t workspace_bytes, const int32_t* plan, int dtype,
+                        float v_scale, int64_t max_seq_len, int chunk, int64_t max_slots, int ranges,
+                        void* workspace, size_t workspace_bytes, const int32_t* plan, int dtype,
                         int kv_dtype, void* stream);
 
 /* ---- Ragged extend (prefill) attention: replaces extend_attention_fwd (nn/attention/

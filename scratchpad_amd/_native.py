@@ -66,11 +66,12 @@ SIGNATURES = {
     "sp_clamp_position": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "sp_decode_plan_slots": (_i64, [_i32, _i64, _i64, _i32]),
     "sp_decode_attention_workspace_bytes": (_sz, [_i64, _i32, _i32]),
-    "sp_decode_plan_bytes": (_sz, [_i32, _i64]),
-    "sp_decode_plan": (_i32, [_vp, _sz, _vp, _i32, _i32, _i64, _i32, _i64, _vp]),
+    "sp_decode_ranges": (_i32, [_i32, _i32, _i32, _i32, _i32]),
+    "sp_decode_plan_bytes": (_sz, [_i32, _i64, _i32]),
+    "sp_decode_plan": (_i32, [_vp, _sz, _vp, _i32, _i32, _i64, _i32, _i64, _i32, _vp]),
     "sp_decode_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32,
                                    _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _i64, _i32, _i64,
-                                   _vp, _sz, _vp, _i32, _i32, _vp]),
+                                   _i32, _vp, _sz, _vp, _i32, _i32, _vp]),
     "sp_extend_attention_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32]),
     "sp_extend_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp,
                                    _i32, _i64, _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32, _f32, _f32,
@@ -119,7 +120,7 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.sp_abi_version() != 7:
+    if lib.sp_abi_version() != 8:
         raise RuntimeError("libscratchpad_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -355,28 +356,47 @@ def decode_plan_slots(bs: int, max_seq_len: int, chunk: int, kv_tokens: Optional
 
 
 def decode_workspace_bytes(bs: int, Hq: int, Dv: int, max_seq_len: int, chunk: int,
-                           max_slots: Optional[int] = None) -> int:
-    """Split workspace for `max_slots` partial slots (default: the static bound bs * ceil(max_seq_len / chunk))."""
+                           max_slots: Optional[int] = None, ranges: int = 0) -> int:
+    """Split workspace for `max_slots` partial slots (default: the static bound bs * ceil(max_seq_len / chunk)) and,
+    with `ranges`, for the bs + ranges slots of the range geometry - whichever is larger."""
     if max_slots is None:
         max_slots = decode_plan_slots(bs, max_seq_len, chunk)
+    if ranges > 0:
+        max_slots = max(max_slots, bs + ranges)
     return int(load().sp_decode_attention_workspace_bytes(max_slots, Hq, Dv))
+
+
+RANGE_HEADER_WORDS = 4         # [pieces in use, piece length R, 0, 0] in front of pos[bs + 1] and start[ranges]
+RANGE_REQUEST_COST = 16        # positions a request takes on the line beyond its keys (attention_internal.h)
+
+
+def decode_ranges(Hq: int, Hkv: int, D: int, dtype: torch.dtype, kv_dtype: Optional[torch.dtype] = None) -> int:
+    """Pieces per head quad the range kernel wants for this shape (sp_decode_ranges): the workgroups the chip holds at
+    once over the head quads; 0 where the range geometry does not apply (byte pool, fp32, Hkv % 4 != 0, G > 16)."""
+    dt = _DTYPES.get(dtype)
+    if dt is None:
+        return 0
+    kv = SP_FP8_E5M2 if kv_dtype in _FP8_POOL_DTYPES else dt
+    return int(load().sp_decode_ranges(Hq, Hkv, D, dt, kv))
 
 
 PLAN_HEADER_WORDS = 4          # [items listed, chunk, items the lengths need, keys the step gathers per kv head]
 
 
-def decode_plan_bytes(bs: int, max_seq_len: int, chunk: int, max_slots: Optional[int] = None) -> int:
+def decode_plan_bytes(bs: int, max_seq_len: int, chunk: int, max_slots: Optional[int] = None, ranges: int = 0) -> int:
     if max_slots is None:
         max_slots = decode_plan_slots(bs, max_seq_len, chunk)
-    return int(load().sp_decode_plan_bytes(bs, max_slots))
+    return int(load().sp_decode_plan_bytes(bs, max_slots, ranges))
 
 
 def decode_plan(plan: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int, chunk: int,
-                max_slots: Optional[int] = None) -> None:
+                max_slots: Optional[int] = None, ranges: int = 0) -> None:
     """Fill `plan` (int32: [count, chunk, needed, keys | slot0[bs] | (request, split) x max_slots]) for this
     step's lengths.  `max_slots`: the item / partial-slot capacity the launches using this plan are given (default:
     the static bound bs * ceil(max_seq_len / chunk)).
-    plan[2] > max_slots afterwards means the capacity was too small (see decode_plan_overflow)."""
+    plan[2] > max_slots afterwards means the capacity was too small (see decode_plan_overflow).
+    `ranges` > 0 appends the range geometry ([pieces, R, 0, 0 | pos[bs + 1] | start[ranges]], include/scratchpad_hip.h)
+    for launches given the same `ranges`."""
     _gpu(plan, seq_lens)
     if plan.dtype != torch.int32 or seq_lens.dtype not in (torch.int32, torch.int64):
         raise RuntimeError("decode_plan: plan must be int32, seq_lens int32/int64")
@@ -385,7 +405,7 @@ def decode_plan(plan: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int, ch
         max_slots = decode_plan_slots(seq_lens.shape[0], max_seq_len, chunk)
     _check(load().sp_decode_plan(plan.data_ptr(), plan.numel() * 4, seq_lens.data_ptr(),
                                  int(seq_lens.dtype == torch.int64), seq_lens.shape[0], max_seq_len,
-                                 chunk, max_slots, _stream()), "sp_decode_plan")
+                                 chunk, max_slots, ranges, _stream()), "sp_decode_plan")
 
 
 def decode_plan_overflow(header, max_slots: int) -> Optional[str]:
@@ -405,10 +425,11 @@ def decode_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
                      logit_cap: float, max_seq_len: int, chunk: int, workspace: torch.Tensor,
                      kv_start: Optional[torch.Tensor] = None,
                      plan: Optional[torch.Tensor] = None, k_scale: Optional[float] = None,
-                     v_scale: Optional[float] = None, max_slots: Optional[int] = None) -> None:
+                     v_scale: Optional[float] = None, max_slots: Optional[int] = None, ranges: int = 0) -> None:
     """q, out: [bs, Hq, D] (row stride free); buffers [P+1, Hkv, D].  k_scale / v_scale: the
     scales the store divided by (None = 1).  With a plan: `max_slots` = the capacity the plan was built
-    for, `chunk` = the smallest split size the plan may carry (the kernels read the actual one from it)."""
+    for, `chunk` = the smallest split size the plan may carry (the kernels read the actual one from it), `ranges` =
+    the pieces its range section was built for (0: none; the workspace then holds max(max_slots, bs + ranges) slots)."""
     _gpu(out, q, k_buffer, v_buffer, req_to_token, req_pool_indices, seq_lens, workspace, kv_start, plan)
     bs, Hq, D = q.shape
     if q.stride(2) != 1 or q.stride(1) != D or out.stride(2) != 1 or out.stride(1) != D:
@@ -427,7 +448,8 @@ def decode_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
         req_to_token.stride(0), req.data_ptr(), seq.data_ptr(), _ptr(kv_start), idx64, bs, Hq,
         k_buffer.shape[1], D, q.stride(0), out.stride(0), k_buffer.stride(0), sm_scale, logit_cap,
         1.0 if k_scale is None else float(k_scale), 1.0 if v_scale is None else float(v_scale),
-        max_seq_len, chunk, max_slots, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+        max_seq_len, chunk, max_slots, ranges if plan is not None else 0, workspace.data_ptr(),
+        workspace.numel() * workspace.element_size(),
         _ptr(plan), _dt(q), kv_dt, _stream()), "sp_decode_attention")
 
 

@@ -147,6 +147,13 @@ class HipAttnBackend(AttentionBackend):
         self._plan_checks = []         # (pinned header copy, event, max_slots) of plans not yet checked
         self._plan_hosts = []          # pinned buffers + events to reuse
         self._plan_lock = threading.Lock()   # the overlap worker checks from the scheduler thread (tp_worker_client.py)
+        # Range geometry (include/scratchpad_hip.h, ABI 8): the pieces the step's keys are cut into, one workgroup per
+        # (piece, four kv heads) - what the chip holds at once; 0 where the range kernel does not take the shape (a
+        # byte pool, fp32, kv heads not in fours), and those launches use the plan's (request, split) items below.
+        # SP_DECODE_RANGES=0 switches it off, =N forces N pieces (A/B runs).
+        env = os.environ.get("SP_DECODE_RANGES", "")
+        self.decode_ranges = int(env) if env else _native.decode_ranges(
+            self.num_head, self.num_kv_head, self.head_dim, getattr(model_runner, "dtype", torch.bfloat16), self.kv_dtype)
 
     # ---------------------------------------------------------------- launch planning
     def _head_groups(self, dtype: torch.dtype) -> int:
@@ -205,13 +212,19 @@ class HipAttnBackend(AttentionBackend):
             chunk *= 2
         return chunk
 
+    def _ranges_for(self, bs: int, max_len: int) -> int:
+        """pieces of the range geometry for a step (0: its line does not fit the plan's int32 positions)"""
+        return self.decode_ranges if bs * (max_len + _native.RANGE_REQUEST_COST) < 2 ** 31 - 1 else 0
+
     def _build_plans(self, plans, bs, windows, max_len, max_slots=None, hints=(None, None, None)):
         """One split plan per kv window (self-attention lens; encoder lens for cross-attention - the
         reference keeps two flashinfer wrappers for the same reason, flashinfer_backend.py:121-131; the
         sliding-window layers' lens).  windows: per plan (lens tensor or None, host bound on their sum).
         Built once per step, read by every layer's launch.  Each plan carries its own split size; returns
-        per plan (tensor, max_slots, smallest chunk) and the largest max_slots (what the workspace must hold)."""
+        per plan (tensor, max_slots, smallest chunk, ranges) and the largest max_slots (what the workspace must hold).
+        Every plan also carries the range geometry (`ranges` pieces) where the backend's shape has one."""
         out, need_slots = [], 1
+        ranges = self._ranges_for(bs, max_len)
         for i, (lens, kv_tokens) in enumerate(windows):
             if lens is None:
                 out.append(None)
@@ -222,15 +235,15 @@ class HipAttnBackend(AttentionBackend):
             else:                          # graph replay: the captured launch's capacity is fixed
                 slots = max_slots
                 chunk = self._fit_chunk(chunk, bs, kv_tokens, max_len, slots)
-            need = _native.decode_plan_bytes(bs, max_len, chunk, slots) // 4
+            need = _native.decode_plan_bytes(bs, max_len, chunk, slots, ranges) // 4
             if plans[i].numel() < need:
                 plans[i] = torch.empty(need, dtype=torch.int32, device=self.device)
-            _native.decode_plan(plans[i], lens, max_len, chunk, slots)
+            _native.decode_plan(plans[i], lens, max_len, chunk, slots, ranges)
             self._watch_plan(plans[i], slots)
             # third field: the smallest split size this plan buffer may carry when the launch runs - the
             # step's own chunk (eager), MIN_CHUNK under graph replay (a later step's plan may use any size)
-            out.append((plans[i], slots, chunk if max_slots is None else self.MIN_CHUNK))
-            need_slots = max(need_slots, slots)
+            out.append((plans[i], slots, chunk if max_slots is None else self.MIN_CHUNK, ranges))
+            need_slots = max(need_slots, slots, bs + ranges if ranges else 0)
         return tuple(out), need_slots
 
     # ---------------------------------------------------------------- plan overflow (an understated seq_lens_sum)
@@ -336,9 +349,11 @@ class HipAttnBackend(AttentionBackend):
         self.cuda_graph_max_seq_len = self.max_context_len
         slots = self._graph_slots(max_bs)
         self._graph_ws = torch.empty(_native.decode_workspace_bytes(max_bs, self.num_head, self.v_head_dim,
-                                                                    self.cuda_graph_max_seq_len, self.MIN_CHUNK, slots),
+                                                                    self.cuda_graph_max_seq_len, self.MIN_CHUNK, slots,
+                                                                    self._ranges_for(max_bs, self.cuda_graph_max_seq_len)),
                                      dtype=torch.uint8, device=self.device)
-        n = _native.decode_plan_bytes(max_bs, self.cuda_graph_max_seq_len, self.MIN_CHUNK, slots) // 4
+        ranges = self._ranges_for(max_bs, self.cuda_graph_max_seq_len)
+        n = _native.decode_plan_bytes(max_bs, self.cuda_graph_max_seq_len, self.MIN_CHUNK, slots, ranges) // 4
         self._graph_plans = [torch.empty(n, dtype=torch.int32, device=self.device) for _ in range(3)]
         self._graph_max_bs = max_bs
         if self.sliding_window_size is not None:
@@ -490,12 +505,12 @@ class HipAttnBackend(AttentionBackend):
         k_scale, v_scale = self._kv_scales(layer)
         seq_lens, kv_start = self._kv_window(layer, forward_batch)
         entry = plans[2] if self._is_windowed(layer) else (plans[1] if layer.is_cross_attention else plans[0])
-        plan, slots, chunk = entry if entry is not None else (None, None, chunk)
+        plan, slots, chunk, ranges = entry if entry is not None else (None, None, chunk, 0)
         kb, vb = forward_batch.token_to_kv_pool.get_kv_buffer(layer.layer_id)
         _native.decode_attention(
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), kb, vb,
             forward_batch.req_to_token_pool.req_to_token, forward_batch.req_pool_indices, seq_lens,
             layer.scaling, layer.logit_cap, max_len, chunk, ws, kv_start, plan,
-            k_scale=k_scale, v_scale=v_scale, max_slots=slots)
+            k_scale=k_scale, v_scale=v_scale, max_slots=slots, ranges=ranges)
         return o

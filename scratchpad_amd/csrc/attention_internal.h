@@ -38,12 +38,35 @@ struct DecodeArgs {
   // which only a launch of several rounds of workgroups hides.  0 = always (the default), INT_MAX = never; a plan-less
   // launch has no key count and streams only when the threshold is 0.
   int nt_min_keys;
-  // the persistent head-per-wave kernel (decode_mfma.hip) takes planned launches of the default configuration:
-  // -1 = with as many workgroups as the chip holds (the default), n > 0 = with n workgroups, 0 = never
-  int persist;
+  // RANGE geometry (the plan's second section, sp_decode_plan with ranges > 0; decode_mfma.hip's range kernel):
+  // [rcount, R, 0, 0 | pos[bs + 1] | start[ranges]].  The step's keys, request after request in batch order, form one
+  // line on which request b takes pos[b] .. pos[b] + len_b and then kRangeReqCost empty positions (what a request costs
+  // a workgroup beyond its keys); the line is cut into rcount <= ranges pieces of R positions, piece j is the work of
+  // one workgroup per head quad, start[j] = the first request with a key at or after position j * R, or -1 if piece j
+  // holds none.  A request whose keys lie in pieces jf .. jl > jf leaves jl - jf + 1 partials in slots b + jf .. b + jl
+  // (b + j grows along the line, so no two (request, piece) pairs share a slot and bs + ranges slots always suffice),
+  // a request inside one piece is written straight to the output.  Null: the launch uses the (request, split) items.
+  const int32_t* rplan;
+  int ranges;    // pieces the range section was sized for = workgroups per head quad of a range launch
 };
 
 static constexpr int kPlanHdr = 4;   // int32 words in front of slot0[]
+static constexpr int kRangeHdr = 4;  // int32 words in front of pos[]
+static constexpr int kRangeReqCost = 16;   // positions a request takes on the line beyond its keys
+static constexpr int kRangeMin = 64;       // shortest piece (keys): one index register, four tiles
+
+// words of a plan's (request, split) section; the range section follows it
+__host__ __device__ inline int64_t plan_item_words(int bs, int64_t max_slots) { return kPlanHdr + (int64_t)bs + 2 * max_slots; }
+
+// request b of a range launch: its partial count and first slot (n <= 1: written straight to the output)
+__device__ __forceinline__ void range_request(const int32_t* rplan, int b, int& len, int& nsplit, int& slot0) {
+  const int R = rplan[1];
+  const int p0 = rplan[kRangeHdr + b], w = rplan[kRangeHdr + b + 1] - p0;
+  len = w > 0 ? w - kRangeReqCost : 0;
+  const int jf = p0 / R, jl = len > 0 ? (p0 + len - 1) / R : jf;
+  nsplit = jl - jf + 1;
+  slot0 = b + jf;
+}
 
 // (request, split) of work item `item`, the split size, and the request's first partial slot
 __device__ __forceinline__ bool decode_item(const DecodeArgs& a, int item, int& b, int& c, int& chunk, int& slot0) {
@@ -138,6 +161,8 @@ int decode_heads_per_load_shift(int num_kv_heads, int head_dim, int dtype, int* 
 // test / tuning hooks behind sp_debug_set
 void set_decode_kernel(int which);
 void set_decode_nt_min_mb(int mb);
-void set_decode_persist(int n);
+void set_decode_ranges(int n);
+// decode_mfma.hip: pieces per head quad the range kernel wants for this shape (0: it does not take the shape)
+int decode_mfma_ranges(int num_q_heads, int num_kv_heads, int head_dim, int dtype, int kv8);
 
 }  // namespace sp

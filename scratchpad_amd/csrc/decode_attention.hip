@@ -295,6 +295,14 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
   if (pair >= a.bs * a.Hq) return;
   const int lane = threadIdx.x & 63;
   const int b = pair / a.Hq, h = pair - b * a.Hq;
+  if (a.rplan) {               // range geometry: the request's pieces from its place on the line
+    int len, nsplit, slot0;
+    range_request(a.rplan, b, len, nsplit, slot0);
+    if (len <= 0 || nsplit <= 1) return;
+    const int hs[1] = {h};
+    decode_merge_rows<Tag, D, 1>(a, b, hs, lane, nsplit, slot0);
+    return;
+  }
   const int seq = min((int)load_idx(a.seq_lens, b, a.idx64), a.max_len);
   const int chunk = a.plan ? a.plan[1] : a.chunk;
   const int slot0 = a.plan ? a.plan[kPlanHdr + b] : b * a.num_splits;
@@ -317,7 +325,7 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
 __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ plan,
                                                            const void* __restrict__ seq_lens,
                                                            int idx64, int bs, int chunk, int max_len,
-                                                           int max_items) {
+                                                           int max_items, int ranges) {
   __shared__ int s_scan[256];
   __shared__ int s_base;
   __shared__ unsigned long long s_keys;
@@ -374,6 +382,63 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ 
     plan[1] = chunk;
     plan[2] = s_base;
     plan[3] = (int)min(s_keys, 0x7fffffffULL);     // keys this step gathers per kv head (DecodeArgs::nt_min_keys)
+  }
+  if (ranges <= 0) return;
+  // ---- the range section (DecodeArgs::rplan): pos[] = exclusive scan of len + kRangeReqCost over the non-empty requests
+  int32_t* rp = plan + plan_item_words(bs, max_items);
+  int32_t* pos = rp + kRangeHdr;
+  int32_t* start = pos + bs + 1;
+  __syncthreads();
+  if (threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < bs; t0 += 256) {
+    const int b = t0 + threadIdx.x;
+    int cost = 0;
+    if (b < bs) {
+      const int seq = min((int)load_idx(seq_lens, b, idx64), max_len);
+      cost = seq > 0 ? seq + kRangeReqCost : 0;
+    }
+    s_scan[threadIdx.x] = cost;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const int v = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0;
+      __syncthreads();
+      s_scan[threadIdx.x] += v;
+      __syncthreads();
+    }
+    if (b < bs) pos[b] = s_base + s_scan[threadIdx.x] - cost;
+    __syncthreads();
+    if (threadIdx.x == 255) s_base += s_scan[255];
+    __syncthreads();
+  }
+  const int T = s_base;                               // (< 2^31: the host checks bs * (max_len + cost))
+  const int R = max(kRangeMin, (int)((((int64_t)T + ranges - 1) / ranges + 15) & ~15LL));
+  const int rcount = T > 0 ? (T + R - 1) / R : 0;
+  if (threadIdx.x == 0) {
+    pos[bs] = T;
+    rp[0] = rcount; rp[1] = R; rp[2] = 0; rp[3] = 0;
+  }
+  __syncthreads();                                    // pos[] is read back below
+  // last request whose position is <= g (empty requests share the position of the next non-empty one, which is the last
+  // of the equals: the one found)
+  auto at_or_before = [&](int g) {
+    int lo = 0, hi = bs;                              // first b in [0, bs] with pos[b] > g (pos[bs] = T > g)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (pos[mid] > g) hi = mid; else lo = mid + 1;
+    }
+    return lo - 1;
+  };
+  for (int j = threadIdx.x; j < ranges; j += 256) {
+    int first = -1;
+    if (j < rcount) {
+      const int g = j * R;
+      int b = at_or_before(g);
+      if (g >= pos[b + 1] - kRangeReqCost)            // in the empty positions behind b's keys: the next request
+        b = pos[b + 1] < T ? at_or_before(pos[b + 1]) : -1;
+      if (b >= 0 && (int64_t)pos[b] < (int64_t)g + R) first = b;
+    }
+    start[j] = first;
   }
 }
 
@@ -453,7 +518,7 @@ static int merge_dim(const DecodeArgs& a, int D, hipStream_t st) {
 }
 
 int run_decode_merge(const DecodeArgs& a, int head_dim, int dtype, hipStream_t st) {
-  if (a.num_splits <= 1) return SP_OK;
+  if (a.num_splits <= 1 && !a.rplan) return SP_OK;
   SP_DISPATCH_DTYPE(dtype, return (merge_dim<Tag>(a, head_dim, st)));
 }
 
@@ -470,10 +535,10 @@ void set_decode_kernel(int which) { g_decode_kernel_forced = which; }
 static constexpr int kDecodeNtMinMbDefault = 0;
 static int g_decode_nt_min_mb = kDecodeNtMinMbDefault;
 void set_decode_nt_min_mb(int mb) { g_decode_nt_min_mb = mb == -2 ? kDecodeNtMinMbDefault : mb; }
-// sp_debug_set("decode_persist", n): the persistent form of the matrix-core kernel (DecodeArgs::persist): -1 = default,
-// 0 = never (the launch-per-item kernel everywhere), n > 0 = with n workgroups
-static int g_decode_persist = -1;
-void set_decode_persist(int n) { g_decode_persist = n < 0 ? -1 : n; }
+// sp_debug_set("decode_ranges", n): 0 = launches never take the range geometry (DecodeArgs::rplan) even when their plan
+// carries one, -1 = default (they do wherever the range kernel applies)
+static int g_decode_ranges = -1;
+void set_decode_ranges(int n) { g_decode_ranges = n < 0 ? -1 : n; }
 static int decode_kernel_choice(int group, int dtype) {
   if (dtype == SP_F32 || group > 16) return 1;
   if (g_decode_kernel_forced == 1 || g_decode_kernel_forced == 2) return g_decode_kernel_forced;
@@ -481,6 +546,10 @@ static int decode_kernel_choice(int group, int dtype) {
 }
 
 int run_decode(const DecodeArgs& a, int head_dim, int group, int dtype, hipStream_t st) {
+  if (a.rplan) {                     // range geometry: the range kernel, whatever "decode_kernel" says
+    const int rc = run_decode_mfma(a, head_dim, dtype, st);
+    return rc == SP_OK ? run_decode_merge(a, head_dim, dtype, st) : rc;
+  }
   if (a.kv8) {                       // fp8 pool: matrix-core kernel only
     if (a.Hq / a.Hkv > 16) return SP_ERR_UNSUPPORTED;
     const int rc = run_decode_mfma(a, head_dim, dtype, st);
@@ -535,19 +604,33 @@ extern "C" SP_API int sp_debug_decode_occupancy(int head_dim, int group, int dty
   return decode_occupancy(head_dim, group, dtype);
 }
 
-extern "C" size_t sp_decode_plan_bytes(int batch_size, int64_t max_slots) {
+// the line of a range plan (attention_internal.h) is indexed with int32
+static inline bool range_line_fits(int batch_size, int64_t max_seq_len) {
+  return (int64_t)batch_size * (max_seq_len + kRangeReqCost) < 0x7fffffffLL;
+}
+
+extern "C" size_t sp_decode_plan_bytes(int batch_size, int64_t max_slots, int ranges) {
   if (batch_size <= 0 || max_slots <= 0) return 16;
-  return (size_t)(kPlanHdr + (int64_t)batch_size + 2 * max_slots) * sizeof(int32_t);
+  int64_t words = plan_item_words(batch_size, max_slots);
+  if (ranges > 0) words += kRangeHdr + (int64_t)batch_size + 1 + ranges;
+  return (size_t)words * sizeof(int32_t);
+}
+
+extern "C" int sp_decode_ranges(int num_q_heads, int num_kv_heads, int head_dim, int dtype, int kv_dtype) {
+  if (num_q_heads <= 0 || num_kv_heads <= 0 || num_q_heads % num_kv_heads) return 0;
+  return decode_mfma_ranges(num_q_heads, num_kv_heads, head_dim, dtype, kv_dtype == SP_FP8_E5M2);
 }
 
 extern "C" int sp_decode_plan(int32_t* plan, size_t plan_bytes, const void* seq_lens, int idx64,
                               int batch_size, int64_t max_seq_len, int chunk, int64_t max_slots,
-                              void* stream) {
+                              int ranges, void* stream) {
   SP_CHECK_ARG(plan && seq_lens && batch_size >= 0 && chunk >= 4 && chunk % 4 == 0);
   SP_CHECK_ARG(max_seq_len >= 0 && max_seq_len <= 0x7fffffffLL && max_slots > 0 && max_slots <= 0x3fffffffLL);
-  if (plan_bytes < sp_decode_plan_bytes(batch_size, max_slots)) return SP_ERR_WORKSPACE;
+  SP_CHECK_ARG(ranges >= 0 && ranges <= 65536);
+  SP_CHECK_ARG(ranges == 0 || range_line_fits(batch_size, max_seq_len));
+  if (plan_bytes < sp_decode_plan_bytes(batch_size, max_slots, ranges)) return SP_ERR_WORKSPACE;
   decode_plan_kernel<<<dim3(1), 256, 0, (hipStream_t)stream>>>(plan, seq_lens, idx64, batch_size,
-                                                               chunk, (int)max_seq_len, (int)max_slots);
+                                                               chunk, (int)max_seq_len, (int)max_slots, ranges);
   SP_LAUNCH_CHECK();
   return SP_OK;
 }
@@ -559,8 +642,8 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
                                    int batch_size, int num_q_heads, int num_kv_heads, int head_dim,
                                    int64_t q_stride, int64_t out_stride, int64_t kv_buffer_stride,
                                    float sm_scale, float logit_cap, float k_scale, float v_scale,
-                                   int64_t max_seq_len, int chunk, int64_t max_slots, void* workspace,
-                                   size_t workspace_bytes, const int32_t* plan, int dtype,
+                                   int64_t max_seq_len, int chunk, int64_t max_slots, int ranges,
+                                   void* workspace, size_t workspace_bytes, const int32_t* plan, int dtype,
                                    int kv_dtype, void* stream) {
   SP_CHECK_ARG(out && q && k_buffer && v_buffer && req_to_token && req_pool_indices && seq_lens);
   SP_CHECK_ARG(batch_size >= 0 && num_q_heads > 0 && num_kv_heads > 0 && head_dim > 0);
@@ -608,11 +691,23 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
   {
     // bytes of K + V one key row costs this launch (all its kv heads)
     const int64_t key_bytes = 2LL * num_kv_heads * head_dim * (kv8 ? 1 : eb);
-    a.persist = g_decode_persist;
     a.nt_min_keys = g_decode_nt_min_mb < 0 ? 0x7fffffff
                                            : (int)(((int64_t)g_decode_nt_min_mb << 20) / key_bytes);   // (< 2^31: mb is an int)
   }
-  if (S > 1) {
+  // The range geometry (DecodeArgs::rplan) where the plan carries it and the range kernel takes the launch: the default
+  // configuration (16-bit pool, always-streaming gathers, no soft-cap) on a shape sp_decode_ranges() accepts.  Everything
+  // else uses the plan's (request, split) items.
+  SP_CHECK_ARG(ranges >= 0 && ranges <= 65536);
+  a.rplan = nullptr; a.ranges = 0;
+  if (plan && ranges > 0 && g_decode_ranges != 0 && logit_cap <= 0.f && a.nt_min_keys == 0 &&
+      range_line_fits(batch_size, max_seq_len) && out_stride % 4 == 0 &&
+      sp_decode_ranges(num_q_heads, num_kv_heads, head_dim, dtype, kv_dtype) > 0) {
+    a.rplan = plan + plan_item_words(batch_size, max_slots);
+    a.ranges = ranges;
+    max_slots = (int64_t)batch_size + ranges;       // partial slots of the range geometry: slot = request + piece
+    a.max_slots = (int)max_slots;
+  }
+  if (S > 1 || a.rplan) {       // (a range launch splits a request wherever a piece ends)
     const size_t need = sp_decode_attention_workspace_bytes(max_slots, num_q_heads, head_dim);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) return SP_ERR_WORKSPACE;
     a.part_o = (float*)workspace;

@@ -433,27 +433,27 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// PERSISTENT form of the head-per-wave kernel (round 5): planned launches of the default configuration (16-bit pool,
-// non-temporal gathers, no soft-cap).  The launch has as many workgroups as the chip holds at once, and each takes
-// (plan item, head quad) units one after the other WITHOUT draining its gathers in between: while a unit's last piece of
-// 64 keys is consumed, the next unit's record and first index piece are fetched, and its first tile's gathers are issued
-// where the current unit has none left to issue.  Which units a workgroup takes is STATIC - unit r * W + w in even rounds,
-// r * W + (W - 1 - w) in odd ones: dealt in serpentine order, the plan's longest-first list gives every workgroup the
-// load greedy longest-processing-time scheduling would (tools/sim_decode_split.py), whereas tickets drawn from one
-// counter cost more than they balance (same-address device-scope atomics serialise at ~50 ns apiece).  The four waves of
-// a workgroup compute the same sequence and take the four heads of each unit; they share nothing (wave-private LDS
-// tile, no barrier).
+// RANGE form of the head-per-wave kernel (round 5): launches of the default configuration (16-bit pool, non-temporal
+// gathers, no soft-cap) whose plan carries the range geometry (DecodeArgs::rplan).  The step's keys form one line,
+// request after request; the plan cuts it into as many equal pieces as the chip holds workgroups per head quad, and
+// workgroup (piece j, head quad) walks piece j: the tail of the request the piece starts in, whole requests, the head
+// of the request it ends in.  Every workgroup gathers the same number of keys - whatever the lengths are, there is no
+// split size to choose and no list of items to deal out - and they all finish together.
 //
-// What this form buys is WHERE the split partials go (profiles/r05_decode_split_cost.txt): fp32 partial rows written
-// to HBM in between the gathers cost ~1.8 us per MB - ten times their share of the bytes.  A wave PARKS the partial
-// rows of its units in LDS the tiles do not use (kParkWaveB per wave: 2 units at G = 4, D = 128) and writes them, in
-// whole 512-byte rows, when it has no unit left - which, the loads being level, is when the launch as a whole is
-// running out of gathers.  (Holding the rows back until EVERY workgroup is done, behind a bounded device-wide barrier,
-// was tried as well: no further gain, profiles/NOTES.md round 5.)  Units past the parking space, groups too wide to
-// park, and unsplit requests' output rows are stored at once, as in the launch-per-item kernel.
-// Same arithmetic, same order of the keys within a unit, same bits as the launch-per-item kernel.
+// What that buys, measured on the (request, split) items of this same kernel (profiles/r05_decode_split_cost.txt):
+//   * balance: batches whose items deal out evenly over the resident workgroups stream at 6.4 TB/s, the ragged headline
+//     batch at 6.15;
+//   * WHERE the partials go: fp32 partial rows written to HBM in between the gathers cost ~1.8 us per MB, ten times
+//     their share of the bytes.  A piece cuts at most two requests (its first and its last); the wave PARKS those
+//     partial rows in LDS the tiles do not use and writes them, in whole 512-byte rows, when the piece is done - which
+//     is when the launch as a whole runs out of gathers.  Requests inside a piece are written straight to the output.
+// The walk never drains the wave's gathers: while a request's last 64 keys are consumed, the next request's record
+// and first index register are fetched, and its first tile's gathers are issued where the current request has none
+// left to issue.  The four waves of a workgroup walk the same piece for the four heads of the quad and share nothing
+// (wave-private LDS tile, no barrier).  The arithmetic per key is that of decode_mfma_kernel; the cuts differ, so the
+// bits are those of another - equally valid - split of the same sums.
 template <typename Tag, int D>
-__global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_pw_kernel(DecodeArgs a) {
+__global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_range_kernel(DecodeArgs a) {
   typedef DmCfg<D> C;
   typedef u32x4 raw_t;
   constexpr int SRC_ROW_B = 2 * D, SRC_CH_B = 16;
@@ -461,6 +461,14 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_pw_kernel(Decod
   constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK, TILE_B = C::TILE_B;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int hgroups = a.Hkv / 4;
+  const int piece = (int)blockIdx.x / hgroups;              // the head quads of one piece are adjacent in launch order
+  const int hk = ((int)blockIdx.x - piece * hgroups) * 4 + wave;
+  const int32_t* rp = a.rplan;
+  if (piece >= rp[0]) return;
+  const int R = rp[1];
+  const int32_t* posv = rp + kRangeHdr;
+  const int lo = piece * R, hi = lo + R;                    // this piece of the line
   const int G = a.Hq / a.Hkv;
   const int col = lane & 15, kq = lane >> 4;
   char* ldsK = lds + wave * 2 * TILE_B;
@@ -472,77 +480,67 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_pw_kernel(Decod
   const int i16 = lane & 15;
   const int tr_row = 4 * kq + (i16 >> 2);
 
-  const int hgroups = a.Hkv / 4;
-  const int nunits = a.plan[0] * hgroups;            // (plan item, head quad) units, in the plan's longest-first order
-  const int chunk = a.plan[1];
-  const int32_t* items = a.plan + kPlanHdr + a.bs;
-  const int W = (int)gridDim.x, w = (int)blockIdx.x;
-
-  struct Unit { int b, c, seq, cs, ce, nsplit, slot0, hk; const int32_t* idx_row; };
-  // A unit's record is read with SCALAR loads written as asm: inside the loop hipcc turns these reads into vector loads
-  // (the kernel's own stores may alias them as far as it knows), each followed by s_waitcnt vmcnt(0) - drained round
-  // trips per unit with no gather in flight.  A scalar load waits on lgkmcnt only: the tile in flight stays in flight.
-  // Two dependent rounds: the item's (b, c), then everything indexed by b at once.
-  auto load_item = [&](int item, int& b, int& c) {
-    int64_t bc;
-    const int64_t* q = (const int64_t*)items + item;       // (b, c) as one 8-byte record (items is 8-byte aligned:
-    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bc) : "s"(q) : "memory");   // bs + 4 words in)
-    b = (int)(uint32_t)bc;
-    c = (int)(bc >> 32);
-  };
-  const void* kv_or_seq = a.kv_start ? a.kv_start : a.seq_lens;   // (a valid address either way)
-  auto load_request = [&](int b, int& slot0, int64_t& seq, int64_t& req, int64_t& kv0) {
-    const int32_t* ps = a.plan + kPlanHdr + b;
+  // a request's share of the piece: keys cs .. ce of request b; `whole`: all of its keys (no partial)
+  struct Seg { int b, cs, ce, end; bool whole; const int32_t* idx_row; };
+  // A request's record is read with SCALAR loads written as asm: inside the loop hipcc turns such reads into vector
+  // loads (the kernel's own stores may alias them as far as it knows), each followed by s_waitcnt vmcnt(0) - drained
+  // round trips with no gather in flight.  A scalar load waits on lgkmcnt only: the tile in flight stays in flight.
+  const void* kv_or_req = a.kv_start ? a.kv_start : a.req_idx;   // (a valid address either way)
+  auto load_request = [&](int b, int& p0, int& p1, int64_t& req, int64_t& kv0) {
+    const int32_t* pp = posv + b;
     if (a.idx64) {
-      const int64_t *p1 = (const int64_t*)a.seq_lens + b, *p2 = (const int64_t*)a.req_idx + b, *p3 = (const int64_t*)kv_or_seq + b;
-      asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dwordx2 %1, %5, 0x0\n\ts_load_dwordx2 %2, %6, 0x0\n\t"
-                   "s_load_dwordx2 %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&s"(slot0), "=&s"(seq), "=&s"(req), "=&s"(kv0) : "s"(ps), "s"(p1), "s"(p2), "s"(p3) : "memory");
+      const int64_t *p2 = (const int64_t*)a.req_idx + b, *p3 = (const int64_t*)kv_or_req + b;
+      asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x4\n\ts_load_dwordx2 %2, %5, 0x0\n\t"
+                   "s_load_dwordx2 %3, %6, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&s"(p0), "=&s"(p1), "=&s"(req), "=&s"(kv0) : "s"(pp), "s"(p2), "s"(p3) : "memory");
     } else {
-      const int32_t *p1 = (const int32_t*)a.seq_lens + b, *p2 = (const int32_t*)a.req_idx + b, *p3 = (const int32_t*)kv_or_seq + b;
-      int s32, r32, k32;
-      asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\t"
-                   "s_load_dword %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&s"(slot0), "=&s"(s32), "=&s"(r32), "=&s"(k32) : "s"(ps), "s"(p1), "s"(p2), "s"(p3) : "memory");
-      seq = s32; req = r32; kv0 = k32;
+      const int32_t *p2 = (const int32_t*)a.req_idx + b, *p3 = (const int32_t*)kv_or_req + b;
+      int r32, k32;
+      asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x4\n\ts_load_dword %2, %5, 0x0\n\t"
+                   "s_load_dword %3, %6, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&s"(p0), "=&s"(p1), "=&s"(r32), "=&s"(k32) : "s"(pp), "s"(p2), "s"(p3) : "memory");
+      req = r32; kv0 = k32;
     }
     if (!a.kv_start) kv0 = 0;
   };
-  int round = 0;
-  // this workgroup's unit of the next round (serpentine dealing), skipping empty ones (never listed by sp_decode_plan;
-  // a cut plan); false when its list is exhausted
-  auto next_unit = [&](Unit& u) -> bool {
-    for (;;) {
-      const int T = __builtin_amdgcn_readfirstlane(round * W + ((round & 1) ? W - 1 - w : w));
-      ++round;
-      if (T >= nunits) return false;
-      const int item = T / hgroups;
-      u.hk = (T - item * hgroups) * 4 + wave;
-      load_item(item, u.b, u.c);
-      int64_t seq, req, kv0;
-      load_request(u.b, u.slot0, seq, req, kv0);
-      u.seq = (int)min(seq, (int64_t)a.max_len);
-      u.cs = u.c * chunk;
-      u.ce = min(u.cs + chunk, u.seq);
-      u.nsplit = (u.seq + chunk - 1) / chunk;
+  // the share of request b (and of the ones behind it while they are empty); false: the piece holds no more keys
+  auto segment_at = [&](int b, Seg& u) -> bool {
+    for (b = __builtin_amdgcn_readfirstlane(b); b < a.bs; ++b) {     // (uniform by construction; the asm needs SGPRs)
+      int p0, p1;
+      int64_t req, kv0;
+      load_request(b, p0, p1, req, kv0);
+      if (p0 >= hi) return false;
+      const int len = p1 - p0 - kRangeReqCost;
+      if (p1 <= p0) continue;                               // an empty request takes no room on the line
+      u.b = b;
+      u.cs = max(lo - p0, 0);
+      u.ce = min(hi - p0, len);
+      u.end = len;
+      u.whole = u.cs == 0 && u.ce == len;
       u.idx_row = a.r2t + req * a.r2t_stride + kv0;
-      if (u.cs < u.seq && u.slot0 + u.c < a.max_slots) return true;
+      if (u.cs < u.ce) return true;                         // (cs >= ce: only the room behind b's keys is in the piece)
     }
+    return false;
   };
 
-  Unit cur;
-  if (!next_unit(cur)) return;
+  Seg cur;
+  {
+    int first;
+    const int32_t* q = posv + a.bs + 1 + piece;             // start[piece]
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(first) : "s"(q) : "memory");
+    if (first < 0 || !segment_at(first, cur)) return;
+  }
 
   uint64_t kbase[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
-    const int R = i * RPL + ld_row;
-    kbase[i] = (uint64_t)(uintptr_t)a.kbuf + (uint64_t)cur.hk * SRC_ROW_B + (uint64_t)((ld_ch ^ (R & (CPR - 1))) * SRC_CH_B);
+    const int Rw = i * RPL + ld_row;
+    kbase[i] = (uint64_t)(uintptr_t)a.kbuf + (uint64_t)hk * SRC_ROW_B + (uint64_t)((ld_ch ^ (Rw & (CPR - 1))) * SRC_CH_B);
   }
   u32x4 qf[KSTEPS];
-  auto load_q = [&](const Unit& u) {
+  auto load_q = [&](const Seg& u) {
     const int hcol = min(col, G - 1);
-    const char* qp = (const char*)a.q + ((int64_t)u.b * a.q_stride + (int64_t)(u.hk * G + hcol) * D + 8 * kq) * 2;
+    const char* qp = (const char*)a.q + ((int64_t)u.b * a.q_stride + (int64_t)(hk * G + hcol) * D + 8 * kq) * 2;
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) qf[s] = ld16(qp + s * 64);
   };
@@ -568,19 +566,19 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_pw_kernel(Decod
   auto stage = [&]() {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int R = i * RPL + ld_row;
-      st16(ldsK + R * ROW_B + ld_ch * 16, kr[i]);
-      st16(ldsV + R * ROW_B + ld_ch * 16, vr[i]);
+      const int Rw = i * RPL + ld_row;
+      st16(ldsK + Rw * ROW_B + ld_ch * 16, kr[i]);
+      st16(ldsV + Rw * ROW_B + ld_ch * 16, vr[i]);
     }
   };
   auto consume = [&](int tile, int n) {
     f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
     {
-      const int R = lane & 15;
+      const int Rw = lane & 15;
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
         const int cg = 4 * ks + kq;
-        const u32x4 kf = ld16(ldsK + R * ROW_B + ((cg ^ (R & (CPR - 1))) * 16));
+        const u32x4 kf = ld16(ldsK + Rw * ROW_B + ((cg ^ (Rw & (CPR - 1))) * 16));
         s = mfma_qk<Tag>(kf, qf[ks], s);
       }
     }
@@ -619,7 +617,7 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_pw_kernel(Decod
       oacc[db] = mfma_pv<Tag>(vf, pf, oacc[db]);
     }
   };
-  // Parking space of this wave behind the tiles: records of [G rows of D floats | 16 log-sum-exps | kv head, slot]
+  // Parking space of this wave behind the tiles: records of [G rows of D floats | 16 log-sum-exps | request]
   const int park_rows_b = G * D * 4;
   const int park_unit_b = park_rows_b + 64 + 16;
   const int park_cap = kDmParkWaveB / park_unit_b;          // 2 at G = 4, D = 128; 0: the group is too wide to park
@@ -628,19 +626,19 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_pw_kernel(Decod
   auto flush_parked = [&]() {
     for (int k = 0; k < parked; ++k) {
       const char* src = park + k * park_unit_b;
-      const int hk_ = __builtin_amdgcn_readfirstlane(*(const int*)(src + park_rows_b + 64));
-      const int slot_ = __builtin_amdgcn_readfirstlane(*(const int*)(src + park_rows_b + 68));
+      const int slot_ = __builtin_amdgcn_readfirstlane(*(const int*)(src + park_rows_b + 64));
       for (int off = lane * 16; off < park_rows_b; off += 1024) {     // whole rows, 16 B per lane
         const int row = off / (D * 4), within = off - row * (D * 4);
-        const int64_t pi = (int64_t)(hk_ * G + row) * a.max_slots + slot_;
+        const int64_t pi = (int64_t)(hk * G + row) * a.max_slots + slot_;
         *(u32x4*)((char*)(a.part_o + pi * D) + within) = ld16(src + off);
       }
-      if (lane < G) a.part_lse[(int64_t)(hk_ * G + lane) * a.max_slots + slot_] = *(const float*)(src + park_rows_b + lane * 4);
+      if (lane < G) a.part_lse[(int64_t)(hk * G + lane) * a.max_slots + slot_] = *(const float*)(src + park_rows_b + lane * 4);
     }
   };
-  // a unit's result: straight to the output (an unsplit request) or as a partial for the merge launch
-  auto write_unit = [&](const Unit& u) {
-    if (u.nsplit > 1 && parked < park_cap) {
+  // a request's result: straight to the output (all of its keys were in this piece) or as the partial of slot b + piece
+  auto write_seg = [&](const Seg& u) {
+    const int slot = u.b + piece;
+    if (!u.whole && parked < park_cap) {
       char* dst = park + parked * park_unit_b;
       if (col < G) {
         const float inv = 1.0f / l_run;
@@ -653,17 +651,14 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_pw_kernel(Decod
         }
         if (kq == 0) *(float*)(dst + park_rows_b + col * 4) = m_run + __builtin_amdgcn_logf(l_run);
       }
-      if (lane == 0) {
-        *(int*)(dst + park_rows_b + 64) = u.hk;
-        *(int*)(dst + park_rows_b + 68) = u.slot0 + u.c;
-      }
+      if (lane == 0) *(int*)(dst + park_rows_b + 64) = slot;
       ++parked;
       return;
     }
     if (col >= G) return;
-    const int h = u.hk * G + col;
+    const int h = hk * G + col;
     float inv = 1.0f / l_run;
-    if (u.nsplit == 1) {
+    if (u.whole) {
       inv *= a.out_scale;
       char* op = (char*)a.out + ((int64_t)u.b * a.o_stride + (int64_t)h * D + 4 * kq) * 2;
 #pragma unroll
@@ -674,7 +669,7 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_pw_kernel(Decod
         *(u32x2*)(op + db * 32) = w;
       }
     } else {
-      const int64_t pi = (int64_t)h * a.max_slots + (u.slot0 + u.c);
+      const int64_t pi = (int64_t)h * a.max_slots + slot;
       float* pp = a.part_o + pi * D + 4 * kq;
 #pragma unroll
       for (int db = 0; db < DBLK; ++db)
@@ -689,32 +684,25 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_pw_kernel(Decod
   for (;;) {
     const int n = min(64, cur.ce - pos);
     const int ntile = (n + TK - 1) / TK;
-    const bool last_piece = pos + 64 >= cur.ce;
-    Unit nxt;
+    const bool last = pos + 64 >= cur.ce;            // the last 64 keys of this request's share
+    Seg nxt;
     bool have_next = false;
     int nextidx = 0;
-    if (last_piece) {
-      have_next = next_unit(nxt);
+    if (last) {
+      // (a share that stops short of its request's end is the piece's last: nothing behind it)
+      have_next = cur.ce == cur.end && segment_at(cur.b + 1, nxt);
       if (have_next) nextidx = (nxt.cs + lane < nxt.ce) ? nxt.idx_row[nxt.cs + lane] : 0;
     } else {
       nextidx = (pos + 64 + lane < cur.ce) ? cur.idx_row[pos + 64 + lane] : 0;
     }
     for (int t = 0; t < ntile; ++t) {
       stage();
-      if (t + 1 < ntile) {
-        issue(t + 1, curidx);
-      } else if (!last_piece) {
-        issue(0, nextidx);                          // the next piece's first tile: no drain between pieces
-      } else if (have_next) {                       // the next UNIT's first tile: no drain between units
-        const int64_t dh = (int64_t)(nxt.hk - cur.hk) * SRC_ROW_B;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) kbase[i] += (uint64_t)dh;
-        issue(0, nextidx);
-      }
+      if (t + 1 < ntile) issue(t + 1, curidx);
+      else if (!last || have_next) issue(0, nextidx);       // the next 64 keys' first tile: no drain in between
       consume(t, n);
     }
-    if (last_piece) {
-      write_unit(cur);
+    if (last) {
+      write_seg(cur);
       if (!have_next) break;
       cur = nxt;
       load_q(cur);
@@ -731,42 +719,26 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_pw_kernel(Decod
   flush_parked();
 }
 
+template <int D>
+static constexpr int dm_range_lds() { return DmCfg<D>::kStageBytes + DmCfg<D>::WAVES * kDmParkWaveB; }
+
 template <typename Tag, int D, bool KV8>
 static int launch_dm_kv(const DecodeArgs& a, hipStream_t st) {
   typedef DmCfg<D> C;
+  const bool hpw = a.Hkv % 4 == 0 && a.o_stride % 4 == 0;
+  if (a.rplan) {                                  // the range geometry: one workgroup per (piece, head quad)
+    if constexpr (KV8) return SP_ERR_INVALID_ARG;
+    else {
+      if (!hpw || a.ranges <= 0 || a.logit_cap > 0.f || a.nt_min_keys != 0) return SP_ERR_INVALID_ARG;
+      decode_mfma_range_kernel<Tag, D><<<dim3((unsigned)a.ranges * (a.Hkv / 4)), 256, dm_range_lds<D>(), st>>>(a);
+      SP_LAUNCH_CHECK();
+      return SP_OK;
+    }
+  }
   // planned: one workgroup per (plan item, head group), the launch covers max_slots items (the surplus
   // exits at once); plan-less: the static (request, split) grid
   const int64_t items = a.plan ? (int64_t)a.max_slots : (int64_t)a.bs * a.num_splits;
-  if (a.Hkv % 4 == 0 && a.o_stride % 4 == 0) {
-    if constexpr (!KV8) {
-      // the persistent form: planned launches of the default (always-streaming, no soft-cap) configuration
-      if (a.plan && a.persist && a.logit_cap <= 0.f && a.nt_min_keys == 0) {
-        constexpr int kLds = C::kStageBytes + C::WAVES * kDmParkWaveB;
-        // as many workgroups as the chip holds at once (asked of the runtime once per instantiation), or the debug value
-        static int resident = 0;
-        if (!resident) {
-          int dev = 0, per_cu = 0;
-          hipDeviceProp_t prop;
-          if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-              hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_mfma_pw_kernel<Tag, D>, 256, kLds) != hipSuccess ||
-              per_cu < 1)
-            return SP_ERR_LAUNCH;
-          resident = per_cu * prop.multiProcessorCount;
-        }
-        // ... when the step can have more units than that: the lengths bound the items by bs x ceil(max_len / chunk)
-        // as well (a graph's launch covers >= 1024 whatever the batch).  A launch of fewer units is a matter of
-        // latency, not of bandwidth, and there the launch-per-item kernel is the faster one (bs 1, 1024 keys: 34 vs 41 us).
-        const int64_t bound = (int64_t)a.bs * a.num_splits;
-        const int64_t wgs = (items < bound ? items : bound) * (a.Hkv / 4);
-        const int64_t want = a.persist > 0 ? a.persist : resident;
-        if (wgs > want || a.persist > 0) {
-          const unsigned grid = (unsigned)(wgs < want ? wgs : want);
-          decode_mfma_pw_kernel<Tag, D><<<dim3(grid), 256, kLds, st>>>(a);
-          SP_LAUNCH_CHECK();
-          return SP_OK;
-        }
-      }
-    }
+  if (hpw) {
     const unsigned grid = (unsigned)(items * (a.Hkv / 4));
     decode_mfma_kernel<Tag, D, true, KV8><<<dim3(grid), 256, C::kLdsBytes, st>>>(a);
   } else {
@@ -788,12 +760,40 @@ static int launch_dm(const DecodeArgs& a, hipStream_t st) {
 int run_decode_mfma(const DecodeArgs& a, int head_dim, int dtype, hipStream_t st) {
   const int G = a.Hq / a.Hkv;
   if (G > 16 || (dtype != SP_BF16 && dtype != SP_F16)) return SP_ERR_UNSUPPORTED;
+  if (a.rplan && !decode_mfma_ranges(a.Hq, a.Hkv, head_dim, dtype, a.kv8)) return SP_ERR_INVALID_ARG;
   if ((a.plan ? (int64_t)a.max_slots : (int64_t)a.bs * a.num_splits) * a.Hkv > 0x7fffffffLL) return SP_ERR_INVALID_ARG;
   if (head_dim == 128)
     return dtype == SP_BF16 ? launch_dm<bf16_tag, 128>(a, st) : launch_dm<f16_tag, 128>(a, st);
   if (head_dim == 64)
     return dtype == SP_BF16 ? launch_dm<bf16_tag, 64>(a, st) : launch_dm<f16_tag, 64>(a, st);
   return SP_ERR_UNSUPPORTED;
+}
+
+// Pieces per head quad the range kernel wants: the workgroups the chip holds at once (asked of the runtime, once per
+// instantiation) over the head quads.  0: the shape is not the range kernel's (a 16-bit pool with Hkv % 4 == 0,
+// G <= 16, D in {64, 128}).
+template <typename Tag, int D>
+static int dm_resident_workgroups() {
+  static int resident = 0;
+  if (!resident) {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_mfma_range_kernel<Tag, D>, 256, dm_range_lds<D>()) !=
+            hipSuccess || per_cu < 1)
+      return 0;
+    resident = per_cu * prop.multiProcessorCount;
+  }
+  return resident;
+}
+
+int decode_mfma_ranges(int num_q_heads, int num_kv_heads, int head_dim, int dtype, int kv8) {
+  if (kv8 || num_kv_heads % 4 || num_q_heads / num_kv_heads > 16 || (dtype != SP_BF16 && dtype != SP_F16)) return 0;
+  int resident = 0;
+  if (head_dim == 128) resident = dtype == SP_BF16 ? dm_resident_workgroups<bf16_tag, 128>() : dm_resident_workgroups<f16_tag, 128>();
+  else if (head_dim == 64) resident = dtype == SP_BF16 ? dm_resident_workgroups<bf16_tag, 64>() : dm_resident_workgroups<f16_tag, 64>();
+  const int pieces = resident / (num_kv_heads / 4);
+  return pieces > 0 ? pieces : (resident > 0 ? 1 : 0);
 }
 
 }  // namespace sp

@@ -144,7 +144,7 @@ extern "C" int sp_debug_set(const char* key, int value) {
   SP_CHECK_ARG(key);
   if (!strcmp(key, "decode_kernel")) { set_decode_kernel(value); return SP_OK; }
   if (!strcmp(key, "decode_nt_min_mb")) { set_decode_nt_min_mb(value); return SP_OK; }
-  if (!strcmp(key, "decode_persist")) { set_decode_persist(value); return SP_OK; }
+  if (!strcmp(key, "decode_ranges")) { set_decode_ranges(value); return SP_OK; }
   if (!strcmp(key, "extend_defer_x10")) { set_extend_defer_x10(value); return SP_OK; }
   if (!strcmp(key, "extend_dma")) { set_extend_dma(value); return SP_OK; }
   if (!strcmp(key, "extend_w64")) { set_extend_w64(value); return SP_OK; }
@@ -256,7 +256,7 @@ extern "C" int sp_extend_attention(void* out, const void* q, const void* k_buffe
   if (chunk > 0x7ffffff0LL) return SP_ERR_INVALID_ARG;
   a.chunk = (int)chunk; a.num_splits = 1; a.max_len = (int)chunk; a.max_slots = (int)num_tokens;
   a.hh_shift = decode_heads_per_load_shift(num_kv_heads, head_dim, dtype, &a.head_groups);
-  a.part_o = nullptr; a.part_lse = nullptr; a.plan = nullptr; a.kv8 = 0; a.nt_min_keys = 0x7fffffff; a.persist = 0;
+  a.part_o = nullptr; a.part_lse = nullptr; a.plan = nullptr; a.kv8 = 0; a.nt_min_keys = 0x7fffffff; a.rplan = nullptr; a.ranges = 0;
   g_extend_last_kernel = 4;
   return run_decode(a, head_dim, G, dtype, st);
 }

@@ -815,52 +815,142 @@ def test_decode_streaming_gathers_change_no_bit(nat, kv, Hq, Hkv, D):
     assert int(plan[3]) == int(lens.clamp(max=100).sum())
 
 
+def range_plan_on_host(lens, max_len, ranges):
+    """the range section of a decode plan (include/scratchpad_hip.h, ABI 8) recomputed in Python"""
+    cost = 16
+    lens = [min(int(l), max_len) if l > 0 else 0 for l in lens]
+    pos = [0]
+    for l in lens:
+        pos.append(pos[-1] + (l + cost if l > 0 else 0))
+    T = pos[-1]
+    R = max(64, ((T + ranges - 1) // ranges + 15) // 16 * 16)
+    rcount = (T + R - 1) // R if T > 0 else 0
+    start = []
+    for j in range(ranges):
+        first = -1
+        if j < rcount:
+            for b, l in enumerate(lens):
+                if l > 0 and pos[b] + l > j * R:              # the first request with a key at or after the cut
+                    first = b if pos[b] < (j + 1) * R else -1
+                    break
+        start.append(first)
+    return rcount, R, pos, start
+
+
+@pytest.mark.parametrize("ranges", [1, 7, 384, 1000])
+@pytest.mark.parametrize("idx_dtype", [torch.int32, torch.int64])
+def test_decode_range_plan_equals_a_host_recount(nat, ranges, idx_dtype):
+    """sp_decode_plan(ranges > 0): positions, piece length, piece count and every piece's first request against a
+    host-side recount - 700 requests (the scan crosses 256-request tiles) with empty and one-key rows, runs of empty
+    rows, a length above max_seq_len (clamped), a negative length (empty); the item section in front is unchanged."""
+    g = torch.Generator().manual_seed(ranges)
+    bs, chunk, max_len = 700, 128, 900
+    lens = torch.randint(0, 901, (bs,), generator=g)
+    lens[torch.randint(0, bs, (70,), generator=g)] = 0
+    lens[torch.randint(0, bs, (70,), generator=g)] = 1
+    lens[100:140] = 0
+    lens[0], lens[5], lens[6], lens[bs - 1] = 900, 5000, -3, 0
+    seq = lens.to(idx_dtype).to(DEV)
+    slots = nat.decode_plan_slots(bs, max_len, chunk, kv_tokens=int(lens.clamp(0, max_len).sum()))
+    words = nat.decode_plan_bytes(bs, max_len, chunk, slots, ranges) // 4
+    assert words == 4 + bs + 2 * slots + 4 + bs + 1 + ranges
+    plan = torch.full((words,), -7, dtype=torch.int32, device=DEV)
+    nat.decode_plan(plan, seq, max_len, chunk, slots, ranges)
+    items_only = torch.full((nat.decode_plan_bytes(bs, max_len, chunk, slots) // 4,), -7, dtype=torch.int32, device=DEV)
+    nat.decode_plan(items_only, seq, max_len, chunk, slots)
+    host = plan.cpu()
+    assert torch.equal(host[:items_only.numel()], items_only.cpu())
+    rp = host[items_only.numel():].tolist()
+    rcount, R, pos, start = range_plan_on_host(lens.tolist(), max_len, ranges)
+    assert rp[:4] == [rcount, R, 0, 0]
+    assert rp[4:4 + bs + 1] == pos
+    assert rp[4 + bs + 1:] == start
+    assert rcount <= ranges and R % 16 == 0 and (rcount - 1) * R < pos[-1] <= rcount * R
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (64, 8, 128), (64, 4, 128), (8, 8, 128), (16, 4, 64), (24, 4, 64)])
-def test_decode_persistent_form_gives_the_same_bits(nat, dt, Hq, Hkv, D):
-    """The persistent form of the head-per-wave kernel (decode_mfma.hip, round 5: resident workgroups take the plan's
-    units in serpentine order and park split partials in LDS until they run out of units) against the launch-per-item
-    kernel: same bits with 3, 8, 64 workgroups (many units per wave: the parking space overflows into direct stores;
-    groups of 4 and 6 park two units per wave, 8 one, 1 seven, 16 none), with the default count, on int32 and int64
-    index tensors, behind a kv_start window, launch after launch on one plan over a workspace full of stale partials;
-    and the oracle's numbers.  sp_debug_set("decode_persist", 0) is the launch-per-item kernel everywhere."""
+def test_decode_range_geometry(nat, dt, Hq, Hkv, D):
+    """The range kernel (decode_mfma.hip, round 5: one workgroup per (piece of the step's keys, four kv heads); a request
+    cut by a piece boundary leaves partials in slots request + piece, parked in LDS until the piece is done) against
+    the oracle, for 1, 3, 40 and 1000 pieces and the count sp_decode_ranges() asks for: requests of 1400 and 1025 keys
+    cut many times, pieces holding dozens of short requests, one-key and empty rows, groups of 4 and 6 (two partials
+    parked per wave), 8 (one), 1 (seven), 16 (none: stored at once).  Per piece count the bits are the same on int32
+    and int64 index tensors, launch after launch on one plan, over a workspace full of stale partials; behind a kv_start
+    window.  sp_debug_set("decode_ranges", 0) sends the same call to the plan's (request, split) items: the bits of a
+    plan without ranges."""
     dtype = DTYPES[dt]
     g = torch.Generator().manual_seed(Hq * 17 + Hkv + D)
     bs, chunk, max_len = 48, 64, 1400
     lens = torch.randint(1, 600, (bs,), generator=g)
-    lens[:6] = torch.tensor([1400, 1025, 64, 65, 1, 0])      # 22 and 17 splits, one, two, a single key, an empty row
+    lens[:8] = torch.tensor([1400, 1025, 64, 65, 1, 0, 0, 1])
+    lens[20:32] = torch.randint(1, 9, (12,), generator=g)     # a run of tiny requests: one piece walks many of them
     start = torch.randint(0, 4, (bs,), generator=g)
     p = paged_problem(700 + Hq + D, bs, Hq, Hkv, D, [int(l) + 4 for l in lens], dtype, DEV)
     q, req = p["q"], p["req_pool_indices"]
     seq = lens.to(DEV)
+    auto = nat.decode_ranges(Hq, Hkv, D, dtype)
+    assert auto > 0 and auto * (Hkv // 4) >= 256, "the range kernel takes these shapes: about a workgroup per resident slot"
     slots = nat.decode_plan_slots(bs, max_len, chunk, kv_tokens=int(lens.sum()))
-    ws = torch.empty(nat.decode_workspace_bytes(bs, Hq, D, max_len, chunk, slots), dtype=torch.uint8, device=DEV)
-    plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, slots) // 4, dtype=torch.int32, device=DEV)
-    outs = {}
-    try:
-        for idx_dtype in (torch.int32, torch.int64):
-            s_, r_, k0 = seq.to(idx_dtype), req.to(idx_dtype), start.to(DEV).to(idx_dtype)
-            nat.decode_plan(plan, s_, max_len, chunk, slots)
-            for persist in (0, 3, 8, 64, -1):
-                nat.debug_set("decode_persist", persist)
-                for rep in range(2):
-                    ws.fill_(0x7f if rep else 0xff)
-                    o = torch.zeros_like(q)
-                    nat.decode_attention(o, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], r_, s_, D ** -0.5, 0.0,
-                                         max_len, chunk, ws, k0, plan, max_slots=slots)
-                    outs[(idx_dtype, persist, rep)] = o
-    finally:
-        nat.debug_set("decode_persist", -1)
-    base = outs[(torch.int32, 0, 0)]
-    assert torch.isfinite(base.float()).all()
-    for key, o in outs.items():
-        assert torch.equal(o, base), key
-    assert float(base[5].float().abs().max()) == 0.0, "an empty row is left untouched"
     c = cpu(p)
     fn = lambda v: ops.decode_attention(c["q"].float(), c["k_buffer"].float(), v, c["req_to_token"],
                                         c["req_pool_indices"], lens, D ** -0.5, 0.0, start)
-    live = [r for r in range(bs) if r != 5]
-    check_vs_oracle(base, dtype, f"persistent decode {dt} Hq{Hq} Hkv{Hkv} D{D}", c["v_buffer"].float(), fn, rows=live)
+    live = [r for r in range(bs) if int(lens[r]) > 0]
+
+    def launch(ranges, idx_dtype, fill):
+        s_, r_, k0 = seq.to(idx_dtype), req.to(idx_dtype), start.to(DEV).to(idx_dtype)
+        ws = torch.empty(nat.decode_workspace_bytes(bs, Hq, D, max_len, chunk, slots, ranges), dtype=torch.uint8, device=DEV)
+        ws.fill_(fill)
+        plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, slots, ranges) // 4, dtype=torch.int32, device=DEV)
+        nat.decode_plan(plan, s_, max_len, chunk, slots, ranges)
+        outs = []
+        for rep in range(2):
+            o = torch.zeros_like(q)
+            nat.decode_attention(o, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], r_, s_, D ** -0.5, 0.0,
+                                 max_len, chunk, ws, k0, plan, max_slots=slots, ranges=ranges)
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1]), (ranges, idx_dtype)
+        return outs[0]
+
+    items = launch(0, torch.int32, 0x7f)
+    for ranges in (1, 3, 40, auto, 1000):
+        o = launch(ranges, torch.int32, 0x7f)
+        assert torch.isfinite(o.float()).all(), ranges
+        assert torch.equal(o, launch(ranges, torch.int64, 0xff)), ranges
+        assert float(o[5].float().abs().max()) == 0.0 and float(o[6].float().abs().max()) == 0.0, "empty rows stay untouched"
+        check_vs_oracle(o, dtype, f"range decode {dt} Hq{Hq} Hkv{Hkv} D{D} ranges {ranges}", c["v_buffer"].float(), fn, rows=live)
+    try:
+        nat.debug_set("decode_ranges", 0)
+        assert torch.equal(launch(auto, torch.int32, 0x7f), items)
+    finally:
+        nat.debug_set("decode_ranges", -1)
+
+
+def test_decode_ranges_where_the_range_kernel_does_not_apply(nat):
+    """sp_decode_ranges() is 0 for byte pools, fp32 and kv heads not in fours; a launch of such a shape - or with a logit
+    soft-cap - that is handed a plan with ranges uses the plan's (request, split) items: the bits of a plan without."""
+    assert nat.decode_ranges(32, 8, 128, torch.bfloat16, torch.uint8) == 0
+    assert nat.decode_ranges(32, 8, 128, torch.float32) == 0
+    assert nat.decode_ranges(8, 1, 128, torch.bfloat16) == 0 and nat.decode_ranges(12, 6, 64, torch.float16) == 0
+    assert nat.decode_ranges(32, 8, 256, torch.bfloat16) == 0
+    assert nat.decode_ranges(32, 8, 128, torch.bfloat16) == 2 * nat.decode_ranges(64, 16, 128, torch.bfloat16)
+    bs, chunk, max_len = 24, 64, 700
+    g = torch.Generator().manual_seed(3)
+    lens = torch.randint(1, 700, (bs,), generator=g)
+    for Hq, Hkv, cap in ((8, 1, 0.0), (32, 8, 30.0)):
+        p = paged_problem(900 + Hq, bs, Hq, Hkv, 128, lens.tolist(), torch.bfloat16, DEV)
+        slots = nat.decode_plan_slots(bs, max_len, chunk, kv_tokens=int(lens.sum()))
+        outs = []
+        for ranges in (0, 96):
+            ws = torch.empty(nat.decode_workspace_bytes(bs, Hq, 128, max_len, chunk, slots, ranges), dtype=torch.uint8, device=DEV)
+            plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, slots, ranges) // 4, dtype=torch.int32, device=DEV)
+            nat.decode_plan(plan, p["seq_lens"], max_len, chunk, slots, ranges)
+            o = torch.zeros_like(p["q"])
+            nat.decode_attention(o, p["q"], p["k_buffer"], p["v_buffer"], p["req_to_token"], p["req_pool_indices"],
+                                 p["seq_lens"], 0.09, cap, max_len, chunk, ws, None, plan, max_slots=slots, ranges=ranges)
+            outs.append(o)
+        assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1]), (Hq, Hkv, cap)
+        check_decode(outs[1], p, 0.09, torch.bfloat16, f"items behind a range plan Hq{Hq} Hkv{Hkv} cap{cap}", cap=cap)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])

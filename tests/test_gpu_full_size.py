@@ -68,19 +68,21 @@ def oracle_rows(q_rows, kb, vb, r2t, req_rows, seq_rows, abs_v=False):
                                 torch.tensor(req_rows), torch.tensor(seq_rows), SCALE)
 
 
-def run_decode(nat, q, kb, vb, r2t, req, seq, chunk, plan=True):
-    """THE SHIPPED FORM (HipAttnBackend's default): a split plan built once per step (the kernels read the split size
-    from it), the matrix-core kernel writing split partials, and the separate merge launch; non-temporal gathers as
-    the library defaults them.  plan=False: the plan-less static (request, split) grid."""
+def run_decode(nat, q, kb, vb, r2t, req, seq, chunk, plan=True, ranges=0):
+    """A plan built once per step, the matrix-core kernel writing partials, and the separate merge launch; non-temporal
+    gathers as the library defaults them.  ranges > 0: THE SHIPPED FORM where the range kernel takes the shape
+    (HipAttnBackend passes sp_decode_ranges()): the plan's range geometry, one workgroup per (piece of the step's keys,
+    four kv heads).  ranges = 0: the plan's (request, split) items at split size `chunk` (what the backend runs on the
+    other shapes).  plan=False: the plan-less static (request, split) grid."""
     bs, hq = q.shape[0], q.shape[1]
     max_len = int(seq.max())
-    ws = torch.empty(nat.decode_workspace_bytes(bs, hq, D, max_len, chunk), dtype=torch.uint8, device=DEV)
+    ws = torch.empty(nat.decode_workspace_bytes(bs, hq, D, max_len, chunk, None, ranges), dtype=torch.uint8, device=DEV)
     o = torch.full_like(q, float("nan"))
     pl = None
     if plan:
-        pl = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk) // 4, dtype=torch.int32, device=DEV)
-        nat.decode_plan(pl, seq, max_len, chunk)
-    nat.decode_attention(o, q, kb, vb, r2t, req, seq, SCALE, 0.0, max_len, chunk, ws, None, pl)
+        pl = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, None, ranges) // 4, dtype=torch.int32, device=DEV)
+        nat.decode_plan(pl, seq, max_len, chunk, None, ranges)
+    nat.decode_attention(o, q, kb, vb, r2t, req, seq, SCALE, 0.0, max_len, chunk, ws, None, pl, ranges=ranges)
     return o
 
 
@@ -122,6 +124,24 @@ def full_size_decode_checks(nat, dt, bs, hq, hkv, rows, what):
     assert torch.equal(o_perm, o512[order])
     # (e) the layout is not part of the result: the same rows in two separate contiguous K / V buffers - same bits
     assert torch.equal(run_decode(nat, q, kb.contiguous(), vb.contiguous(), r2t, req, seq, 512), o512)
+    # (f) the range geometry (what HipAttnBackend ships where sp_decode_ranges() > 0: config 2's shape), at the piece
+    # count the library asks for and at two others: the oracle rows, at most 2 units from the split results, slot
+    # relocation bit-exact; a permuted batch is cut at other places - another split of the same sums: 2 units
+    auto = nat.decode_ranges(hq, hkv, D, dtype)
+    assert (auto > 0) == (hkv % 4 == 0)
+    if auto:
+        for ranges in (auto, 61, 1500):
+            orr = run_decode(nat, q, kb, vb, r2t, req, seq, 512, ranges=ranges)
+            assert torch.isfinite(orr.float()).all()
+            assert_attn_close(orr[rows], ref, aref, dtype, what=f"{what} {dt}: {ranges} ranges, rows vs oracle")
+            diff = (orr.float() - o512.float()).abs()
+            assert float(diff.max()) <= 2.5 * u * float(vb.float().abs().max()), f"{ranges} ranges vs chunk 512: {float(diff.max()):.3e}"
+            if ranges == auto:
+                assert torch.equal(run_decode(nat, q, kb2, vb2, r2t2, req, seq, 512, ranges=ranges), orr)
+                op = run_decode(nat, q[order].contiguous(), kb, vb, r2t, req[order].contiguous(), seq[order].contiguous(),
+                                512, ranges=ranges)
+                diff = (op.float() - orr[order].float()).abs()
+                assert float(diff.max()) <= 2.5 * u * float(vb.float().abs().max()), f"permuted batch: {float(diff.max()):.3e}"
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])

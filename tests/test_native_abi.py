@@ -26,7 +26,7 @@ def test_header_declares_the_whole_path():
     for s in ["sp_rmsnorm", "sp_fused_add_rmsnorm", "sp_silu_and_mul", "sp_rotary_embedding",
               "sp_kv_store", "sp_write_req_to_token", "sp_compute_position", "sp_clamp_position",
               "sp_decode_attention", "sp_decode_attention_workspace_bytes", "sp_decode_plan",
-              "sp_decode_plan_bytes", "sp_extend_attention",
+              "sp_decode_plan_bytes", "sp_decode_ranges", "sp_extend_attention",
               "sp_extend_attention_workspace_bytes", "sp_abi_version", "sp_status_string",
               "sp_argmax", "sp_softmax_temperature", "sp_top_k_top_p_min_p_sample",
               "sp_top_k_top_p_min_p_renorm"]:
@@ -45,7 +45,7 @@ def test_python_binding_covers_every_symbol():
 
 def test_abi_version_and_status_strings(lib):
     lib.sp_abi_version.restype = ctypes.c_int
-    assert lib.sp_abi_version() == 7
+    assert lib.sp_abi_version() == 8
     lib.sp_status_string.restype = ctypes.c_char_p
     assert lib.sp_status_string(0) == b"ok"
     assert b"unsupported" in lib.sp_status_string(-2)
@@ -71,9 +71,11 @@ def test_host_side_argument_validation_needs_no_gpu(lib):
     assert lib.sp_decode_attention_workspace_bytes(256 * 8, 32, 128) == 256 * 32 * 8 * 129 * 4 + 16
     assert lib.sp_decode_attention_workspace_bytes(0, 8, 64) == 16
     lib.sp_decode_plan_bytes.restype = ctypes.c_size_t
-    lib.sp_decode_plan_bytes.argtypes = [ctypes.c_int, ctypes.c_int64]
+    lib.sp_decode_plan_bytes.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int]
     # a 4-word header (listed, chunk, needed, keys), slot0[bs], the item pairs (ABI 7: no arrival counters behind them)
-    assert lib.sp_decode_plan_bytes(256, 2304) == (4 + 256 + 2 * 2304) * 4
+    assert lib.sp_decode_plan_bytes(256, 2304, 0) == (4 + 256 + 2 * 2304) * 4
+    # ABI 8: with ranges, the range geometry behind them: [pieces, R, 0, 0], pos[bs + 1], start[ranges]
+    assert lib.sp_decode_plan_bytes(256, 2304, 384) == (4 + 256 + 2 * 2304 + 4 + 257 + 384) * 4
 
 
 def test_ops_refuse_host_tensors():

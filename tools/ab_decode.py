@@ -2,9 +2,13 @@
 """A/B of decode-attention builds / switches in ONE process on one box (boxes differ by ~2.5 % in this kernel).
 
 Every LIBSPEC named on the command line - FILE[@key=value,...] under scratchpad_amd/lib, the switches applied through
-sp_debug_set after loading - runs the SAME decode launch in interleaved rounds: the shipped form (split plan + separate
+sp_debug_set after loading - runs the SAME decode launch in interleaved rounds: the shipped form (plan + separate
 merge launch, K/V as the two strided views of one interleaved [P+1, 2, Hkv, D] arena as MHATokenToKVPool makes them,
-non-temporal gathers by default).  Outputs are compared bit for bit with the first library's.
+non-temporal gathers by default).  The pseudo-switch ranges=N (N = -1: what sp_decode_ranges() asks for) gives the plan
+and the launch the range geometry (ABI 8); without it the launch uses the (request, split) items at --chunk.  Outputs
+are compared with the first library's (bit for bit within one geometry; the geometries differ in the last bits).
+NOTE: dlopen hands out ONE copy of a library file however often it is named - to compare switches of one build, copy
+the file under a second name.
 
   python tools/ab_decode.py libscratchpad_hip.so libscratchpad_hip_x.so [--shape headline|hkv1|bs64|...] [--chunk 768]
   shapes: headline = bs 256, Hq 32 / Hkv 8, contexts U[128,4096] seed 0;  hkv1 = bs 128, Hq 8 / Hkv 1 (config 4's rank)
@@ -22,7 +26,9 @@ sys.path.insert(0, ROOT)
 
 SHAPES = {"headline": (256, 32, 8, "128:4096"), "hkv1": (128, 8, 1, "128:4096"), "bs128": (128, 32, 8, "128:4096"),
           "bs64": (64, 32, 8, "128:4096"), "bs8": (8, 32, 8, "1024"), "bs1": (1, 32, 8, "1024"),
-          "ctx1024": (256, 32, 8, "1024"), "ctx4096": (256, 32, 8, "4096")}
+          "ctx1024": (256, 32, 8, "1024"), "ctx4096": (256, 32, 8, "4096"),
+          # uniform contexts that deal out evenly over 768 resident workgroups at split size 768 (2 and 3 units each)
+          "ctx2304": (256, 32, 8, "2304"), "ctx3456": (256, 32, 8, "3456")}
 
 
 def load_native(libspec, tag):
@@ -32,10 +38,14 @@ def load_native(libspec, tag):
     spec.loader.exec_module(m)
     m._LIB_PATH = os.path.join(ROOT, "scratchpad_amd", "lib", libfile)
     m.load()
+    ranges = 0
     for kv in filter(None, switches.split(",")):
         k, v = kv.split("=")
-        m.debug_set(k, int(v))
-    return m
+        if k == "ranges":
+            ranges = int(v)
+        else:
+            m.debug_set(k, int(v))
+    return m, ranges
 
 
 def main():
@@ -78,18 +88,21 @@ def main():
     eb = q.element_size()
     alg = total * 2 * Hkv * D * (1 if a.kv == "fp8" else eb) + 2 * bs * Hq * D * eb + 4 * total
     slots = (max(1024, 8 * bs) + bs) if a.graph_slots else None
-    nats = [load_native(lib, i) for i, lib in enumerate(a.libs)]
-    ws = torch.empty(nats[0].decode_workspace_bytes(bs, Hq, D, max_len, a.chunk, slots), dtype=torch.uint8, device=dev)
+    loaded = [load_native(lib, i) for i, lib in enumerate(a.libs)]
+    nats = [n for n, _ in loaded]
+    rngs = [n.decode_ranges(Hq, Hkv, D, dt, arena.dtype) if r < 0 else r for n, r in loaded]
+    ws = torch.empty(max(n.decode_workspace_bytes(bs, Hq, D, max_len, a.chunk, slots, ranges=r) for n, r in zip(nats, rngs)),
+                     dtype=torch.uint8, device=dev)
     plans, outs = [], []
-    for n in nats:
-        pl = torch.empty(n.decode_plan_bytes(bs, max_len, a.chunk, slots) // 4, dtype=torch.int32, device=dev)
-        n.decode_plan(pl, seq, max_len, a.chunk, slots)
+    for n, r in zip(nats, rngs):
+        pl = torch.empty(n.decode_plan_bytes(bs, max_len, a.chunk, slots, ranges=r) // 4, dtype=torch.int32, device=dev)
+        n.decode_plan(pl, seq, max_len, a.chunk, slots, ranges=r)
         plans.append(pl)
         outs.append(torch.full_like(q, float("nan")))
 
     def run(i):
         nats[i].decode_attention(outs[i], q, kb, vb, r2t, req, seq, D ** -0.5, 0.0, max_len, a.chunk, ws, None, plans[i],
-                                 max_slots=slots)
+                                 max_slots=slots, ranges=rngs[i])
     for i in range(len(nats)):
         run(i)
     torch.cuda.synchronize()
@@ -98,7 +111,9 @@ def main():
           f"alg bytes {alg / 1e9:.3f} GB", flush=True)
     for i in range(1, len(nats)):
         same = torch.equal(outs[i], outs[0])
-        print(f"{a.libs[i]} vs {a.libs[0]}: bit-identical={same} finite={bool(torch.isfinite(outs[i].float()).all())}", flush=True)
+        err = float((outs[i].float() - outs[0].float()).abs().max())
+        print(f"{a.libs[i]} (ranges {rngs[i]}) vs {a.libs[0]} (ranges {rngs[0]}): bit-identical={same} max|diff|={err:.3g} "
+              f"finite={bool(torch.isfinite(outs[i].float()).all())}", flush=True)
     times = [[] for _ in nats]
     for r in range(a.rounds + 1):
         for i in range(len(nats)):

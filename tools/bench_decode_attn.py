@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Micro-benchmark of sp_decode_attention on the headline workload's shapes (no model around it).
 
-  python tools/bench_decode_attn.py [--bs 256] [--ctx uniform|N] [--chunks 128,256,512] [--iters 20]
-Prints one line per chunk: avg launch time (HIP events on the launch stream), algorithmic GB/s."""
+  python tools/bench_decode_attn.py [--bs 256] [--ctx uniform|N] [--chunks 128,256,512] [--ranges -1|0|N] [--iters 20]
+Prints one line per chunk: avg launch time (HIP events on the launch stream), algorithmic GB/s.  --ranges: the plan's
+range geometry as HipAttnBackend uses it (-1, the default: sp_decode_ranges() pieces where the range kernel takes the
+shape; the split size then only sizes the plan's item section), 0: the (request, split) items at the split size."""
 import argparse
 import os
 import sys
@@ -34,6 +36,7 @@ def main():
     ap.add_argument("--slots", type=int, default=0,
                     help="work items the launch covers (graph replay covers max(1024, 8 bs) + bs; default: what the step needs)")
     ap.add_argument("--gemm", action="store_true", help="interleave a bf16 GEMM between launches (as in a model)")
+    ap.add_argument("--ranges", type=int, default=-1, help="pieces of the range geometry (-1: sp_decode_ranges(), 0: none)")
     a = ap.parse_args()
     if a.lib:
         _native._LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scratchpad_amd", "lib", a.lib)
@@ -77,15 +80,19 @@ def main():
     alg = total * 2 * a.Hkv * a.D * kv_eb + 2 * a.bs * a.Hq * a.D * eb + 4 * total
     max_len = int(ctx.max())
     ref = None
+    ranges = a.ranges if a.ranges >= 0 else _native.decode_ranges(a.Hq, a.Hkv, a.D, dt, kb.dtype)
+    if a.no_plan:
+        ranges = 0
+    print(f"range geometry: {ranges} pieces" if ranges else "(request, split) items", flush=True)
     for chunk in [int(c) for c in a.chunks.split(",")]:
         slots = a.slots or None
-        ws = torch.empty(_native.decode_workspace_bytes(a.bs, a.Hq, a.D, max_len, chunk, slots), dtype=torch.uint8, device=dev)
+        ws = torch.empty(_native.decode_workspace_bytes(a.bs, a.Hq, a.D, max_len, chunk, slots, ranges), dtype=torch.uint8, device=dev)
         plan = None
         if not a.no_plan:
-            plan = torch.empty(_native.decode_plan_bytes(a.bs, max_len, chunk, slots) // 4, dtype=torch.int32, device=dev)
-            _native.decode_plan(plan, seq, max_len, chunk, slots)
+            plan = torch.empty(_native.decode_plan_bytes(a.bs, max_len, chunk, slots, ranges) // 4, dtype=torch.int32, device=dev)
+            _native.decode_plan(plan, seq, max_len, chunk, slots, ranges)
         run = lambda: _native.decode_attention(o, q, kb, vb, r2t, req, seq, a.D ** -0.5, 0.0, max_len, chunk, ws, None, plan,
-                                               max_slots=slots)
+                                               max_slots=slots, ranges=ranges)
         for _ in range(a.warmup):
             run()
         torch.cuda.synchronize()

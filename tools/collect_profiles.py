@@ -22,10 +22,10 @@ def main(tag):
            f"--no-cpu-baseline --no-ttft   (MI355X; tools/gpu_round_report.sh)\n"
            f"# bench line of this run: {b['value']} tokens/s, {b['ms_per_step']} ms/step; roofline: "
            f"{json.dumps(b['roofline'])}\n"
-           f"# decode_mfma_kernel rows include 2x32 graph-capture warm-up launches at the padded fill length (min_us).\n")
+           f"# decode_mfma_* rows include 2x32 graph-capture warm-up launches at the padded fill length (min_us).\n")
     body = "\n".join(line for line in ks if not line.startswith("{"))
-    tail = ("\n# steady-state rows above (\"#\"): launches > 100 us only for decode_mfma_kernel (drops the capture "
-            "warm-ups).\n# attn+merge per layer = decode_mfma_kernel + decode_merge_kernel steady averages; bench.py's "
+    tail = ("\n# steady-state rows above (\"#\"): launches > 100 us only for decode_mfma_* (drops the capture "
+            "warm-ups).\n# attn+merge per layer = decode_mfma_* + decode_merge_kernel steady averages; bench.py's "
             "HIP-event\n# average of the same pair (roofline.avg_launch_ms) additionally contains the inter-kernel gap "
             "of its eager pass.\n")
     open(os.path.join(P, f"{tag}_bench_kernel_stats.txt"), "w").write(hdr + body + tail)

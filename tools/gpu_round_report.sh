@@ -63,7 +63,7 @@ cd $GRAFT_REPO_ROOT
 STATS=$(find $R/prof -name "*kernel_stats.csv" | head -1)
 TRACE=$(find $R/prof -name "*kernel_trace.csv" | head -1)
 python tools/prof_summary.py $STATS 22 > $R/kernel_stats.txt
-python tools/prof_summary.py --steady $TRACE decode_mfma_kernel decode_merge_kernel >> $R/kernel_stats.txt
+python tools/prof_summary.py --steady $TRACE decode_mfma_ decode_merge_kernel >> $R/kernel_stats.txt
 tail -1 $R/prof_bench.json | cut -c1-300 >> $R/kernel_stats.txt
 rm -rf $R/prof
 cat $R/kernel_stats.txt

@@ -14,8 +14,8 @@ timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/w -- python3 $B > $OUT/w.log 2>&1 || { tail -5 $OUT/f.log $OUT/w.log; exit 1; }
 cd $GRAFT_REPO_ROOT
 { echo "# rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE} --kernel-trace -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-ttft --profile-steps 1 $*"
-  python tools/pmc_summary.py $OUT/f decode_mfma_kernel decode_merge_kernel
-  python tools/pmc_summary.py $OUT/w decode_mfma_kernel decode_merge_kernel
+  python tools/pmc_summary.py $OUT/f decode_mfma_ decode_merge_kernel
+  python tools/pmc_summary.py $OUT/w decode_mfma_ decode_merge_kernel
   grep -h '^{"metric"' $OUT/f.log | tail -1 | cut -c1-600; } > $OUT/summary.txt
 KEY=$KEY python - <<'PY'
 import csv, glob, json, os, re, sys
@@ -25,7 +25,7 @@ out = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "pmc_bench")
 def steady(root, counter):
     """per-launch counter values of the model's steady-state launches: the decode_mfma launches above half the largest
     value (drops graph-capture warm-ups at the padded fill length) and all merge launches behind them"""
-    vals = {"decode_mfma_kernel": [], "decode_merge_kernel": []}
+    vals = {"decode_mfma_": [], "decode_merge_kernel": []}     # decode_mfma_range_kernel / decode_mfma_kernel
     for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] != counter:
@@ -33,8 +33,8 @@ def steady(root, counter):
             for k in vals:
                 if k in r["Kernel_Name"]:
                     vals[k].append(float(r["Counter_Value"]))
-    big = max(vals["decode_mfma_kernel"])
-    a = [v for v in vals["decode_mfma_kernel"] if v > 0.5 * big]
+    big = max(vals["decode_mfma_"])
+    a = [v for v in vals["decode_mfma_"] if v > 0.5 * big]
     m = vals["decode_merge_kernel"]
     mbig = max(m) if m else 0.0
     mm = [v for v in m if v > 0.5 * mbig] if m else [0.0]
@@ -45,7 +45,7 @@ line = json.loads([l for l in open(os.path.join(out, "f.log")) if l.startswith('
 alg = line["roofline"]["algorithmic_bytes_per_launch"]
 hbm = (2 * fa + wa + fm + wm) * 1024.0
 rec = {"workload": "python3 bench.py " + " ".join(sys.argv[1:]) + " (in the model, HIP-graph replay)", "bench_workload": os.environ["KEY"],
-       "kernel": "decode_mfma_kernel+decode_merge_kernel", "algorithmic_bytes": int(alg), "launches_averaged": n,
+       "kernel": line["roofline"]["kernel"], "algorithmic_bytes": int(alg), "launches_averaged": n,
        "fetch_size_kib": fa, "write_size_kib": wa, "merge_fetch_kib": fm, "merge_write_kib": wm,
        "hbm_bytes_per_launch": int(hbm), "traffic_over_algorithmic": round(hbm / alg, 4), "in_model": True,
        "correction": "FETCH_SIZE x 2 for the 16-B/lane streaming gathers (gfx950), WRITE_SIZE and the merge as counted",

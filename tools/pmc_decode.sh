@@ -19,8 +19,8 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 cd $GRAFT_REPO_ROOT
 find $OUT/kt -name "*kernel_stats.csv" -exec cat {} \; | grep -i "decode_\|\"Name\"" > $OUT/kernel_stats.csv
 { echo "# $NAME: python3 tools/bench_decode_attn.py $SHAPE $FLAG  (bench workload: $KEY)"
-  python tools/pmc_summary.py $OUT/f decode_mfma_kernel decode_merge_kernel
-  python tools/pmc_summary.py $OUT/w decode_mfma_kernel decode_merge_kernel
+  python tools/pmc_summary.py $OUT/f decode_mfma_ decode_merge_kernel
+  python tools/pmc_summary.py $OUT/w decode_mfma_ decode_merge_kernel
   grep -h "^chunk" $OUT/f.log
   echo "# rocprofv3 --kernel-trace --stats (ns):"; cat $OUT/kernel_stats.csv; } > $OUT/summary.txt
 NAME=$NAME KEY=$KEY SHAPE="$SHAPE $FLAG" python - <<'PY'
@@ -29,16 +29,18 @@ sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 import bench
 name = os.environ["NAME"]
 out = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "pmc_" + name)
-vals, alg = {}, None
+vals, alg, attn = {}, None, "decode_mfma_kernel"
 for line in open(os.path.join(out, "summary.txt")):
     m = re.match(r"(\S+)<.*?>\s+(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+\s+mean=\s*([\d.]+)", line)
     if m:
         vals[(m.group(1), m.group(2))] = float(m.group(3))
+        if m.group(1).startswith("decode_mfma_"):        # decode_mfma_range_kernel or decode_mfma_kernel: one of them runs
+            attn = m.group(1)
     m = re.search(r"alg bytes ([\d.]+) GB", line)
     if m:
         alg = float(m.group(1)) * 1e9
 g = lambda k, c: vals.get((k, c), 0.0)
-hbm = (2 * g("decode_mfma_kernel", "FETCH_SIZE") + g("decode_mfma_kernel", "WRITE_SIZE")
+hbm = (2 * g(attn, "FETCH_SIZE") + g(attn, "WRITE_SIZE")
        + g("decode_merge_kernel", "FETCH_SIZE") + g("decode_merge_kernel", "WRITE_SIZE")) * 1024.0
 ns = {}
 for line in open(os.path.join(out, "kernel_stats.csv")):
@@ -46,9 +48,9 @@ for line in open(os.path.join(out, "kernel_stats.csv")):
     if m:
         ns[m.group(1)] = float(m.group(4))
 rec = {"workload": "tools/bench_decode_attn.py " + os.environ["SHAPE"], "bench_workload": os.environ["KEY"],
-       "kernel": "decode_mfma_kernel" + ("+decode_merge_kernel" if ("decode_merge_kernel", "FETCH_SIZE") in vals else " (fused merge)"),
+       "kernel": attn + "+decode_merge_kernel",
        "algorithmic_bytes": int(alg),
-       "fetch_size_kib": g("decode_mfma_kernel", "FETCH_SIZE"), "write_size_kib": g("decode_mfma_kernel", "WRITE_SIZE"),
+       "fetch_size_kib": g(attn, "FETCH_SIZE"), "write_size_kib": g(attn, "WRITE_SIZE"),
        "merge_fetch_kib": g("decode_merge_kernel", "FETCH_SIZE"), "merge_write_kib": g("decode_merge_kernel", "WRITE_SIZE"),
        "hbm_bytes_per_launch": int(hbm), "traffic_over_algorithmic": round(hbm / alg, 4),
        "rocprof_avg_ns": ns,

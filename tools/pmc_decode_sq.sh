@@ -27,7 +27,7 @@ cd $GRAFT_REPO_ROOT
   echo "# decode attention, tools/bench_decode_attn.py --chunks 768 --interleave (plan + merge launch); default shape = bs 256 Hq 32 Hkv 8 U[128,4096] bf16"
   for na in "${NAMES[@]}"; do
     name=${na%%:*}; echo "# $name: bench_decode_attn.py ${na#*:}"
-    for g in g1 g2 g3; do d=${name}_$g; echo "## $d"; python tools/pmc_summary.py $OUT/$d decode_mfma_kernel; grep -h "^chunk" $OUT/$d.log; done
+    for g in g1 g2 g3; do d=${name}_$g; echo "## $d"; python tools/pmc_summary.py $OUT/$d decode_mfma_; grep -h "^chunk" $OUT/$d.log; done
   done
 } > $OUT/summary.txt 2>&1
 for na in "${NAMES[@]}"; do name=${na%%:*}; for g in g1 g2 g3; do rm -rf $OUT/${name}_$g; done; done

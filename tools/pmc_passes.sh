@@ -19,7 +19,7 @@ run dec8_write "WRITE_SIZE" $DEC
 cd $GRAFT_REPO_ROOT
 {
   for d in ext_sq1 ext_sq2 ext_fetch; do echo "## $d"; python tools/pmc_summary.py $OUT/$d extend_mfma_kernel; done
-  for d in dec8_fetch dec8_write; do echo "## $d"; python tools/pmc_summary.py $OUT/$d decode_mfma_kernel decode_merge_kernel; done
+  for d in dec8_fetch dec8_write; do echo "## $d"; python tools/pmc_summary.py $OUT/$d decode_mfma_ decode_merge_kernel; done
   grep -h "extend bs\|chunk" $OUT/ext_fetch.log $OUT/dec8_fetch.log
 } > $OUT/summary.txt 2>&1
 rm -rf $OUT/ext_sq1 $OUT/ext_sq2 $OUT/ext_fetch $OUT/dec8_fetch $OUT/dec8_write
