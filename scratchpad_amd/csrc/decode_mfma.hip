@@ -109,9 +109,10 @@ struct DmCfg {
   static constexpr int kMergeBytes = WAVES * 16 * (D + 2) * 4;
   static constexpr int kLdsBytes = kStageBytes > kMergeBytes ? kStageBytes : kMergeBytes;
 };
-// persistent form: LDS per wave in which split partials wait for the end of the wave's work (with the 32 KiB of tiles
-// at D = 128: 49 KiB per workgroup, three workgroups per CU)
-static constexpr int kDmParkWaveB = 4352;
+// range kernel: LDS per wave in which the partials of cut requests wait for the end of the piece: 4 records at G = 4,
+// D = 128 (a piece cuts at most two requests), 2 at G = 8, 1 at G = 16.  With the 32 KiB of tiles at D = 128 that is
+// 64.6 KiB per workgroup: the two workgroups per CU a range launch runs (decode_mfma_ranges) fit.
+static constexpr int kDmParkWaveB = 2 * (8 * 128 * 4 + 64 + 16);
 
 // HPW ("head per wave", Hkv % 4 == 0): the 4 waves take the 4 adjacent KV heads of the SAME keys - the
 // workgroup then reads whole 1 KiB token half-rows, and each wave owns its heads outright: no merge,
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
 //     batch at 6.15;
 //   * WHERE the partials go: fp32 partial rows written to HBM in between the gathers cost ~1.8 us per MB, ten times
 //     their share of the bytes.  A piece cuts at most two requests (its first and its last); the wave PARKS those
-//     partial rows in LDS the tiles do not use and writes them, in whole 512-byte rows, when the piece is done - which
+//     partial rows in LDS behind the tiles and writes them, in whole 512-byte rows, when the piece is done - which
 //     is when the launch as a whole runs out of gathers.  Requests inside a piece are written straight to the output.
 // The walk never drains the wave's gathers: while a request's last 64 keys are consumed, the next request's record
 // and first index register are fetched, and its first tile's gathers are issued where the current request has none
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_range_kernel(De
   // Parking space of this wave behind the tiles: records of [G rows of D floats | 16 log-sum-exps | request]
   const int park_rows_b = G * D * 4;
   const int park_unit_b = park_rows_b + 64 + 16;
-  const int park_cap = kDmParkWaveB / park_unit_b;          // 2 at G = 4, D = 128; 0: the group is too wide to park
+  const int park_cap = kDmParkWaveB / park_unit_b;          // (at least 1: G <= 16, D <= 128)
   char* park = lds + 4 * 2 * TILE_B + wave * kDmParkWaveB;
   int parked = 0;
   auto flush_parked = [&]() {
@@ -769,31 +770,38 @@ int run_decode_mfma(const DecodeArgs& a, int head_dim, int dtype, hipStream_t st
   return SP_ERR_UNSUPPORTED;
 }
 
-// Pieces per head quad the range kernel wants: the workgroups the chip holds at once (asked of the runtime, once per
-// instantiation) over the head quads.  0: the shape is not the range kernel's (a 16-bit pool with Hkv % 4 == 0,
-// G <= 16, D in {64, 128}).
+// Pieces per head quad the range kernel wants: TWO workgroups per CU over the head quads - all resident at once (the
+// runtime is asked, once per instantiation), every one the same length.  Measured on MI355X, bs 256, contexts
+// U[128, 4096] (profiles/r05_decode_range.txt): 1 / 2 / 3 workgroups per CU 340.7 / 339.7 / 348.1 us, two rounds of
+// shorter pieces 366 - 392: a piece pays its start, its cut requests' partials and its tail once, so few long streams
+// beat many short ones as soon as they keep HBM busy, and 8 waves per CU with one 8 KiB tile in flight each do
+// (6.6 TB/s).  0: the shape is not the range kernel's (a 16-bit pool with Hkv % 4 == 0, G <= 16, D in {64, 128}).
 template <typename Tag, int D>
-static int dm_resident_workgroups() {
-  static int resident = 0;
-  if (!resident) {
+static int dm_range_workgroups() {
+  static int workgroups = 0;
+  if (!workgroups) {
     int dev = 0, per_cu = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_mfma_range_kernel<Tag, D>, 256, dm_range_lds<D>()) !=
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (dm_range_lds<D>() > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)decode_mfma_range_kernel<Tag, D>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            dm_range_lds<D>()) != hipSuccess)
+      return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_mfma_range_kernel<Tag, D>, 256, dm_range_lds<D>()) !=
             hipSuccess || per_cu < 1)
       return 0;
-    resident = per_cu * prop.multiProcessorCount;
+    workgroups = (per_cu < 2 ? per_cu : 2) * prop.multiProcessorCount;
   }
-  return resident;
+  return workgroups;
 }
 
 int decode_mfma_ranges(int num_q_heads, int num_kv_heads, int head_dim, int dtype, int kv8) {
   if (kv8 || num_kv_heads % 4 || num_q_heads / num_kv_heads > 16 || (dtype != SP_BF16 && dtype != SP_F16)) return 0;
-  int resident = 0;
-  if (head_dim == 128) resident = dtype == SP_BF16 ? dm_resident_workgroups<bf16_tag, 128>() : dm_resident_workgroups<f16_tag, 128>();
-  else if (head_dim == 64) resident = dtype == SP_BF16 ? dm_resident_workgroups<bf16_tag, 64>() : dm_resident_workgroups<f16_tag, 64>();
-  const int pieces = resident / (num_kv_heads / 4);
-  return pieces > 0 ? pieces : (resident > 0 ? 1 : 0);
+  int wgs = 0;
+  if (head_dim == 128) wgs = dtype == SP_BF16 ? dm_range_workgroups<bf16_tag, 128>() : dm_range_workgroups<f16_tag, 128>();
+  else if (head_dim == 64) wgs = dtype == SP_BF16 ? dm_range_workgroups<bf16_tag, 64>() : dm_range_workgroups<f16_tag, 64>();
+  const int pieces = wgs / (num_kv_heads / 4);
+  return pieces > 0 ? pieces : (wgs > 0 ? 1 : 0);
 }
 
 }  // namespace sp
