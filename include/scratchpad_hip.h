@@ -175,7 +175,7 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  * line: no two (request, piece) pairs share a slot) and the merge launch combines them: the workspace then holds
  * batch_size + ranges slots, whatever sum(seq_lens) is - the overflow below cannot happen on this path.
  * sp_decode_ranges() is the piece count the library wants for a shape: two workgroups per CU, all resident at once, over the
- * head quads (two per CU: 256 pieces for 8 kv heads on MI355X), or 0 where the range kernel does not apply (a byte pool, fp32,
+ * head quads (two per CU: 256 pieces for 8 kv heads on MI355X), or 0 where the range kernel does not apply (fp32,
  * num_kv_heads % 4 != 0, groups wider than 16).  Launches it does not take (those shapes, a logit soft-cap, out rows
  * not 8-byte aligned, sp_debug_set("decode_ranges", 0)) use the plan's (request, split) items as before: a plan
  * always carries both.  Requires batch_size * (max_seq_len + 16) < 2^31 (else SP_ERR_INVALID_ARG from sp_decode_plan;

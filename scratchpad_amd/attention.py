@@ -148,8 +148,8 @@ class HipAttnBackend(AttentionBackend):
         self._plan_hosts = []          # pinned buffers + events to reuse
         self._plan_lock = threading.Lock()   # the overlap worker checks from the scheduler thread (tp_worker_client.py)
         # Range geometry (include/scratchpad_hip.h, ABI 8): the pieces the step's keys are cut into, one workgroup per
-        # (piece, four kv heads) - what the chip holds at once; 0 where the range kernel does not take the shape (a
-        # byte pool, fp32, kv heads not in fours), and those launches use the plan's (request, split) items below.
+        # (piece, four kv heads), two per CU; 0 where the range kernel does not take the shape (fp32, kv heads not in
+        # fours), and those launches use the plan's (request, split) items below.
         # SP_DECODE_RANGES=0 switches it off, =N forces N pieces (A/B runs).
         env = os.environ.get("SP_DECODE_RANGES", "")
         self.decode_ranges = int(env) if env else _native.decode_ranges(

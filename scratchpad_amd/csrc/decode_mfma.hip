@@ -113,6 +113,9 @@ struct DmCfg {
 // D = 128 (a piece cuts at most two requests), 2 at G = 8, 1 at G = 16.  With the 32 KiB of tiles at D = 128 that is
 // 64.6 KiB per workgroup: the two workgroups per CU a range launch runs (decode_mfma_ranges) fit.
 static constexpr int kDmParkWaveB = 2 * (8 * 128 * 4 + 64 + 16);
+// ... and on a byte pool, where a tile in flight is half the bytes, THREE workgroups per CU: 2 records at G = 4, 1 at
+// G = 8, none (stored at once) at G = 16; 49 KiB per workgroup at D = 128
+static constexpr int kDmParkWaveB8 = 2 * (4 * 128 * 4 + 64 + 16);
 
 // HPW ("head per wave", Hkv % 4 == 0): the 4 waves take the 4 adjacent KV heads of the SAME keys - the
 // workgroup then reads whole 1 KiB token half-rows, and each wave owns its heads outright: no merge,
@@ -453,11 +456,13 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
 // left to issue.  The four waves of a workgroup walk the same piece for the four heads of the quad and share nothing
 // (wave-private LDS tile, no barrier).  The arithmetic per key is that of decode_mfma_kernel; the cuts differ, so the
 // bits are those of another - equally valid - split of the same sums.
-template <typename Tag, int D>
+template <typename Tag, int D, bool KV8>
 __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_range_kernel(DecodeArgs a) {
   typedef DmCfg<D> C;
-  typedef u32x4 raw_t;
-  constexpr int SRC_ROW_B = 2 * D, SRC_CH_B = 16;
+  typedef typename std::conditional<KV8, f16_tag, Tag>::type CT;      // dtype of the tile math (see decode_mfma_kernel)
+  typedef typename std::conditional<KV8, u32x2, u32x4>::type raw_t;   // one lane's gathered chunk
+  constexpr int SRC_ROW_B = KV8 ? D : 2 * D;                          // bytes of one head row in the pool
+  constexpr int SRC_CH_B = KV8 ? 8 : 16;                              // bytes of the 8 elements a lane gathers
   constexpr int TK = C::TK, ROW_B = C::ROW_B, CPR = C::CPR, RPL = C::RPL, NLD = C::NLD;
   constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK, TILE_B = C::TILE_B;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -476,7 +481,7 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_range_kernel(De
   char* ldsV = ldsK + TILE_B;
   const float qk_scale = a.sm_scale * kLog2eM;
   const int ld_row = lane / CPR, ld_ch = lane % CPR;
-  const uint32_t tok_bytes = (uint32_t)(a.kv_stride * 2);
+  const uint32_t tok_bytes = (uint32_t)(a.kv_stride * (KV8 ? 1 : 2));
   const int64_t v_minus_k = a.vbuf - a.kbuf;
   const int i16 = lane & 15;
   const int tr_row = 4 * kq + (i16 >> 2);
@@ -543,7 +548,10 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_range_kernel(De
     const int hcol = min(col, G - 1);
     const char* qp = (const char*)a.q + ((int64_t)u.b * a.q_stride + (int64_t)(hk * G + hcol) * D + 8 * kq) * 2;
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) qf[s] = ld16(qp + s * 64);
+    for (int s = 0; s < KSTEPS; ++s) {
+      qf[s] = ld16(qp + s * 64);
+      if constexpr (KV8 && std::is_same<Tag, bf16_tag>::value) qf[s] = bf16x8_to_f16x8(qf[s]);
+    }
   };
   load_q(cur);
 
@@ -568,8 +576,13 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_range_kernel(De
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int Rw = i * RPL + ld_row;
-      st16(ldsK + Rw * ROW_B + ld_ch * 16, kr[i]);
-      st16(ldsV + Rw * ROW_B + ld_ch * 16, vr[i]);
+      if constexpr (KV8) {
+        st16(ldsK + Rw * ROW_B + ld_ch * 16, expand_e5m2x8(kr[i]));
+        st16(ldsV + Rw * ROW_B + ld_ch * 16, expand_e5m2x8(vr[i]));
+      } else {
+        st16(ldsK + Rw * ROW_B + ld_ch * 16, kr[i]);
+        st16(ldsV + Rw * ROW_B + ld_ch * 16, vr[i]);
+      }
     }
   };
   auto consume = [&](int tile, int n) {
@@ -580,7 +593,7 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_range_kernel(De
       for (int ks = 0; ks < KSTEPS; ++ks) {
         const int cg = 4 * ks + kq;
         const u32x4 kf = ld16(ldsK + Rw * ROW_B + ((cg ^ (Rw & (CPR - 1))) * 16));
-        s = mfma_qk<Tag>(kf, qf[ks], s);
+        s = mfma_qk<CT>(kf, qf[ks], s);
       }
     }
     float x[4], mx = kNegBigM;
@@ -605,8 +618,8 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_range_kernel(De
     psum += xchg32m(psum);
     l_run = l_run * alpha + psum;
     u32x2 pf;
-    pf[0] = pack2m<Tag>(x[0], x[1]);
-    pf[1] = pack2m<Tag>(x[2], x[3]);
+    pf[0] = pack2m<CT>(x[0], x[1]);
+    pf[1] = pack2m<CT>(x[2], x[3]);
 #pragma unroll
     for (int db = 0; db < DBLK; ++db) {
       const int cg = 2 * db + ((i16 & 3) >> 1);
@@ -615,14 +628,15 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_range_kernel(De
       const u32x2 vf = __builtin_bit_cast(u32x2, vt);
 #pragma unroll
       for (int r = 0; r < 4; ++r) oacc[db][r] *= alpha;
-      oacc[db] = mfma_pv<Tag>(vf, pf, oacc[db]);
+      oacc[db] = mfma_pv<CT>(vf, pf, oacc[db]);
     }
   };
   // Parking space of this wave behind the tiles: records of [G rows of D floats | 16 log-sum-exps | request]
   const int park_rows_b = G * D * 4;
   const int park_unit_b = park_rows_b + 64 + 16;
-  const int park_cap = kDmParkWaveB / park_unit_b;          // (at least 1: G <= 16, D <= 128)
-  char* park = lds + 4 * 2 * TILE_B + wave * kDmParkWaveB;
+  constexpr int kParkWaveB = KV8 ? kDmParkWaveB8 : kDmParkWaveB;
+  const int park_cap = kParkWaveB / park_unit_b;            // (16-bit pool: at least 1 - G <= 16, D <= 128)
+  char* park = lds + 4 * 2 * TILE_B + wave * kParkWaveB;
   int parked = 0;
   auto flush_parked = [&]() {
     for (int k = 0; k < parked; ++k) {
@@ -720,21 +734,18 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_range_kernel(De
   flush_parked();
 }
 
-template <int D>
-static constexpr int dm_range_lds() { return DmCfg<D>::kStageBytes + DmCfg<D>::WAVES * kDmParkWaveB; }
+template <int D, bool KV8>
+static constexpr int dm_range_lds() { return DmCfg<D>::kStageBytes + DmCfg<D>::WAVES * (KV8 ? kDmParkWaveB8 : kDmParkWaveB); }
 
 template <typename Tag, int D, bool KV8>
 static int launch_dm_kv(const DecodeArgs& a, hipStream_t st) {
   typedef DmCfg<D> C;
   const bool hpw = a.Hkv % 4 == 0 && a.o_stride % 4 == 0;
   if (a.rplan) {                                  // the range geometry: one workgroup per (piece, head quad)
-    if constexpr (KV8) return SP_ERR_INVALID_ARG;
-    else {
-      if (!hpw || a.ranges <= 0 || a.logit_cap > 0.f || a.nt_min_keys != 0) return SP_ERR_INVALID_ARG;
-      decode_mfma_range_kernel<Tag, D><<<dim3((unsigned)a.ranges * (a.Hkv / 4)), 256, dm_range_lds<D>(), st>>>(a);
-      SP_LAUNCH_CHECK();
-      return SP_OK;
-    }
+    if (!hpw || a.ranges <= 0 || a.logit_cap > 0.f || a.nt_min_keys != 0) return SP_ERR_INVALID_ARG;
+    decode_mfma_range_kernel<Tag, D, KV8><<<dim3((unsigned)a.ranges * (a.Hkv / 4)), 256, dm_range_lds<D, KV8>(), st>>>(a);
+    SP_LAUNCH_CHECK();
+    return SP_OK;
   }
   // planned: one workgroup per (plan item, head group), the launch covers max_slots items (the surplus
   // exits at once); plan-less: the static (request, split) grid
@@ -770,36 +781,42 @@ int run_decode_mfma(const DecodeArgs& a, int head_dim, int dtype, hipStream_t st
   return SP_ERR_UNSUPPORTED;
 }
 
-// Pieces per head quad the range kernel wants: TWO workgroups per CU over the head quads - all resident at once (the
-// runtime is asked, once per instantiation), every one the same length.  Measured on MI355X, bs 256, contexts
+// Pieces per head quad the range kernel wants: TWO workgroups per CU (three on a byte pool) over the head quads - all
+// resident at once (the runtime is asked, once per instantiation), every one the same length.  Measured on MI355X, bs 256, contexts
 // U[128, 4096] (profiles/r05_decode_range.txt): 1 / 2 / 3 workgroups per CU 340.7 / 339.7 / 348.1 us, two rounds of
 // shorter pieces 366 - 392: a piece pays its start, its cut requests' partials and its tail once, so few long streams
 // beat many short ones as soon as they keep HBM busy, and 8 waves per CU with one 8 KiB tile in flight each do
 // (6.6 TB/s).  0: the shape is not the range kernel's (a 16-bit pool with Hkv % 4 == 0, G <= 16, D in {64, 128}).
-template <typename Tag, int D>
+template <typename Tag, int D, bool KV8>
 static int dm_range_workgroups() {
   static int workgroups = 0;
   if (!workgroups) {
     int dev = 0, per_cu = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    if (dm_range_lds<D>() > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)decode_mfma_range_kernel<Tag, D>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            dm_range_lds<D>()) != hipSuccess)
+    if (dm_range_lds<D, KV8>() > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)decode_mfma_range_kernel<Tag, D, KV8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            dm_range_lds<D, KV8>()) != hipSuccess)
       return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_mfma_range_kernel<Tag, D>, 256, dm_range_lds<D>()) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_mfma_range_kernel<Tag, D, KV8>, 256, dm_range_lds<D, KV8>()) !=
             hipSuccess || per_cu < 1)
       return 0;
-    workgroups = (per_cu < 2 ? per_cu : 2) * prop.multiProcessorCount;
+    const int want = KV8 ? 3 : 2;
+    workgroups = (per_cu < want ? per_cu : want) * prop.multiProcessorCount;
   }
   return workgroups;
 }
 
 int decode_mfma_ranges(int num_q_heads, int num_kv_heads, int head_dim, int dtype, int kv8) {
-  if (kv8 || num_kv_heads % 4 || num_q_heads / num_kv_heads > 16 || (dtype != SP_BF16 && dtype != SP_F16)) return 0;
+  if (num_kv_heads % 4 || num_q_heads / num_kv_heads > 16 || (dtype != SP_BF16 && dtype != SP_F16)) return 0;
   int wgs = 0;
-  if (head_dim == 128) wgs = dtype == SP_BF16 ? dm_range_workgroups<bf16_tag, 128>() : dm_range_workgroups<f16_tag, 128>();
-  else if (head_dim == 64) wgs = dtype == SP_BF16 ? dm_range_workgroups<bf16_tag, 64>() : dm_range_workgroups<f16_tag, 64>();
+  auto of = [&](auto tag, auto dim) {
+    typedef decltype(tag) T;
+    constexpr int Dd = decltype(dim)::value;
+    return kv8 ? dm_range_workgroups<T, Dd, true>() : dm_range_workgroups<T, Dd, false>();
+  };
+  if (head_dim == 128) wgs = dtype == SP_BF16 ? of(bf16_tag{}, std::integral_constant<int, 128>{}) : of(f16_tag{}, std::integral_constant<int, 128>{});
+  else if (head_dim == 64) wgs = dtype == SP_BF16 ? of(bf16_tag{}, std::integral_constant<int, 64>{}) : of(f16_tag{}, std::integral_constant<int, 64>{});
   const int pieces = wgs / (num_kv_heads / 4);
   return pieces > 0 ? pieces : (wgs > 0 ? 1 : 0);
 }

@@ -137,6 +137,43 @@ def test_decode_over_fp8_pool(dtype, Hq, Hkv, D):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (64, 8, 128), (8, 8, 64)])
+def test_decode_range_geometry_over_fp8_pool(dtype, Hq, Hkv, D):
+    """the range kernel on a byte pool (ABI 8: one workgroup per (piece of the step's keys, four kv heads); e5m2 widened
+    on the way into the LDS tile, fp16 tile math): the oracle on the widened pool, for the piece count the library asks
+    for and for 1, 5 and 300 pieces; same bits launch after launch and on int64 index tensors; 2 units from the
+    (request, split) items of the same plan"""
+    from scratchpad_amd import _native
+    g = torch.Generator().manual_seed(Hq + D)
+    lens = [1400, 1025, 64, 65, 1, 2, 513] + torch.randint(1, 500, (29,), generator=g).tolist()
+    bs, chunk, max_len = len(lens), 64, 1400
+    p = _fp8_problem(73, bs, Hq, Hkv, D, lens, dtype)
+    scale = 1.0 / math.sqrt(D)
+    c = cpu(p)
+    ref = ops.decode_attention(c["q"].float(), c["k_buffer"], c["v_buffer"], c["req_to_token"],
+                               c["req_pool_indices"], c["seq_lens"], scale)
+    vmax = float(c["v_buffer"].view(torch.float8_e5m2).float().abs().max())
+    kb, vb = p["k_buffer"].view(torch.float8_e5m2), p["v_buffer"].view(torch.float8_e5m2)
+    auto = _native.decode_ranges(Hq, Hkv, D, dtype, kb.dtype)
+    assert auto > 0
+    outs = {}
+    for ranges in (0, 1, 5, auto, 300):
+        ws = torch.empty(_native.decode_workspace_bytes(bs, Hq, D, max_len, chunk, None, ranges), dtype=torch.uint8, device=DEV)
+        ws.fill_(0x7f)
+        plan = torch.empty(_native.decode_plan_bytes(bs, max_len, chunk, None, ranges) // 4, dtype=torch.int32, device=DEV)
+        for idt in (torch.int32, torch.int64, torch.int32):
+            _native.decode_plan(plan, p["seq_lens"].to(idt), max_len, chunk, None, ranges)
+            o = torch.full_like(p["q"], float("nan"))
+            _native.decode_attention(o, p["q"], kb, vb, p["req_to_token"], p["req_pool_indices"].to(idt),
+                                     p["seq_lens"].to(idt), scale, 0.0, max_len, chunk, ws, None, plan, ranges=ranges)
+            assert torch.equal(o, outs.setdefault(ranges, o)), (ranges, idt)
+        assert_close(outs[ranges], ref, dtype, what=f"fp8 range decode, {ranges} pieces", vmax=vmax)
+    u = {torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8}[dtype]
+    for ranges in (1, 5, auto, 300):
+        assert float((outs[ranges].float() - outs[0].float()).abs().max()) <= 2.5 * u * vmax, ranges
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (8, 1, 128), (8, 2, 64)])
 def test_extend_over_fp8_pool(dtype, Hq, Hkv, D):
     from scratchpad_amd import _native
