@@ -168,16 +168,18 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  * order, form one line (request b at pos[b] .. pos[b] + len_b, then 16 empty positions - what a request costs a
  * workgroup beyond its keys); the line is cut into rcount <= ranges equal pieces of R positions (R a multiple of 16,
  * at least 64) and start[j] is the first request with a key at or after j * R (-1: piece j holds none).  A launch
- * given the same `ranges` runs one workgroup per (piece, four kv heads): it walks its piece - the tail of one request,
- * whole requests, the head of another - so every workgroup gathers the same number of keys whatever the lengths are,
- * there is no split size to choose, and a request is written straight to the output unless a cut falls inside it.  A
- * request whose keys lie in pieces jf .. jl > jf leaves its partials in slots b + jf .. b + jl (b + j grows along the
- * line: no two (request, piece) pairs share a slot) and the merge launch combines them: the workspace then holds
- * batch_size + ranges slots, whatever sum(seq_lens) is - the overflow below cannot happen on this path.
- * sp_decode_ranges() is the piece count the library wants for a shape: two workgroups per CU, all resident at once, over the
- * head quads (two per CU: 256 pieces for 8 kv heads on MI355X), or 0 where the range kernel does not apply (fp32,
- * num_kv_heads % 4 != 0, groups wider than 16).  Launches it does not take (those shapes, a logit soft-cap, out rows
- * not 8-byte aligned, sp_debug_set("decode_ranges", 0)) use the plan's (request, split) items as before: a plan
+ * given the same `ranges` runs one WAVE per (piece, kv head) - with the kv heads in fours a workgroup is the four
+ * heads of one piece: each walks its piece - the tail of one request, whole requests, the head of another - so every
+ * wave gathers the same number of keys whatever the lengths are, there is no split size to choose, and a request is
+ * written straight to the output unless a cut falls inside it.  A request whose keys lie in pieces jf .. jl > jf leaves
+ * its partials in slots b + jf .. b + jl (b + j grows along the line: no two (request, piece) pairs share a slot) and
+ * the merge launch combines them: the workspace then holds batch_size + ranges slots, whatever sum(seq_lens) is - the
+ * overflow below cannot happen on this path.
+ * sp_decode_ranges() is the piece count the library wants for a shape: two workgroups per CU (three on a byte pool),
+ * all resident at once, four waves each, over the kv heads - 256 pieces for 8 kv heads on MI355X, 2048 for a
+ * tensor-parallel rank's single head - or 0 where the range kernel does not apply (fp32, groups wider than 16, head
+ * sizes other than 64 / 128).  Launches it does not take (those shapes, a logit soft-cap, out rows not 8-byte aligned,
+ * sp_debug_set("decode_ranges", 0)) use the plan's (request, split) items as before: a plan
  * always carries both.  Requires batch_size * (max_seq_len + 16) < 2^31 (else SP_ERR_INVALID_ARG from sp_decode_plan;
  * pass ranges = 0).  Results of the two geometries differ in the last bits (another split of the same sums).
  *

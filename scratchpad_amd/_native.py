@@ -371,8 +371,8 @@ RANGE_REQUEST_COST = 16        # positions a request takes on the line beyond it
 
 
 def decode_ranges(Hq: int, Hkv: int, D: int, dtype: torch.dtype, kv_dtype: Optional[torch.dtype] = None) -> int:
-    """Pieces per head quad the range kernel wants for this shape (sp_decode_ranges): two workgroups per CU over the
-    head quads; 0 where the range geometry does not apply (fp32, Hkv % 4 != 0, G > 16, D not 64 / 128)."""
+    """Pieces the range kernel wants for this shape (sp_decode_ranges): two workgroups per CU (three on a byte pool) over the
+    kv heads, a wave per (piece, head); 0 where the range geometry does not apply (fp32, G > 16, D not 64 / 128)."""
     dt = _DTYPES.get(dtype)
     if dt is None:
         return 0

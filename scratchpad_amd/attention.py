@@ -147,9 +147,9 @@ class HipAttnBackend(AttentionBackend):
         self._plan_checks = []         # (pinned header copy, event, max_slots) of plans not yet checked
         self._plan_hosts = []          # pinned buffers + events to reuse
         self._plan_lock = threading.Lock()   # the overlap worker checks from the scheduler thread (tp_worker_client.py)
-        # Range geometry (include/scratchpad_hip.h, ABI 8): the pieces the step's keys are cut into, one workgroup per
-        # (piece, four kv heads), two per CU; 0 where the range kernel does not take the shape (fp32, kv heads not in
-        # fours), and those launches use the plan's (request, split) items below.
+        # Range geometry (include/scratchpad_hip.h, ABI 8): the pieces the step's keys are cut into, one wave per (piece,
+        # kv head), two workgroups per CU; 0 where the range kernel does not take the shape (fp32, groups wider than
+        # 16), and those launches use the plan's (request, split) items below.
         # SP_DECODE_RANGES=0 switches it off, =N forces N pieces (A/B runs).
         env = os.environ.get("SP_DECODE_RANGES", "")
         self.decode_ranges = int(env) if env else _native.decode_ranges(

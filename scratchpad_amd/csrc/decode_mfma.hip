@@ -437,11 +437,11 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// RANGE form of the head-per-wave kernel (round 5): launches of the default configuration (16-bit pool, non-temporal
+// RANGE kernel (round 5): launches of the default configuration (16-bit or e5m2 byte pool, non-temporal
 // gathers, no soft-cap) whose plan carries the range geometry (DecodeArgs::rplan).  The step's keys form one line,
-// request after request; the plan cuts it into as many equal pieces as the chip holds workgroups per head quad, and
-// workgroup (piece j, head quad) walks piece j: the tail of the request the piece starts in, whole requests, the head
-// of the request it ends in.  Every workgroup gathers the same number of keys - whatever the lengths are, there is no
+// request after request; the plan cuts it into equal pieces - as many as two workgroups per CU have waves per kv head -
+// and wave (piece j, kv head) walks piece j: the tail of the request the piece starts in, whole requests, the head
+// of the request it ends in.  Every wave gathers the same number of keys - whatever the lengths are, there is no
 // split size to choose and no list of items to deal out - and they all finish together.
 //
 // What that buys, measured on the (request, split) items of this same kernel (profiles/r05_decode_split_cost.txt):
@@ -467,10 +467,15 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_range_kernel(De
   constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK, TILE_B = C::TILE_B;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int hgroups = a.Hkv / 4;
-  const int piece = (int)blockIdx.x / hgroups;              // the head quads of one piece are adjacent in launch order
-  const int hk = ((int)blockIdx.x - piece * hgroups) * 4 + wave;
+  // wave -> (piece, kv head): the heads of one piece are adjacent in launch order.  With the kv heads in fours a
+  // workgroup is the four heads of ONE piece - its waves walk the same requests and read whole 1 KiB token half-rows
+  // between them; with fewer (a tensor-parallel rank's one or two heads) its waves walk different pieces.  Nothing
+  // here depends on which: the waves share nothing.
+  const int gw = (int)blockIdx.x * 4 + wave;
+  const int piece = gw / a.Hkv;
+  const int hk = gw - piece * a.Hkv;
   const int32_t* rp = a.rplan;
+  if (piece >= a.ranges) return;                            // (the launch's last workgroup when ranges * Hkv is not in fours)
   if (piece >= rp[0]) return;
   const int R = rp[1];
   const int32_t* posv = rp + kRangeHdr;
@@ -741,9 +746,10 @@ template <typename Tag, int D, bool KV8>
 static int launch_dm_kv(const DecodeArgs& a, hipStream_t st) {
   typedef DmCfg<D> C;
   const bool hpw = a.Hkv % 4 == 0 && a.o_stride % 4 == 0;
-  if (a.rplan) {                                  // the range geometry: one workgroup per (piece, head quad)
-    if (!hpw || a.ranges <= 0 || a.logit_cap > 0.f || a.nt_min_keys != 0) return SP_ERR_INVALID_ARG;
-    decode_mfma_range_kernel<Tag, D, KV8><<<dim3((unsigned)a.ranges * (a.Hkv / 4)), 256, dm_range_lds<D, KV8>(), st>>>(a);
+  if (a.rplan) {                                  // the range geometry: one wave per (piece, kv head)
+    if (a.o_stride % 4 || a.ranges <= 0 || a.logit_cap > 0.f || a.nt_min_keys != 0) return SP_ERR_INVALID_ARG;
+    const unsigned grid = (unsigned)(((int64_t)a.ranges * a.Hkv + 3) / 4);
+    decode_mfma_range_kernel<Tag, D, KV8><<<dim3(grid), 256, dm_range_lds<D, KV8>(), st>>>(a);
     SP_LAUNCH_CHECK();
     return SP_OK;
   }
@@ -781,12 +787,12 @@ int run_decode_mfma(const DecodeArgs& a, int head_dim, int dtype, hipStream_t st
   return SP_ERR_UNSUPPORTED;
 }
 
-// Pieces per head quad the range kernel wants: TWO workgroups per CU (three on a byte pool) over the head quads - all
-// resident at once (the runtime is asked, once per instantiation), every one the same length.  Measured on MI355X, bs 256, contexts
+// Pieces the range kernel wants: TWO workgroups per CU (three on a byte pool), four waves each, over the kv heads - all
+// resident at once (the runtime is asked, once per instantiation), every wave's piece the same length.  Measured on MI355X, bs 256, contexts
 // U[128, 4096] (profiles/r05_decode_range.txt): 1 / 2 / 3 workgroups per CU 340.7 / 339.7 / 348.1 us, two rounds of
 // shorter pieces 366 - 392: a piece pays its start, its cut requests' partials and its tail once, so few long streams
 // beat many short ones as soon as they keep HBM busy, and 8 waves per CU with one 8 KiB tile in flight each do
-// (6.6 TB/s).  0: the shape is not the range kernel's (a 16-bit pool with Hkv % 4 == 0, G <= 16, D in {64, 128}).
+// (6.6 TB/s).  0: the shape is not the range kernel's (16-bit q, G <= 16, D in {64, 128}).
 template <typename Tag, int D, bool KV8>
 static int dm_range_workgroups() {
   static int workgroups = 0;
@@ -808,7 +814,7 @@ static int dm_range_workgroups() {
 }
 
 int decode_mfma_ranges(int num_q_heads, int num_kv_heads, int head_dim, int dtype, int kv8) {
-  if (num_kv_heads % 4 || num_q_heads / num_kv_heads > 16 || (dtype != SP_BF16 && dtype != SP_F16)) return 0;
+  if (num_q_heads / num_kv_heads > 16 || (dtype != SP_BF16 && dtype != SP_F16)) return 0;
   int wgs = 0;
   auto of = [&](auto tag, auto dim) {
     typedef decltype(tag) T;
@@ -817,7 +823,7 @@ int decode_mfma_ranges(int num_q_heads, int num_kv_heads, int head_dim, int dtyp
   };
   if (head_dim == 128) wgs = dtype == SP_BF16 ? of(bf16_tag{}, std::integral_constant<int, 128>{}) : of(f16_tag{}, std::integral_constant<int, 128>{});
   else if (head_dim == 64) wgs = dtype == SP_BF16 ? of(bf16_tag{}, std::integral_constant<int, 64>{}) : of(f16_tag{}, std::integral_constant<int, 64>{});
-  const int pieces = wgs / (num_kv_heads / 4);
+  const int pieces = wgs * 4 / num_kv_heads;                 // a wave per (piece, kv head)
   return pieces > 0 ? pieces : (wgs > 0 ? 1 : 0);
 }
 

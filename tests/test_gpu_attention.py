@@ -869,13 +869,15 @@ def test_decode_range_plan_equals_a_host_recount(nat, ranges, idx_dtype):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (64, 8, 128), (64, 4, 128), (8, 8, 128), (16, 4, 64), (24, 4, 64)])
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (64, 8, 128), (64, 4, 128), (8, 8, 128), (16, 4, 64), (24, 4, 64),
+                                      (8, 1, 128), (10, 2, 128), (18, 6, 64)])
 def test_decode_range_geometry(nat, dt, Hq, Hkv, D):
-    """The range kernel (decode_mfma.hip, round 5: one workgroup per (piece of the step's keys, four kv heads); a request
-    cut by a piece boundary leaves partials in slots request + piece, parked in LDS until the piece is done) against
-    the oracle, for 1, 3, 40 and 1000 pieces and the count sp_decode_ranges() asks for: requests of 1400 and 1025 keys
-    cut many times, pieces holding dozens of short requests, one-key and empty rows, groups of 4 and 6 (two partials
-    parked per wave), 8 (one), 1 (seven), 16 (none: stored at once).  Per piece count the bits are the same on int32
+    """The range kernel (decode_mfma.hip, round 5: one wave per (piece of the step's keys, kv head); a request cut by a
+    piece boundary leaves partials in slots request + piece, parked in LDS until the piece is done) against the oracle,
+    for 1, 3, 40 and 1000 pieces and the count sp_decode_ranges() asks for: requests of 1400 and 1025 keys cut many
+    times, pieces holding dozens of short requests, one-key and empty rows, groups of 1 to 16 (four to one partials
+    parked per wave), kv heads in fours (a workgroup = the four heads of one piece) and not (its waves walk different
+    pieces; 1 x 10 waves leave the last workgroup half empty).  Per piece count the bits are the same on int32
     and int64 index tensors, launch after launch on one plan, over a workspace full of stale partials; behind a kv_start
     window.  sp_debug_set("decode_ranges", 0) sends the same call to the plan's (request, split) items: the bits of a
     plan without ranges."""
@@ -890,7 +892,7 @@ def test_decode_range_geometry(nat, dt, Hq, Hkv, D):
     q, req = p["q"], p["req_pool_indices"]
     seq = lens.to(DEV)
     auto = nat.decode_ranges(Hq, Hkv, D, dtype)
-    assert auto > 0 and auto * (Hkv // 4) >= 256, "the range kernel takes these shapes: about a workgroup per resident slot"
+    assert auto > 0 and auto * Hkv >= 4 * 256, "the range kernel takes these shapes: at least a workgroup per CU"
     slots = nat.decode_plan_slots(bs, max_len, chunk, kv_tokens=int(lens.sum()))
     c = cpu(p)
     fn = lambda v: ops.decode_attention(c["q"].float(), c["k_buffer"].float(), v, c["req_to_token"],
@@ -927,19 +929,21 @@ def test_decode_range_geometry(nat, dt, Hq, Hkv, D):
 
 
 def test_decode_ranges_where_the_range_kernel_does_not_apply(nat):
-    """sp_decode_ranges() is 0 for fp32 and kv heads not in fours; a launch of such a shape - or with a logit soft-cap -
-    that is handed a plan with ranges uses the plan's (request, split) items: the bits of a plan without."""
+    """sp_decode_ranges() is 0 for fp32, groups wider than 16 and head sizes other than 64 / 128; an fp32 launch - or one
+    with a logit soft-cap - that is handed a plan with ranges uses the plan's (request, split) items: the bits of a plan
+    without."""
     # (two workgroups per CU on a 16-bit pool, three on a byte pool - a tile in flight is half the bytes there)
     assert 2 * nat.decode_ranges(32, 8, 128, torch.bfloat16, torch.uint8) == 3 * nat.decode_ranges(32, 8, 128, torch.bfloat16) > 0
     assert nat.decode_ranges(32, 8, 128, torch.float32) == 0
-    assert nat.decode_ranges(8, 1, 128, torch.bfloat16) == 0 and nat.decode_ranges(12, 6, 64, torch.float16) == 0
-    assert nat.decode_ranges(32, 8, 256, torch.bfloat16) == 0
+    assert nat.decode_ranges(32, 1, 128, torch.bfloat16) == 0 and nat.decode_ranges(32, 8, 256, torch.bfloat16) == 0
+    # a wave per (piece, kv head): the fewer heads, the more pieces
     assert nat.decode_ranges(32, 8, 128, torch.bfloat16) == 2 * nat.decode_ranges(64, 16, 128, torch.bfloat16)
+    assert nat.decode_ranges(8, 1, 128, torch.bfloat16) == 8 * nat.decode_ranges(32, 8, 128, torch.bfloat16)
     bs, chunk, max_len = 24, 64, 700
     g = torch.Generator().manual_seed(3)
     lens = torch.randint(1, 700, (bs,), generator=g)
-    for Hq, Hkv, cap in ((8, 1, 0.0), (32, 8, 30.0)):
-        p = paged_problem(900 + Hq, bs, Hq, Hkv, 128, lens.tolist(), torch.bfloat16, DEV)
+    for Hq, Hkv, cap, dtype in ((8, 2, 0.0, torch.float32), (32, 8, 30.0, torch.bfloat16)):
+        p = paged_problem(900 + Hq, bs, Hq, Hkv, 128, lens.tolist(), dtype, DEV)
         slots = nat.decode_plan_slots(bs, max_len, chunk, kv_tokens=int(lens.sum()))
         outs = []
         for ranges in (0, 96):
@@ -951,7 +955,7 @@ def test_decode_ranges_where_the_range_kernel_does_not_apply(nat):
                                  p["seq_lens"], 0.09, cap, max_len, chunk, ws, None, plan, max_slots=slots, ranges=ranges)
             outs.append(o)
         assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1]), (Hq, Hkv, cap)
-        check_decode(outs[1], p, 0.09, torch.bfloat16, f"items behind a range plan Hq{Hq} Hkv{Hkv} cap{cap}", cap=cap)
+        check_decode(outs[1], p, 0.09, dtype, f"items behind a range plan Hq{Hq} Hkv{Hkv} cap{cap}", cap=cap)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])

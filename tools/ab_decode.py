@@ -28,7 +28,9 @@ SHAPES = {"headline": (256, 32, 8, "128:4096"), "hkv1": (128, 8, 1, "128:4096"),
           "bs64": (64, 32, 8, "128:4096"), "bs8": (8, 32, 8, "1024"), "bs1": (1, 32, 8, "1024"),
           "ctx1024": (256, 32, 8, "1024"), "ctx4096": (256, 32, 8, "4096"),
           # uniform contexts that deal out evenly over 768 resident workgroups at split size 768 (2 and 3 units each)
-          "ctx2304": (256, 32, 8, "2304"), "ctx3456": (256, 32, 8, "3456")}
+          "ctx2304": (256, 32, 8, "2304"), "ctx3456": (256, 32, 8, "3456"),
+          # a tensor-parallel rank's one or two kv heads at larger batches
+          "hkv1_bs256": (256, 8, 1, "128:4096"), "hkv1_ctx4096": (256, 8, 1, "4096"), "hkv2": (256, 16, 2, "128:4096")}
 
 
 def load_native(libspec, tag):
