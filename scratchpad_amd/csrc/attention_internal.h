@@ -41,13 +41,13 @@ struct DecodeArgs {
   // RANGE geometry (the plan's second section, sp_decode_plan with ranges > 0; decode_mfma.hip's range kernel):
   // [rcount, R, 0, 0 | pos[bs + 1] | start[ranges]].  The step's keys, request after request in batch order, form one
   // line on which request b takes pos[b] .. pos[b] + len_b and then kRangeReqCost empty positions (what a request costs
-  // a workgroup beyond its keys); the line is cut into rcount <= ranges pieces of R positions, piece j is the work of
-  // one workgroup per head quad, start[j] = the first request with a key at or after position j * R, or -1 if piece j
+  // a wave beyond its keys); the line is cut into rcount <= ranges pieces of R positions, piece j is the work of
+  // one wave per kv head, start[j] = the first request with a key at or after position j * R, or -1 if piece j
   // holds none.  A request whose keys lie in pieces jf .. jl > jf leaves jl - jf + 1 partials in slots b + jf .. b + jl
   // (b + j grows along the line, so no two (request, piece) pairs share a slot and bs + ranges slots always suffice),
   // a request inside one piece is written straight to the output.  Null: the launch uses the (request, split) items.
   const int32_t* rplan;
-  int ranges;    // pieces the range section was sized for = workgroups per head quad of a range launch
+  int ranges;    // pieces the range section was sized for = waves per kv head of a range launch
 };
 
 static constexpr int kPlanHdr = 4;   // int32 words in front of slot0[]
@@ -162,7 +162,7 @@ int decode_heads_per_load_shift(int num_kv_heads, int head_dim, int dtype, int* 
 void set_decode_kernel(int which);
 void set_decode_nt_min_mb(int mb);
 void set_decode_ranges(int n);
-// decode_mfma.hip: pieces per head quad the range kernel wants for this shape (0: it does not take the shape)
+// decode_mfma.hip: pieces the range kernel wants for this shape (0: it does not take the shape)
 int decode_mfma_ranges(int num_q_heads, int num_kv_heads, int head_dim, int dtype, int kv8);
 
 }  // namespace sp

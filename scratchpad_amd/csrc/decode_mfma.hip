@@ -21,6 +21,10 @@
 //     factor of O^T is lane-local;
 //   * the 4 waves' (m, l, O) are merged through LDS (the tile area is reused), split partials go to
 //     the same workspace / merge kernel as the VALU path.
+//
+// Two kernels share this tile arithmetic.  decode_mfma_kernel runs one workgroup per (request, split) item - the
+// plan's item list or the plan-less static grid; decode_mfma_range_kernel (below, round 5) runs one wave per (equal
+// piece of the step's keys, kv head) and is what planned launches of the default configuration take.
 #include <type_traits>
 
 #include "attention_internal.h"
