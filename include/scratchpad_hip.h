@@ -176,7 +176,7 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  * the merge launch combines them: the workspace then holds batch_size + ranges slots, whatever sum(seq_lens) is - the
  * overflow below cannot happen on this path.
  * sp_decode_ranges() is the piece count the library wants for a shape: two workgroups per CU (three on a byte pool),
- * all resident at once, four waves each, over the kv heads - 256 pieces for 8 kv heads on MI355X, 2048 for a
+ * all resident at once, four waves each, over the kv heads (at most 1024) - 256 pieces for 8 kv heads on MI355X, 1024 for a
  * tensor-parallel rank's single head - or 0 where the range kernel does not apply (fp32, groups wider than 16, head
  * sizes other than 64 / 128).  Launches it does not take (those shapes, a logit soft-cap, out rows not 8-byte aligned,
  * sp_debug_set("decode_ranges", 0)) use the plan's (request, split) items as before: a plan

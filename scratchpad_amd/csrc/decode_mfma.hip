@@ -827,8 +827,10 @@ int decode_mfma_ranges(int num_q_heads, int num_kv_heads, int head_dim, int dtyp
   };
   if (head_dim == 128) wgs = dtype == SP_BF16 ? of(bf16_tag{}, std::integral_constant<int, 128>{}) : of(f16_tag{}, std::integral_constant<int, 128>{});
   else if (head_dim == 64) wgs = dtype == SP_BF16 ? of(bf16_tag{}, std::integral_constant<int, 64>{}) : of(f16_tag{}, std::integral_constant<int, 64>{});
-  const int pieces = wgs * 4 / num_kv_heads;                 // a wave per (piece, kv head)
-  return pieces > 0 ? pieces : (wgs > 0 ? 1 : 0);
+  // a wave per (piece, kv head); at most 1024 pieces - a rank's single head: its pieces are short already, and every cut
+  // costs a partial (bs 128, one head: 2048 / 1024 pieces 32.9 / 31.5 us, traffic 1.10 x the algorithmic bytes at 2048)
+  const int pieces = wgs * 4 / num_kv_heads;
+  return pieces > 1024 ? 1024 : pieces > 0 ? pieces : (wgs > 0 ? 1 : 0);
 }
 
 }  // namespace sp

@@ -938,7 +938,8 @@ def test_decode_ranges_where_the_range_kernel_does_not_apply(nat):
     assert nat.decode_ranges(32, 1, 128, torch.bfloat16) == 0 and nat.decode_ranges(32, 8, 256, torch.bfloat16) == 0
     # a wave per (piece, kv head): the fewer heads, the more pieces
     assert nat.decode_ranges(32, 8, 128, torch.bfloat16) == 2 * nat.decode_ranges(64, 16, 128, torch.bfloat16)
-    assert nat.decode_ranges(8, 1, 128, torch.bfloat16) == 8 * nat.decode_ranges(32, 8, 128, torch.bfloat16)
+    assert nat.decode_ranges(16, 2, 128, torch.bfloat16) == 4 * nat.decode_ranges(32, 8, 128, torch.bfloat16)
+    assert nat.decode_ranges(8, 1, 128, torch.bfloat16) == 1024          # (capped: a single head's pieces are short already)
     bs, chunk, max_len = 24, 64, 700
     g = torch.Generator().manual_seed(3)
     lens = torch.randint(1, 700, (bs,), generator=g)
