@@ -166,8 +166,8 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  * Range geometry (ABI 8).  A plan built with `ranges` > 0 carries a second section,
  * [rcount, R, 0, 0 | pos[bs + 1] | start[ranges]], behind the items: the step's keys, request after request in batch
  * order, form one line (request b at pos[b] .. pos[b] + len_b, then 16 empty positions - what a request costs a
- * workgroup beyond its keys); the line is cut into rcount <= ranges equal pieces of R positions (R a multiple of 16,
- * at least 64) and start[j] is the first request with a key at or after j * R (-1: piece j holds none).  A launch
+ * workgroup beyond its keys); the line is cut into rcount <= ranges equal pieces of R = ceil(length / ranges) positions
+ * (at least 64) and start[j] is the first request with a key at or after j * R (-1: piece j holds none).  A launch
  * given the same `ranges` runs one WAVE per (piece, kv head) - with the kv heads in fours a workgroup is the four
  * heads of one piece: each walks its piece - the tail of one request, whole requests, the head of another - so every
  * wave gathers the same number of keys whatever the lengths are, there is no split size to choose, and a request is

@@ -412,7 +412,9 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ 
     __syncthreads();
   }
   const int T = s_base;                               // (< 2^31: the host checks bs * (max_len + cost))
-  const int R = max(kRangeMin, (int)((((int64_t)T + ranges - 1) / ranges + 15) & ~15LL));
+  // (not rounded to the tile: a batch of equal lengths whose size is a multiple of the piece count - decode steps of a
+  // full graph bucket - then has its cuts exactly between requests: no partials at all)
+  const int R = max(kRangeMin, (int)(((int64_t)T + ranges - 1) / ranges));
   const int rcount = T > 0 ? (T + R - 1) / R : 0;
   if (threadIdx.x == 0) {
     pos[bs] = T;

@@ -823,7 +823,7 @@ def range_plan_on_host(lens, max_len, ranges):
     for l in lens:
         pos.append(pos[-1] + (l + cost if l > 0 else 0))
     T = pos[-1]
-    R = max(64, ((T + ranges - 1) // ranges + 15) // 16 * 16)
+    R = max(64, (T + ranges - 1) // ranges)
     rcount = (T + R - 1) // R if T > 0 else 0
     start = []
     for j in range(ranges):
@@ -865,7 +865,7 @@ def test_decode_range_plan_equals_a_host_recount(nat, ranges, idx_dtype):
     assert rp[:4] == [rcount, R, 0, 0]
     assert rp[4:4 + bs + 1] == pos
     assert rp[4 + bs + 1:] == start
-    assert rcount <= ranges and R % 16 == 0 and (rcount - 1) * R < pos[-1] <= rcount * R
+    assert rcount <= ranges and (rcount - 1) * R < pos[-1] <= rcount * R
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
