@@ -13,7 +13,10 @@ The shipped rule (attention.py:_plan_chunk: power-of-two floor of sum * groups /
 with the best candidate split size.
 
   python tools/sim_decode_split.py            # the headline batch and the other bench shapes, seed 0
-No GPU involved.  The numbers this printed in round 5 are in profiles/NOTES.md."""
+No GPU involved.  The numbers this printed in round 5 are in profiles/NOTES.md.
+(This models the (request, split) ITEM geometry.  Since the second half of round 5 a decode step of the default configuration runs
+the range geometry - equal pieces of the step's keys, no split size to choose - and the items only serve soft-cap / fp32 / plan-less
+launches: profiles/r05_decode_range.txt.)"""
 import argparse
 import heapq
 
