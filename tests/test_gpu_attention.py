@@ -928,6 +928,62 @@ def test_decode_range_geometry(nat, dt, Hq, Hkv, D):
         nat.debug_set("decode_ranges", -1)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_decode_range_geometry_fuzz(nat, seed):
+    """Randomised steps through the range kernel against the oracle: batch sizes 1 .. 300, head shapes with the kv heads in
+    fours and not, both head sizes and 16-bit dtypes, length mixes (uniform - cuts exactly between requests, ragged, mostly
+    tiny, a few very long, many empty), piece counts from 1 to several times the batch size (pieces with no key at all,
+    pieces of the minimum length, one piece for everything), int32 / int64 index tensors, a kv_start window; and the plan's
+    range section against the host recount on every draw."""
+    g = torch.Generator().manual_seed(4000 + seed)
+    r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    Hq, Hkv, D = [(32, 8, 128), (8, 1, 128), (16, 4, 64), (12, 2, 128), (64, 8, 128), (6, 3, 64)][seed]
+    dtype = (torch.bfloat16, torch.float16)[seed % 2]
+    for draw in range(4):
+        bs = [r(1, 6), r(20, 60), r(100, 300), r(8, 40)][draw]
+        kind = (seed + draw) % 5
+        if kind == 0:
+            lens = torch.full((bs,), r(1, 400))
+        elif kind == 1:
+            lens = torch.randint(1, 700, (bs,), generator=g)
+        elif kind == 2:
+            lens = torch.randint(1, 6, (bs,), generator=g)
+            lens[r(0, bs - 1)] = r(300, 900)
+        elif kind == 3:
+            lens = torch.randint(0, 3, (bs,), generator=g) * torch.randint(1, 200, (bs,), generator=g)
+            lens[r(0, bs - 1)] = r(1, 50)
+        else:
+            lens = torch.randint(1, 80, (bs,), generator=g)
+            lens[: max(1, bs // 8)] = torch.randint(500, 1500, (max(1, bs // 8),), generator=g)
+        max_len, chunk = int(lens.max()), 64
+        ranges = [1, r(2, 9), r(10, 3 * bs + 10), nat.decode_ranges(Hq, Hkv, D, dtype)][(seed + draw) % 4]
+        start = torch.randint(0, 3, (bs,), generator=g)
+        p = paged_problem(5000 + 10 * seed + draw, bs, Hq, Hkv, D, [int(l) + 3 for l in lens], dtype, DEV)
+        idt = (torch.int32, torch.int64)[draw % 2]
+        seq, req, k0 = lens.to(idt).to(DEV), p["req_pool_indices"].to(idt), start.to(idt).to(DEV)
+        slots = nat.decode_plan_slots(bs, max_len, chunk, kv_tokens=int(lens.sum()))
+        ws = torch.empty(nat.decode_workspace_bytes(bs, Hq, D, max_len, chunk, slots, ranges), dtype=torch.uint8, device=DEV)
+        ws.fill_(0x7f)
+        plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, slots, ranges) // 4, dtype=torch.int32, device=DEV)
+        nat.decode_plan(plan, seq, max_len, chunk, slots, ranges)
+        rcount, R, pos, first = range_plan_on_host(lens.tolist(), max_len, ranges)
+        rp = plan.cpu()[4 + bs + 2 * slots:].tolist()
+        what = f"fuzz seed {seed} draw {draw}: bs {bs} Hq{Hq} Hkv{Hkv} D{D} kind {kind} ranges {ranges} R {R} pieces {rcount}"
+        assert rp[:2] == [rcount, R] and rp[4:4 + bs + 1] == pos and rp[4 + bs + 1:] == first, what
+        o = torch.zeros_like(p["q"])
+        nat.decode_attention(o, p["q"], p["k_buffer"], p["v_buffer"], p["req_to_token"], req, seq, D ** -0.5, 0.0,
+                             max_len, chunk, ws, k0, plan, max_slots=slots, ranges=ranges)
+        assert torch.isfinite(o.float()).all(), what
+        c = cpu(p)
+        fn = lambda v: ops.decode_attention(c["q"].float(), c["k_buffer"].float(), v, c["req_to_token"],
+                                            c["req_pool_indices"], lens, D ** -0.5, 0.0, start)
+        live = [i for i in range(bs) if int(lens[i]) > 0]
+        dead = [i for i in range(bs) if int(lens[i]) == 0]
+        check_vs_oracle(o, dtype, what, c["v_buffer"].float(), fn, rows=live)
+        if dead:
+            assert float(o[dead].float().abs().max()) == 0.0, what + ": empty rows stay untouched"
+
+
 def test_decode_ranges_where_the_range_kernel_does_not_apply(nat):
     """sp_decode_ranges() is 0 for fp32, groups wider than 16 and head sizes other than 64 / 128; an fp32 launch - or one
     with a logit soft-cap - that is handed a plan with ranges uses the plan's (request, split) items: the bits of a plan
