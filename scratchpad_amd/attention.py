@@ -216,7 +216,7 @@ class HipAttnBackend(AttentionBackend):
         """pieces of the range geometry for a step (0: its line does not fit the plan's int32 positions)"""
         return self.decode_ranges if bs * (max_len + _native.RANGE_REQUEST_COST) < 2 ** 31 - 1 else 0
 
-    def _build_plans(self, plans, bs, windows, max_len, max_slots=None, hints=(None, None, None)):
+    def _build_plans(self, plans, bs, windows, max_len, max_slots=None, hints=(None, None, None), ranges=None):
         """One split plan per kv window (self-attention lens; encoder lens for cross-attention - the
         reference keeps two flashinfer wrappers for the same reason, flashinfer_backend.py:121-131; the
         sliding-window layers' lens).  windows: per plan (lens tensor or None, host bound on their sum).
@@ -224,7 +224,8 @@ class HipAttnBackend(AttentionBackend):
         per plan (tensor, max_slots, smallest chunk, ranges) and the largest max_slots (what the workspace must hold).
         Every plan also carries the range geometry (`ranges` pieces) where the backend's shape has one."""
         out, need_slots = [], 1
-        ranges = self._ranges_for(bs, max_len)
+        if ranges is None:
+            ranges = self._ranges_for(bs, max_len)
         for i, (lens, kv_tokens) in enumerate(windows):
             if lens is None:
                 out.append(None)
@@ -352,7 +353,8 @@ class HipAttnBackend(AttentionBackend):
                                                                     self.cuda_graph_max_seq_len, self.MIN_CHUNK, slots,
                                                                     self._ranges_for(max_bs, self.cuda_graph_max_seq_len)),
                                      dtype=torch.uint8, device=self.device)
-        ranges = self._ranges_for(max_bs, self.cuda_graph_max_seq_len)
+        # the piece count is launch geometry: ONE value for every bucket, decided for the largest (a smaller bucket's line fits too)
+        self._graph_ranges = ranges = self._ranges_for(max_bs, self.cuda_graph_max_seq_len)
         n = _native.decode_plan_bytes(max_bs, self.cuda_graph_max_seq_len, self.MIN_CHUNK, slots, ranges) // 4
         self._graph_plans = [torch.empty(n, dtype=torch.int32, device=self.device) for _ in range(3)]
         self._graph_max_bs = max_bs
@@ -368,7 +370,8 @@ class HipAttnBackend(AttentionBackend):
         assert bs <= self._graph_max_bs
         plans, _ = self._build_plans(self._graph_plans, bs, self._windows(bs, seq_lens, seq_lens_sum, encoder_lens,
                                                                           None),
-                                     self.cuda_graph_max_seq_len, self._graph_slots(bs), hints=(max_hint, None, None))
+                                     self.cuda_graph_max_seq_len, self._graph_slots(bs), hints=(max_hint, None, None),
+                                     ranges=self._graph_ranges)
         # MIN_CHUNK: the smallest split size a replayed plan may carry (the merge launch is always captured)
         self.forward_metadata = (self.MIN_CHUNK, self.cuda_graph_max_seq_len, self._graph_ws, plans)
 
