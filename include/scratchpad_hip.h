@@ -57,7 +57,9 @@ SP_API const char* sp_status_string(int status);
  * unit drawing the plan's items by ticket: 1 = where it pays, i.e. a plan with at least 32 items per
  * workgroup and row blocks of at most ~32 tiles, the default; 2 = every planned launch the kernel applies to;
  * 0 = never; without it mode 1 of "extend_w64" means mean extend length >= 768 or a cached prefix >= 1024
- * tokens; the two forms agree bit for bit), "ar_fused_blocks", "skinny_nt".  Nothing on the call path reads the environment.  Returns
+ * tokens; the two forms agree bit for bit), "decode_ranges" (0 = decode launches never take the range geometry of
+ * their plan: the (request, split) items everywhere; -1 = the default, wherever the range kernel applies),
+ * "decode_nt_min_mb" (see sp_decode_attention), "ar_fused_blocks", "skinny_nt".  Nothing on the call path reads the environment.  Returns
  * SP_ERR_INVALID_ARG for an unknown key.                                                          */
 SP_API int sp_debug_set(const char* key, int value);
 /* Read-only counterpart (ABI 6): "w64_descriptor_patched" (1 = extend_w64.hip was built in stages with its kernels'
