@@ -92,12 +92,13 @@ __device__ __forceinline__ bool decode_item(const DecodeArgs& a, int item, int& 
 // and merged online across groups of 16 (every product-sum is an explicit fma).
 // Partials are laid out [Hq][slot][D]: a request's splits are consecutive slots, so one (request, head)'s partials
 // are one contiguous run (with [slot][Hq][D] the merge read 512-byte pieces 16 KiB apart: 10.5 us instead of 6.8).
-template <typename Tag, int D, int U>
+// GRP = partials loaded per round trip: 16, or 4 for the requests of at most four partials (most of a range launch's: a
+// piece cuts a request once or twice) - the same arithmetic on the live partials in the same order, a quarter of the loads.
+template <typename Tag, int D, int U, int GRP = 16>
 __device__ __forceinline__ void decode_merge_rows(const DecodeArgs& a, int b, const int (&h)[U], int lane,
                                                   int nsplit, int slot0) {
   typedef Elem<Tag> E;
   constexpr int PER = D / 64;
-  constexpr int GRP = 16;
   constexpr float kFloor = -1.0e30f;
   const float* lse[U];
   const float* po[U];

@@ -300,7 +300,8 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
     range_request(a.rplan, b, len, nsplit, slot0);
     if (len <= 0 || nsplit <= 1) return;
     const int hs[1] = {h};
-    decode_merge_rows<Tag, D, 1>(a, b, hs, lane, nsplit, slot0);
+    if (nsplit <= 4) decode_merge_rows<Tag, D, 1, 4>(a, b, hs, lane, nsplit, slot0);
+    else decode_merge_rows<Tag, D, 1>(a, b, hs, lane, nsplit, slot0);
     return;
   }
   const int seq = min((int)load_idx(a.seq_lens, b, a.idx64), a.max_len);
@@ -311,7 +312,8 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
   nsplit = min(nsplit, a.max_slots - slot0);   // never past the workspace (a plan cut short by a broken bound)
   if (nsplit < 1) return;
   const int hs[1] = {h};
-  decode_merge_rows<Tag, D, 1>(a, b, hs, lane, nsplit, slot0);
+  if (nsplit <= 4) decode_merge_rows<Tag, D, 1, 4>(a, b, hs, lane, nsplit, slot0);
+  else decode_merge_rows<Tag, D, 1>(a, b, hs, lane, nsplit, slot0);
 }
 
 // Build the step's split plan: plan[0] = number of non-empty (request, split) items the plan lists, plan[1] = chunk,

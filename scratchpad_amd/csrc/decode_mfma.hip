@@ -121,15 +121,193 @@ static constexpr int kDmParkWaveB = 2 * (8 * 128 * 4 + 64 + 16);
 // G = 8, none (stored at once) at G = 16; 49 KiB per workgroup at D = 128
 static constexpr int kDmParkWaveB8 = 2 * (4 * 128 * 4 + 64 + 16);
 
+// The state and the tile arithmetic of ONE wave, shared by the two kernels below: the gather of a 16-key tile into
+// registers, its image in the wave-private LDS tile, S^T = K.Q^T, the online softmax of the wave's G columns, O^T += V^T.P^T,
+// and the two ways a result leaves the wave.  KV8: the pool holds fp8 e5m2 bytes - a lane gathers 8 bytes instead of 16,
+// expands them to 8 halves on the way into the LDS tile (e5m2 is the top byte of a half: one v_perm_b32 per two elements,
+// exact), and the tile math runs in fp16 whatever the model dtype is (bf16 q is converted once per request; P is rounded to
+// fp16); the output keeps the model dtype.  HBM bytes per context token halve; everything after the LDS tile is unchanged.
+template <typename Tag, int D, bool KV8>
+struct DmWave {
+  typedef DmCfg<D> C;
+  typedef typename std::conditional<KV8, f16_tag, Tag>::type CT;      // dtype of the tile math
+  typedef typename std::conditional<KV8, u32x2, u32x4>::type raw_t;   // one lane's gathered chunk
+  static constexpr int SRC_ROW_B = KV8 ? D : 2 * D;                   // bytes of one head row in the pool
+  static constexpr int SRC_CH_B = KV8 ? 8 : 16;                       // bytes of the 8 elements a lane gathers
+  static constexpr int TK = C::TK, ROW_B = C::ROW_B, CPR = C::CPR, RPL = C::RPL, NLD = C::NLD;
+  static constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK, TILE_B = C::TILE_B;
+
+  int lane, col, kq;               // MFMA column (query head) / k quarter
+  int ld_row, ld_ch;               // gather mapping: lane -> (row within the wave-load, 16-byte chunk)
+  int i16, tr_row;                 // fragment-read addresses (constant per lane): V row this lane addresses in a tr read
+  char *ldsK, *ldsV;               // this wave's tile
+  // Address of the chunk a lane gathers from K row `slot`:  kbase[i] + slot * tok_bytes, ONE v_mad_u64_u32 (the slot is a
+  // non-negative int32 and the token stride fits 32 bits - the host checks it - so no 64 x 64-bit product, which the
+  // compiler expands into three quarter-rate multiplies: PMC, round 5: the address arithmetic was 40 % of the loop's
+  // vector instructions).  kbase[i] holds everything that does not depend on the key: pool base, head, and the source
+  // chunk, XOR-swizzled by the tile row so that the LDS image is conflict-free.  V sits at a launch-uniform distance
+  // from K (the pool's two views; one add).
+  uint32_t tok_bytes;
+  int64_t v_minus_k;
+  uint64_t kbase[NLD];
+  u32x4 qf[KSTEPS];                // Q fragments: B operand of S^T = K.Q^T; lane (col, kq) holds Q[head col][32s + 8kq .. +7]
+  f32x4_t oacc[DBLK];              // O^T: lane (col, kq) holds d = 16db + 4kq .. +3 of head col
+  float m_run, l_run;
+  float qk_scale, cap;
+
+  __device__ __forceinline__ void init(const DecodeArgs& a, char* tile, int lane_, int hk) {
+    lane = lane_;
+    col = lane & 15; kq = lane >> 4;
+    ld_row = lane / CPR; ld_ch = lane % CPR;
+    i16 = lane & 15;
+    tr_row = 4 * kq + (i16 >> 2);
+    ldsK = tile;
+    ldsV = tile + TILE_B;
+    tok_bytes = (uint32_t)(a.kv_stride * (KV8 ? 1 : 2));
+    v_minus_k = a.vbuf - a.kbuf;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int R = i * RPL + ld_row;
+      kbase[i] = (uint64_t)(uintptr_t)a.kbuf + (uint64_t)hk * SRC_ROW_B + (uint64_t)((ld_ch ^ (R & (CPR - 1))) * SRC_CH_B);
+    }
+    cap = a.logit_cap;
+    qk_scale = cap > 0.f ? a.sm_scale : a.sm_scale * kLog2eM;
+  }
+  // request b's query rows of kv head hk; padding columns repeat the last head and are never stored
+  __device__ __forceinline__ void load_q(const DecodeArgs& a, int b, int hk, int G) {
+    const int hcol = min(col, G - 1);
+    const char* qp = (const char*)a.q + ((int64_t)b * a.q_stride + (int64_t)(hk * G + hcol) * D + 8 * kq) * 2;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      qf[s] = ld16(qp + s * 64);
+      if constexpr (KV8 && std::is_same<Tag, bf16_tag>::value) qf[s] = bf16x8_to_f16x8(qf[s]);
+    }
+  }
+  __device__ __forceinline__ void reset() {
+#pragma unroll
+    for (int db = 0; db < DBLK; ++db) oacc[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    m_run = kNegBigM;
+    l_run = 0.f;
+  }
+  // gather tile `tile` of the 64 keys whose slots sit in `idxreg` (lanes past the keys hold slot 0, the pool's dummy row:
+  // no select needed); NT: non-temporal loads
+  template <bool NT>
+  __device__ __forceinline__ void issue(int tile, int idxreg, raw_t (&kd)[NLD], raw_t (&vd)[NLD]) const {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int key = tile * TK + i * RPL + ld_row;
+      const uint32_t slot = (uint32_t)__shfl(idxreg, key & 63, 64);
+      // (an integer turned into a pointer is a FLAT pointer to the compiler - flat loads also count in lgkmcnt and
+      // take the aperture check: name the global address space)
+      typedef const raw_t __attribute__((address_space(1)))* gptr_t;
+      const uint64_t ka = kbase[i] + (uint64_t)slot * tok_bytes;
+      const gptr_t kp = (gptr_t)ka, vp = (gptr_t)(ka + (uint64_t)v_minus_k);
+      if constexpr (NT) {
+        kd[i] = __builtin_nontemporal_load(kp);
+        vd[i] = __builtin_nontemporal_load(vp);
+      } else {
+        kd[i] = *kp;
+        vd[i] = *vp;
+      }
+    }
+  }
+  // registers -> this wave's LDS tile: position (row R, chunk ld_ch) holds source chunk ld_ch ^ R, i.e. logical chunk cg of
+  // row R sits at chunk cg ^ R
+  __device__ __forceinline__ void stage(const raw_t (&ks)[NLD], const raw_t (&vs)[NLD]) const {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int R = i * RPL + ld_row;
+      if constexpr (KV8) {
+        st16(ldsK + R * ROW_B + ld_ch * 16, expand_e5m2x8(ks[i]));
+        st16(ldsV + R * ROW_B + ld_ch * 16, expand_e5m2x8(vs[i]));
+      } else {
+        st16(ldsK + R * ROW_B + ld_ch * 16, ks[i]);
+        st16(ldsV + R * ROW_B + ld_ch * 16, vs[i]);
+      }
+    }
+  }
+  // the staged tile `tile` of a 64-key span with n keys; CAP: logit soft-cap
+  template <bool CAP>
+  __device__ __forceinline__ void consume(int tile, int n) {
+    // ---- S^T = K . Q^T: lane (key = col index of A rows = lane&15, kq)
+    f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    {
+      const int R = lane & 15;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int cg = 4 * ks + kq;                          // logical chunk: dims 32ks + 8kq ..
+        const u32x4 kf = ld16(ldsK + R * ROW_B + ((cg ^ (R & (CPR - 1))) * 16));
+        s = mfma_qk<CT>(kf, qf[ks], s);
+      }
+    }
+    // ---- scale, mask, online softmax for column `col`; this lane holds keys 4kq + j
+    float x[4], mx = kNegBigM;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = s[j] * qk_scale;
+      if constexpr (CAP) v = cap * tanhf(v / cap) * kLog2eM;
+      x[j] = (tile * TK + 4 * kq + j < n) ? v : -INFINITY;
+      mx = fmaxf(mx, x[j]);
+    }
+    mx = fmaxf(mx, xchg16m(mx));
+    mx = fmaxf(mx, xchg32m(mx));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      x[j] = __builtin_amdgcn_exp2f(x[j] - m_new);
+      psum += x[j];
+    }
+    psum += xchg16m(psum);
+    psum += xchg32m(psum);
+    l_run = l_run * alpha + psum;
+    u32x2 pf;  // B operand of O^T += V^T.P^T: P^T[k = 4kq + j][col]
+    pf[0] = pack2m<CT>(x[0], x[1]);
+    pf[1] = pack2m<CT>(x[2], x[3]);
+    // ---- O^T[16 d x 16 cols] per d block; V^T fragment by one transposed read:
+    //      lane i of a 16-lane group addresses row 4kq + (i>>2), elements 4(i&3)..+3 of the block
+#pragma unroll
+    for (int db = 0; db < DBLK; ++db) {
+      const int cg = 2 * db + ((i16 & 3) >> 1);             // logical 16-byte chunk of the row
+      const char* vp = ldsV + tr_row * ROW_B + ((cg ^ (tr_row & (CPR - 1))) * 16) + 8 * (i16 & 1);
+      const s16x4_m vt = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_m*)vp);
+      const u32x2 vf = __builtin_bit_cast(u32x2, vt);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[db][r] *= alpha;
+      oacc[db] = mfma_pv<CT>(vf, pf, oacc[db]);
+    }
+  }
+  // the wave owns heads hk*G .. hk*G+G-1 of request b outright: normalise and write the output rows from registers
+  __device__ __forceinline__ void store_out(const DecodeArgs& a, int b, int hk, int G) const {
+    if (col >= G) return;
+    const float inv = 1.0f / l_run * a.out_scale;
+    char* op = (char*)a.out + ((int64_t)b * a.o_stride + (int64_t)(hk * G + col) * D + 4 * kq) * 2;
+#pragma unroll
+    for (int db = 0; db < DBLK; ++db) {
+      u32x2 w;
+      w[0] = pack2m<Tag>(oacc[db][0] * inv, oacc[db][1] * inv);
+      w[1] = pack2m<Tag>(oacc[db][2] * inv, oacc[db][3] * inv);
+      *(u32x2*)(op + db * 32) = w;
+    }
+  }
+  // ... or its partial (normalised rows + log2-sum-exp) to slot `slot` of the workspace
+  __device__ __forceinline__ void store_partial(const DecodeArgs& a, int hk, int G, int slot) const {
+    if (col >= G) return;
+    const float inv = 1.0f / l_run;
+    const int64_t pi = (int64_t)(hk * G + col) * a.max_slots + slot;
+    float* pp = a.part_o + pi * D + 4 * kq;
+#pragma unroll
+    for (int db = 0; db < DBLK; ++db)
+      *(float4*)(pp + 16 * db) = make_float4(oacc[db][0] * inv, oacc[db][1] * inv, oacc[db][2] * inv, oacc[db][3] * inv);
+    if (kq == 0) a.part_lse[pi] = m_run + __builtin_amdgcn_logf(l_run);
+  }
+};
+
 // HPW ("head per wave", Hkv % 4 == 0): the 4 waves take the 4 adjacent KV heads of the SAME keys - the
 // workgroup then reads whole 1 KiB token half-rows, and each wave owns its heads outright: no merge,
 // no barrier anywhere.  Otherwise (few KV heads per rank) the waves split the keys of one head.
-//
-// KV8: the pool holds fp8 e5m2 bytes (--kv-cache-dtype fp8_e5m2).  A lane gathers 8 bytes instead of
-// 16, expands them to 8 halves on the way into the LDS tile (e5m2 is the top byte of a half: one
-// v_perm_b32 per two elements, exact), and the tile math runs in fp16 whatever the model dtype is
-// (bf16 q is converted once per workgroup; P is rounded to fp16); the output keeps the model dtype.
-// HBM bytes per context token halve; everything after the LDS tile is unchanged.
 template <typename Tag, int D, bool HPW, bool KV8>
 #ifndef SP_DEC_WAVES
 #define SP_DEC_WAVES 3
@@ -137,12 +315,9 @@ template <typename Tag, int D, bool HPW, bool KV8>
 __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeArgs a) {
   typedef DmCfg<D> C;
   typedef Elem<Tag> E;
-  typedef typename std::conditional<KV8, f16_tag, Tag>::type CT;      // dtype of the tile math
-  typedef typename std::conditional<KV8, u32x2, u32x4>::type raw_t;   // one lane's gathered chunk
-  constexpr int SRC_ROW_B = KV8 ? D : 2 * D;                          // bytes of one head row in the pool
-  constexpr int SRC_CH_B = KV8 ? 8 : 16;                              // bytes of the 8 elements a lane gathers
-  constexpr int TK = C::TK, ROW_B = C::ROW_B, CPR = C::CPR, RPL = C::RPL, NLD = C::NLD;
-  constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK, TILE_B = C::TILE_B, WAVES = C::WAVES;
+  typedef DmWave<Tag, D, KV8> W;
+  typedef typename W::raw_t raw_t;
+  constexpr int TK = C::TK, NLD = C::NLD, TILE_B = C::TILE_B, WAVES = C::WAVES;
   extern __shared__ __attribute__((aligned(16))) char lds[];
 
   // blockIdx -> (item, kv head or head quad); the heads of one token row are adjacent in launch order
@@ -162,49 +337,10 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
   const int32_t* idx_row = a.r2t + req * a.r2t_stride + kv0;
   const int G = a.Hq / a.Hkv;
 
-  const int col = lane & 15, kq = lane >> 4;       // MFMA column (query head) / k quarter
-  char* ldsK = lds + wave * 2 * TILE_B;
-  char* ldsV = ldsK + TILE_B;
-
-  // Q fragments: B operand of S^T = K.Q^T; lane (col, kq) holds Q[head col][32s + 8kq .. +7]
-  u32x4 qf[KSTEPS];
-  {
-    const int hcol = min(col, G - 1);              // padding columns repeat the last head; never stored
-    const char* qp = (const char*)a.q +
-                     ((int64_t)b * a.q_stride + (int64_t)(hk * G + hcol) * D + 8 * kq) * 2;
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
-      qf[s] = ld16(qp + s * 64);
-      if constexpr (KV8 && std::is_same<Tag, bf16_tag>::value) qf[s] = bf16x8_to_f16x8(qf[s]);
-    }
-  }
-  const float cap = a.logit_cap;
-  const float qk_scale = cap > 0.f ? a.sm_scale : a.sm_scale * kLog2eM;
-
-  f32x4_t oacc[DBLK];
-#pragma unroll
-  for (int db = 0; db < DBLK; ++db) oacc[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float m_run = kNegBigM, l_run = 0.f;
-
-  // gather mapping: lane -> (row within the wave-load, 16-byte chunk)
-  const int ld_row = lane / CPR, ld_ch = lane % CPR;
-  // Address of the chunk a lane gathers from K row `slot`:  kbase[i] + slot * tok_bytes, ONE v_mad_u64_u32 (the slot is a
-  // non-negative int32 and the token stride fits 32 bits - the host checks it - so no 64 x 64-bit product, which the
-  // compiler expands into three quarter-rate multiplies: PMC, round 5: the address arithmetic was 40 % of the loop's
-  // vector instructions).  kbase[i] holds everything that does not depend on the key: pool base, head, and the source
-  // chunk, XOR-swizzled by the tile row so that the LDS image is conflict-free.  V sits at a launch-uniform distance
-  // from K (the pool's two views; one add).
-  const uint32_t tok_bytes = (uint32_t)(a.kv_stride * (KV8 ? 1 : 2));
-  const int64_t v_minus_k = a.vbuf - a.kbuf;
-  uint64_t kbase[NLD];
-#pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    const int R = i * RPL + ld_row;
-    kbase[i] = (uint64_t)(uintptr_t)a.kbuf + (uint64_t)hk * SRC_ROW_B + (uint64_t)((ld_ch ^ (R & (CPR - 1))) * SRC_CH_B);
-  }
-  // fragment-read addresses (constant per lane)
-  const int i16 = lane & 15;
-  const int tr_row = 4 * kq + (i16 >> 2);          // V row this lane addresses in a tr read
+  W w;
+  w.init(a, lds + wave * 2 * TILE_B, lane, hk);
+  w.load_q(a, b, hk, G);
+  w.reset();
 
   // this wave's keys: the whole split (HPW) or a contiguous share of it in whole tiles
   const int sub = HPW ? ce - cs : ((ce - cs + WAVES * TK - 1) / (WAVES * TK)) * TK;
@@ -226,112 +362,6 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
 
     raw_t kr[NLD], vr[NLD];
     raw_t kr2[NLD], vr2[NLD];   // KV8 only: a second set (see the loop below); unused and optimised away otherwise
-    auto issue_from = [&](int tile, int idxreg, raw_t (&kd)[NLD], raw_t (&vd)[NLD]) {
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        const int key = tile * TK + i * RPL + ld_row;         // key within the piece
-        // (lanes of the index register past the piece's keys hold slot 0, the pool's dummy row: no select needed)
-        const uint32_t slot = (uint32_t)__shfl(idxreg, key & 63, 64);
-        // (an integer turned into a pointer is a FLAT pointer to the compiler - flat loads also count in lgkmcnt and
-        // take the aperture check: name the global address space)
-        typedef const raw_t __attribute__((address_space(1)))* gptr_t;
-        const uint64_t ka = kbase[i] + (uint64_t)slot * tok_bytes;
-        const gptr_t kp = (gptr_t)ka, vp = (gptr_t)(ka + (uint64_t)v_minus_k);
-        if constexpr (NT) {
-          kd[i] = __builtin_nontemporal_load(kp);
-          vd[i] = __builtin_nontemporal_load(vp);
-        } else {
-          kd[i] = *kp;
-          vd[i] = *vp;
-        }
-      }
-    };
-    auto issue_to = [&](int tile, raw_t (&kd)[NLD], raw_t (&vd)[NLD]) { issue_from(tile, myidx, kd, vd); };
-    auto issue = [&](int tile) { issue_to(tile, kr, vr); };
-    auto stage_from = [&](const raw_t (&ks)[NLD], const raw_t (&vs)[NLD]) {
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        const int R = i * RPL + ld_row;
-        if constexpr (KV8) {
-          st16(ldsK + R * ROW_B + ld_ch * 16, expand_e5m2x8(ks[i]));
-          st16(ldsV + R * ROW_B + ld_ch * 16, expand_e5m2x8(vs[i]));
-        } else {
-          st16(ldsK + R * ROW_B + ld_ch * 16, ks[i]);
-          st16(ldsV + R * ROW_B + ld_ch * 16, vs[i]);
-        }
-      }
-    };
-    auto stage = [&]() {
-      // registers -> this wave's LDS tile: position (row R, chunk ld_ch) holds source chunk
-      // ld_ch ^ R, i.e. logical chunk cg of row R sits at chunk cg ^ R
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        const int R = i * RPL + ld_row;
-        if constexpr (KV8) {
-          st16(ldsK + R * ROW_B + ld_ch * 16, expand_e5m2x8(kr[i]));
-          st16(ldsV + R * ROW_B + ld_ch * 16, expand_e5m2x8(vr[i]));
-        } else {
-          st16(ldsK + R * ROW_B + ld_ch * 16, kr[i]);
-          st16(ldsV + R * ROW_B + ld_ch * 16, vr[i]);
-        }
-      }
-    };
-    auto consume = [&](int tile) {
-      // ---- S^T = K . Q^T: lane (key = col index of A rows = lane&15, kq)
-      f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      {
-        const int R = lane & 15;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-          const int cg = 4 * ks + kq;                          // logical chunk: dims 32ks + 8kq ..
-          const u32x4 kf = ld16(ldsK + R * ROW_B + ((cg ^ (R & (CPR - 1))) * 16));
-          s = mfma_qk<CT>(kf, qf[ks], s);
-        }
-      }
-      // ---- scale, mask, online softmax for column `col`; this lane holds keys 4kq + j
-      float x[4], mx = kNegBigM;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float v = s[j] * qk_scale;
-        if constexpr (CAP) v = cap * tanhf(v / cap) * kLog2eM;
-        x[j] = (tile * TK + 4 * kq + j < n) ? v : -INFINITY;
-        mx = fmaxf(mx, x[j]);
-      }
-      mx = fmaxf(mx, xchg16m(mx));
-      mx = fmaxf(mx, xchg32m(mx));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      float psum = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        x[j] = __builtin_amdgcn_exp2f(x[j] - m_new);
-        psum += x[j];
-      }
-      psum += xchg16m(psum);
-      psum += xchg32m(psum);
-      l_run = l_run * alpha + psum;
-      u32x2 pf;  // B operand of O^T += V^T.P^T: P^T[k = 4kq + j][col]
-      pf[0] = pack2m<CT>(x[0], x[1]);
-      pf[1] = pack2m<CT>(x[2], x[3]);
-      // ---- O^T[16 d x 16 cols] per d block; V^T fragment by one transposed read:
-      //      lane i of a 16-lane group addresses row 4kq + (i>>2), elements 4(i&3)..+3 of the block
-#pragma unroll
-      for (int db = 0; db < DBLK; ++db) {
-        const int cg = 2 * db + ((i16 & 3) >> 1);             // logical 16-byte chunk of the row
-        const char* vp = ldsV + tr_row * ROW_B + ((cg ^ (tr_row & (CPR - 1))) * 16) + 8 * (i16 & 1);
-        const s16x4_m vt = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4_m*)vp);
-        const u32x2 vf = __builtin_bit_cast(u32x2, vt);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) oacc[db][r] *= alpha;
-        oacc[db] = mfma_pv<CT>(vf, pf, oacc[db]);
-      }
-    };
-
-    // one register set: the tile's registers are free as soon as they are in LDS, so the next
-    // tile's gathers are issued right there and fly during this tile's MFMAs and softmax (and under
-    // the other waves of the SIMD: ~100 VGPRs => 4 waves per SIMD)
 #ifdef SP_DEC_ONESET   // diagnostic build: one register set for byte pools too
     constexpr bool kTwoSets = false;
 #elif defined(SP_DEC_TWOSETS)   // diagnostic build: two register sets for 16-bit pools too (with -DSP_DEC_WAVES=2: no spills)
@@ -343,65 +373,48 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
       // a byte pool moves half the bytes per gather: with one tile in flight per wave the CU has half the
       // bytes in flight of the 16-bit kernel (5.1 vs 5.7 TB/s).  Two register sets (8 B per lane and gather:
       // 16 registers more), tiles t+1 and t+2 in flight while tile t is consumed.
-      issue_to(0, kr, vr);
-      if (1 < ntile) issue_to(1, kr2, vr2);
+      w.template issue<NT>(0, myidx, kr, vr);
+      if (1 < ntile) w.template issue<NT>(1, myidx, kr2, vr2);
       for (int t = 0; t < ntile; t += 2) {
-        stage_from(kr, vr);
-        if (t + 2 < ntile) issue_to(t + 2, kr, vr);
-        consume(t);
+        w.stage(kr, vr);
+        if (t + 2 < ntile) w.template issue<NT>(t + 2, myidx, kr, vr);
+        w.template consume<CAP>(t, n);
         if (t + 1 < ntile) {
-          stage_from(kr2, vr2);
-          if (t + 3 < ntile) issue_to(t + 3, kr2, vr2);
-          consume(t + 1);
+          w.stage(kr2, vr2);
+          if (t + 3 < ntile) w.template issue<NT>(t + 3, myidx, kr2, vr2);
+          w.template consume<CAP>(t + 1, n);
         }
       }
     } else {
-    issue(0);
-    for (int t = 0; t < ntile; ++t) {
-      stage();
-      if (t + 1 < ntile) issue(t + 1);
-      consume(t);
-    }
+      // one register set: the tile's registers are free as soon as they are in LDS, so the next
+      // tile's gathers are issued right there and fly during this tile's MFMAs and softmax (and under
+      // the other waves of the SIMD)
+      w.template issue<NT>(0, myidx, kr, vr);
+      for (int t = 0; t < ntile; ++t) {
+        w.stage(kr, vr);
+        if (t + 1 < ntile) w.template issue<NT>(t + 1, myidx, kr, vr);
+        w.template consume<CAP>(t, n);
+      }
     }
   }
   };
   // (a plan-less launch has no key count to compare: it streams only when the threshold is "always", the default)
   const bool nt = a.plan ? a.plan[3] >= a.nt_min_keys : a.nt_min_keys == 0;
-  if (cap > 0.f) {
+  if (w.cap > 0.f) {
     if (nt) key_loop(std::true_type{}, std::true_type{}); else key_loop(std::false_type{}, std::true_type{});
   } else {
     if (nt) key_loop(std::true_type{}, std::false_type{}); else key_loop(std::false_type{}, std::false_type{});
   }
 
   if constexpr (HPW) {
-    // ---- this wave owns heads hk*G .. hk*G+G-1: normalise and write straight from registers
-    //      (lane (col, kq) holds d = 16db + 4kq .. +3 of head col)
-    if (col < G) {
-      const int h = hk * G + col;
-      float inv = 1.0f / l_run;
-      if (nsplit == 1) {
-        inv *= a.out_scale;
-        char* op = (char*)a.out + ((int64_t)b * a.o_stride + (int64_t)h * D + 4 * kq) * 2;
-#pragma unroll
-        for (int db = 0; db < DBLK; ++db) {
-          u32x2 w;
-          w[0] = pack2m<Tag>(oacc[db][0] * inv, oacc[db][1] * inv);
-          w[1] = pack2m<Tag>(oacc[db][2] * inv, oacc[db][3] * inv);
-          *(u32x2*)(op + db * 32) = w;
-        }
-      } else {
-        const int64_t pi = (int64_t)h * a.max_slots + (slot0 + c);
-        float* pp = a.part_o + pi * D + 4 * kq;
-#pragma unroll
-        for (int db = 0; db < DBLK; ++db)
-          *(float4*)(pp + 16 * db) = make_float4(oacc[db][0] * inv, oacc[db][1] * inv,
-                                                 oacc[db][2] * inv, oacc[db][3] * inv);
-        if (kq == 0) a.part_lse[pi] = m_run + __builtin_amdgcn_logf(l_run);
-      }
-    }
+    // ---- this wave owns heads hk*G .. hk*G+G-1: straight from registers
+    if (nsplit == 1) w.store_out(a, b, hk, G);
+    else w.store_partial(a, hk, G, slot0 + c);
     return;
   }
   // ---- merge the 4 waves through LDS (reusing the tile area): O^T[d][col], m, l per column
+  const int col = w.col, kq = w.kq;
+  constexpr int DBLK = C::DBLK;
   __syncthreads();  // every wave is done with its tiles
   float* sm_o = (float*)lds;                       // [WAVES][16 cols][D]
   float* sm_ml = sm_o + WAVES * 16 * D;            // [WAVES][16 cols][2]
@@ -409,10 +422,10 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
     float* dst = sm_o + (wave * 16 + col) * D + 4 * kq;
 #pragma unroll
     for (int db = 0; db < DBLK; ++db)
-      *(float4*)(dst + 16 * db) = make_float4(oacc[db][0], oacc[db][1], oacc[db][2], oacc[db][3]);
+      *(float4*)(dst + 16 * db) = make_float4(w.oacc[db][0], w.oacc[db][1], w.oacc[db][2], w.oacc[db][3]);
     if (kq == 0) {
-      sm_ml[(wave * 16 + col) * 2] = m_run;
-      sm_ml[(wave * 16 + col) * 2 + 1] = l_run;
+      sm_ml[(wave * 16 + col) * 2] = w.m_run;
+      sm_ml[(wave * 16 + col) * 2 + 1] = w.l_run;
     }
   }
   __syncthreads();
@@ -420,22 +433,22 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
     const int d = i % D, g = i / D;
     float M = kNegBigM;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) M = fmaxf(M, sm_ml[(w * 16 + g) * 2]);
-    float L = 0.f, O = 0.f;
+    for (int wv = 0; wv < WAVES; ++wv) M = fmaxf(M, sm_ml[(wv * 16 + g) * 2]);
+    float Lsum = 0.f, O = 0.f;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
-      const float wgt = __builtin_amdgcn_exp2f(sm_ml[(w * 16 + g) * 2] - M);
-      L += sm_ml[(w * 16 + g) * 2 + 1] * wgt;
-      O += sm_o[(w * 16 + g) * D + d] * wgt;
+    for (int wv = 0; wv < WAVES; ++wv) {
+      const float wgt = __builtin_amdgcn_exp2f(sm_ml[(wv * 16 + g) * 2] - M);
+      Lsum += sm_ml[(wv * 16 + g) * 2 + 1] * wgt;
+      O += sm_o[(wv * 16 + g) * D + d] * wgt;
     }
     const int h = hk * G + g;
-    const float o = O / L;
+    const float o = O / Lsum;
     if (nsplit == 1) {
       E::store(a.out, (int64_t)b * a.o_stride + (int64_t)h * D + d, o * a.out_scale);
     } else {
       const int64_t pi = (int64_t)h * a.max_slots + (slot0 + c);
       a.part_o[pi * D + d] = o;
-      if (d == 0) a.part_lse[pi] = M + __builtin_amdgcn_logf(L);
+      if (d == 0) a.part_lse[pi] = M + __builtin_amdgcn_logf(Lsum);
     }
   }
 }
@@ -463,12 +476,9 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_kernel(DecodeAr
 template <typename Tag, int D, bool KV8>
 __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_range_kernel(DecodeArgs a) {
   typedef DmCfg<D> C;
-  typedef typename std::conditional<KV8, f16_tag, Tag>::type CT;      // dtype of the tile math (see decode_mfma_kernel)
-  typedef typename std::conditional<KV8, u32x2, u32x4>::type raw_t;   // one lane's gathered chunk
-  constexpr int SRC_ROW_B = KV8 ? D : 2 * D;                          // bytes of one head row in the pool
-  constexpr int SRC_CH_B = KV8 ? 8 : 16;                              // bytes of the 8 elements a lane gathers
-  constexpr int TK = C::TK, ROW_B = C::ROW_B, CPR = C::CPR, RPL = C::RPL, NLD = C::NLD;
-  constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK, TILE_B = C::TILE_B;
+  typedef DmWave<Tag, D, KV8> W;
+  typedef typename W::raw_t raw_t;
+  constexpr int TK = C::TK, NLD = C::NLD, DBLK = C::DBLK, TILE_B = C::TILE_B;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   // wave -> (piece, kv head): the heads of one piece are adjacent in launch order.  With the kv heads in fours a
@@ -485,15 +495,6 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_range_kernel(De
   const int32_t* posv = rp + kRangeHdr;
   const int lo = piece * R, hi = lo + R;                    // this piece of the line
   const int G = a.Hq / a.Hkv;
-  const int col = lane & 15, kq = lane >> 4;
-  char* ldsK = lds + wave * 2 * TILE_B;
-  char* ldsV = ldsK + TILE_B;
-  const float qk_scale = a.sm_scale * kLog2eM;
-  const int ld_row = lane / CPR, ld_ch = lane % CPR;
-  const uint32_t tok_bytes = (uint32_t)(a.kv_stride * (KV8 ? 1 : 2));
-  const int64_t v_minus_k = a.vbuf - a.kbuf;
-  const int i16 = lane & 15;
-  const int tr_row = 4 * kq + (i16 >> 2);
 
   // a request's share of the piece: keys cs .. ce of request b; `whole`: all of its keys (no partial)
   struct Seg { int b, cs, ce, end; bool whole; const int32_t* idx_row; };
@@ -546,101 +547,13 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_range_kernel(De
     if (first < 0 || !segment_at(first, cur)) return;
   }
 
-  uint64_t kbase[NLD];
-#pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    const int Rw = i * RPL + ld_row;
-    kbase[i] = (uint64_t)(uintptr_t)a.kbuf + (uint64_t)hk * SRC_ROW_B + (uint64_t)((ld_ch ^ (Rw & (CPR - 1))) * SRC_CH_B);
-  }
-  u32x4 qf[KSTEPS];
-  auto load_q = [&](const Seg& u) {
-    const int hcol = min(col, G - 1);
-    const char* qp = (const char*)a.q + ((int64_t)u.b * a.q_stride + (int64_t)(hk * G + hcol) * D + 8 * kq) * 2;
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
-      qf[s] = ld16(qp + s * 64);
-      if constexpr (KV8 && std::is_same<Tag, bf16_tag>::value) qf[s] = bf16x8_to_f16x8(qf[s]);
-    }
-  };
-  load_q(cur);
+  W w;
+  w.init(a, lds + wave * 2 * TILE_B, lane, hk);
+  w.load_q(a, cur.b, hk, G);
+  w.reset();
+  const int col = w.col, kq = w.kq;
 
-  f32x4_t oacc[DBLK];
-#pragma unroll
-  for (int db = 0; db < DBLK; ++db) oacc[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float m_run = kNegBigM, l_run = 0.f;
-
-  raw_t kr[NLD], vr[NLD];
-  auto issue = [&](int tile, int idxreg) {
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int key = tile * TK + i * RPL + ld_row;
-      const uint32_t slot = (uint32_t)__shfl(idxreg, key & 63, 64);
-      typedef const raw_t __attribute__((address_space(1)))* gptr_t;
-      const uint64_t ka = kbase[i] + (uint64_t)slot * tok_bytes;
-      kr[i] = __builtin_nontemporal_load((gptr_t)ka);
-      vr[i] = __builtin_nontemporal_load((gptr_t)(ka + (uint64_t)v_minus_k));
-    }
-  };
-  auto stage = [&]() {
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int Rw = i * RPL + ld_row;
-      if constexpr (KV8) {
-        st16(ldsK + Rw * ROW_B + ld_ch * 16, expand_e5m2x8(kr[i]));
-        st16(ldsV + Rw * ROW_B + ld_ch * 16, expand_e5m2x8(vr[i]));
-      } else {
-        st16(ldsK + Rw * ROW_B + ld_ch * 16, kr[i]);
-        st16(ldsV + Rw * ROW_B + ld_ch * 16, vr[i]);
-      }
-    }
-  };
-  auto consume = [&](int tile, int n) {
-    f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    {
-      const int Rw = lane & 15;
-#pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        const int cg = 4 * ks + kq;
-        const u32x4 kf = ld16(ldsK + Rw * ROW_B + ((cg ^ (Rw & (CPR - 1))) * 16));
-        s = mfma_qk<CT>(kf, qf[ks], s);
-      }
-    }
-    float x[4], mx = kNegBigM;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float v = s[j] * qk_scale;
-      x[j] = (tile * TK + 4 * kq + j < n) ? v : -INFINITY;
-      mx = fmaxf(mx, x[j]);
-    }
-    mx = fmaxf(mx, xchg16m(mx));
-    mx = fmaxf(mx, xchg32m(mx));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      x[j] = __builtin_amdgcn_exp2f(x[j] - m_new);
-      psum += x[j];
-    }
-    psum += xchg16m(psum);
-    psum += xchg32m(psum);
-    l_run = l_run * alpha + psum;
-    u32x2 pf;
-    pf[0] = pack2m<CT>(x[0], x[1]);
-    pf[1] = pack2m<CT>(x[2], x[3]);
-#pragma unroll
-    for (int db = 0; db < DBLK; ++db) {
-      const int cg = 2 * db + ((i16 & 3) >> 1);
-      const char* vp = ldsV + tr_row * ROW_B + ((cg ^ (tr_row & (CPR - 1))) * 16) + 8 * (i16 & 1);
-      const s16x4_m vt = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_m*)vp);
-      const u32x2 vf = __builtin_bit_cast(u32x2, vt);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) oacc[db][r] *= alpha;
-      oacc[db] = mfma_pv<CT>(vf, pf, oacc[db]);
-    }
-  };
-  // Parking space of this wave behind the tiles: records of [G rows of D floats | 16 log-sum-exps | request]
+  // Parking space of this wave behind the tiles: records of [G rows of D floats | 16 log-sum-exps | slot]
   const int park_rows_b = G * D * 4;
   const int park_unit_b = park_rows_b + 64 + 16;
   constexpr int kParkWaveB = KV8 ? kDmParkWaveB8 : kDmParkWaveB;
@@ -661,50 +574,35 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_range_kernel(De
   };
   // a request's result: straight to the output (all of its keys were in this piece) or as the partial of slot b + piece
   auto write_seg = [&](const Seg& u) {
-    const int slot = u.b + piece;
-    if (!u.whole && parked < park_cap) {
-      char* dst = park + parked * park_unit_b;
-      if (col < G) {
-        const float inv = 1.0f / l_run;
-#pragma unroll
-        for (int db = 0; db < DBLK; ++db) {
-          u32x4 w;
-          w[0] = as_u32(oacc[db][0] * inv); w[1] = as_u32(oacc[db][1] * inv);
-          w[2] = as_u32(oacc[db][2] * inv); w[3] = as_u32(oacc[db][3] * inv);
-          st16(dst + col * (D * 4) + (16 * db + 4 * kq) * 4, w);
-        }
-        if (kq == 0) *(float*)(dst + park_rows_b + col * 4) = m_run + __builtin_amdgcn_logf(l_run);
-      }
-      if (lane == 0) *(int*)(dst + park_rows_b + 64) = slot;
-      ++parked;
+    if (u.whole) {
+      w.store_out(a, u.b, hk, G);
       return;
     }
-    if (col >= G) return;
-    const int h = hk * G + col;
-    float inv = 1.0f / l_run;
-    if (u.whole) {
-      inv *= a.out_scale;
-      char* op = (char*)a.out + ((int64_t)u.b * a.o_stride + (int64_t)h * D + 4 * kq) * 2;
+    const int slot = u.b + piece;
+    if (parked >= park_cap) {
+      w.store_partial(a, hk, G, slot);
+      return;
+    }
+    char* dst = park + parked * park_unit_b;
+    if (col < G) {
+      const float inv = 1.0f / w.l_run;
 #pragma unroll
       for (int db = 0; db < DBLK; ++db) {
-        u32x2 w;
-        w[0] = pack2m<Tag>(oacc[db][0] * inv, oacc[db][1] * inv);
-        w[1] = pack2m<Tag>(oacc[db][2] * inv, oacc[db][3] * inv);
-        *(u32x2*)(op + db * 32) = w;
+        u32x4 v;
+        v[0] = as_u32(w.oacc[db][0] * inv); v[1] = as_u32(w.oacc[db][1] * inv);
+        v[2] = as_u32(w.oacc[db][2] * inv); v[3] = as_u32(w.oacc[db][3] * inv);
+        st16(dst + col * (D * 4) + (16 * db + 4 * kq) * 4, v);
       }
-    } else {
-      const int64_t pi = (int64_t)h * a.max_slots + slot;
-      float* pp = a.part_o + pi * D + 4 * kq;
-#pragma unroll
-      for (int db = 0; db < DBLK; ++db)
-        *(float4*)(pp + 16 * db) = make_float4(oacc[db][0] * inv, oacc[db][1] * inv, oacc[db][2] * inv, oacc[db][3] * inv);
-      if (kq == 0) a.part_lse[pi] = m_run + __builtin_amdgcn_logf(l_run);
+      if (kq == 0) *(float*)(dst + park_rows_b + col * 4) = w.m_run + __builtin_amdgcn_logf(w.l_run);
     }
+    if (lane == 0) *(int*)(dst + park_rows_b + 64) = slot;
+    ++parked;
   };
 
+  raw_t kr[NLD], vr[NLD];
   int pos = cur.cs;
   int curidx = (pos + lane < cur.ce) ? cur.idx_row[pos + lane] : 0;
-  issue(0, curidx);
+  w.template issue<true>(0, curidx, kr, vr);
   for (;;) {
     const int n = min(64, cur.ce - pos);
     const int ntile = (n + TK - 1) / TK;
@@ -720,20 +618,17 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_range_kernel(De
       nextidx = (pos + 64 + lane < cur.ce) ? cur.idx_row[pos + 64 + lane] : 0;
     }
     for (int t = 0; t < ntile; ++t) {
-      stage();
-      if (t + 1 < ntile) issue(t + 1, curidx);
-      else if (!last || have_next) issue(0, nextidx);       // the next 64 keys' first tile: no drain in between
-      consume(t, n);
+      w.stage(kr, vr);
+      if (t + 1 < ntile) w.template issue<true>(t + 1, curidx, kr, vr);
+      else if (!last || have_next) w.template issue<true>(0, nextidx, kr, vr);   // the next 64 keys' first tile: no drain in between
+      w.template consume<false>(t, n);
     }
     if (last) {
       write_seg(cur);
       if (!have_next) break;
       cur = nxt;
-      load_q(cur);
-#pragma unroll
-      for (int db = 0; db < DBLK; ++db) oacc[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      m_run = kNegBigM;
-      l_run = 0.f;
+      w.load_q(a, cur.b, hk, G);
+      w.reset();
       pos = cur.cs;
     } else {
       pos += 64;
