@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--kv", default="same", choices=["same", "fp8"])
     ap.add_argument("--graph-slots", action="store_true", help="the launch covers max(1024, 8 bs) + bs items, as under graph replay")
+    ap.add_argument("--sequential-slots", action="store_true",
+                    help="requests take consecutive KV slots (default: a random permutation of the pool, page_size 1)")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--rounds", type=int, default=7)
     a = ap.parse_args()
@@ -76,7 +78,7 @@ def main():
     if a.kv == "fp8":
         arena = arena.to(torch.float8_e5m2).view(torch.uint8)
     kb, vb = arena[:, 0], arena[:, 1]
-    perm = (torch.randperm(P, generator=g) + 1).to(torch.int32)
+    perm = ((torch.arange(P) if a.sequential_slots else torch.randperm(P, generator=g)) + 1).to(torch.int32)
     r2t = torch.zeros(bs, max_len + 8, dtype=torch.int32)
     off = 0
     for b in range(bs):
