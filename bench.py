@@ -209,7 +209,6 @@ def populate_batch(mr, ctx, gen):
     batch.req_pool_indices = torch.tensor(rows, dtype=torch.int64, device=dev)
     batch.seq_lens = ctx.to(torch.int64).to(dev)
     batch.seq_lens_sum = int(ctx.sum())
-    batch.seq_lens_max = int(ctx.max())
     table = mr.req_to_token_pool.req_to_token
     slots = alloc.alloc(int(ctx.sum()))
     off = 0

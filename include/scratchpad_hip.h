@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 8
+#define SP_ABI_VERSION 9
 #define SP_API __attribute__((visibility("default")))
 
 typedef enum { SP_F32 = 0, SP_F16 = 1, SP_BF16 = 2, SP_FP8_E5M2 = 3 /* KV pool only */ } sp_dtype;
@@ -66,7 +66,9 @@ SP_API int sp_debug_set(const char* key, int value);
  * register allocation fixed at assembly level - scratchpad_amd/build.py compile_w64 - and the
  * 4-wave x 64-row extend kernels may launch; anything else: sp_extend_attention keeps to the 8-wave kernel),
  * "extend_last_kernel" (what the last sp_extend_attention call launched: 1 = 8-wave matrix-core kernel, 2 = 4-wave
- * x 64-row kernel, 3 = its persistent form, 4 = row streams on the decode kernel, 0 = none yet).  -1: unknown key. */
+ * x 64-row kernel, 3 = its persistent form, 4 = row streams on the decode kernel, 0 = none yet), "decode_last_kernel"
+ * (ABI 9; what the last sp_decode_attention call launched: 1 = VALU kernel, 2 = matrix-core kernel on (request, split)
+ * items, 3 = range kernel, 0 = none yet).  -1: unknown key. */
 SP_API int sp_debug_get(const char* key);
 
 /* ---- RMSNorm: replaces flashinfer.norm.rmsnorm / fused_add_rmsnorm
@@ -151,7 +153,7 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  * ABI 7: a plan is read-only for the launches that use it, so launches on several streams may share one.)
  *   - Without a plan the grid is the static (request, split) rectangle: slot0[b] = b * num_splits,
  *     num_splits = ceil(max_seq_len / chunk), max_slots is ignored (= batch_size * num_splits).
- *   - With a `plan` (sp_decode_plan: [count, chunk, needed, keys | slot0[bs] | (b, c) x max_slots], built once per step from
+ *   - With a `plan` (sp_decode_plan: [count, chunk, needed, keys | slot0[bs] | (b, c) x max_slots], `plan_bytes` long, built once per step from
  *     the same seq_lens and shared by all layers - the counterpart of flashinfer's begin_forward()/plan,
  *     flashinfer_backend.py:623-670, and of TritonAttnBackend.init_forward_metadata,
  *     triton_backend.py:48-68) the launch covers `max_slots` work items, the kernels read the split size
@@ -165,9 +167,9 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  *     batches); a plan never changes the result, only which workgroup computes which split.
  * workspace: sp_decode_attention_workspace_bytes(max_slots, ...); plan: sp_decode_plan_bytes().
  *
- * Range geometry (ABI 8).  A plan built with `ranges` > 0 carries a second section,
- * [rcount, R, 0, 0 | pos[bs + 1] | start[ranges]], behind the items: the step's keys, request after request in batch
- * order, form one line (request b at pos[b] .. pos[b] + len_b, then 16 empty positions - what a request costs a
+ * Range geometry (ABI 8; what a default decode step runs).  A plan built with `ranges` > 0 carries a second section,
+ * [rcount, R, ranges, batch_size | pos[bs + 1] | start[ranges]], behind the items: the step's keys, request after request
+ * in batch order, form one line (request b at pos[b] .. pos[b] + len_b, then 16 empty positions - what a request costs a
  * workgroup beyond its keys); the line is cut into rcount <= ranges equal pieces of R = ceil(length / ranges) positions
  * (at least 64) and start[j] is the first request with a key at or after j * R (-1: piece j holds none).  A launch
  * given the same `ranges` runs one WAVE per (piece, kv head) - with the kv heads in fours a workgroup is the four
@@ -177,13 +179,31 @@ SP_API int sp_clamp_position(int64_t* positions, const void* seq_lens, int idx64
  * its partials in slots b + jf .. b + jl (b + j grows along the line: no two (request, piece) pairs share a slot) and
  * the merge launch combines them: the workspace then holds batch_size + ranges slots, whatever sum(seq_lens) is - the
  * overflow below cannot happen on this path.
- * sp_decode_ranges() is the piece count the library wants for a shape: two workgroups per CU (three on a byte pool),
- * all resident at once, four waves each, over the kv heads (at most 1024) - 256 pieces for 8 kv heads on MI355X, 1024 for a
- * tensor-parallel rank's single head - or 0 where the range kernel does not apply (fp32, groups wider than 16, head
- * sizes other than 64 / 128).  Launches it does not take (those shapes, a logit soft-cap, out rows not 8-byte aligned,
- * sp_debug_set("decode_ranges", 0)) use the plan's (request, split) items as before: a plan
- * always carries both.  Requires batch_size * (max_seq_len + 16) < 2^31 (else SP_ERR_INVALID_ARG from sp_decode_plan;
- * pass ranges = 0).  Results of the two geometries differ in the last bits (another split of the same sums).
+ * sp_decode_ranges() is the piece count the library wants for a shape ON THE CURRENT DEVICE (the answer, and the
+ * kernel's LDS limit behind it, are kept per device of the process: set the device before the first call, as for any
+ * launch): two workgroups per CU (three on a byte pool), all resident at once, four waves each, over the kv heads (at
+ * most 1024) - 256 pieces for 8 kv heads on MI355X, 1024 for a tensor-parallel rank's single head - or 0 where the range
+ * kernel does not apply (fp32, groups wider than 16, head sizes other than 64 / 128).  Launches it does not take (those
+ * shapes, a logit soft-cap, out rows not 8-byte aligned, sp_debug_set("decode_ranges", 0)) use the plan's (request, split)
+ * items.  Requires batch_size * (max_seq_len + 16) < 2^31 (else SP_ERR_INVALID_ARG from sp_decode_plan; pass ranges = 0).
+ * Results of the two geometries differ in the last bits (another split of the same sums), and under the range geometry
+ * the cuts - hence a request's last bits - depend on the lengths of the whole batch, not on the request alone.
+ *
+ * Plan and launch must agree (ABI 9).  The sections of a plan are located from (batch_size, max_slots, ranges), so
+ * sp_decode_attention must be given the values the plan was BUILT with - where the reference rebuilds indices and launch
+ * from one begin_forward() call (flashinfer_backend.py:623-670) and they cannot disagree.  What is checked:
+ *   - `plan_bytes` (sp_decode_attention) must cover sp_decode_plan_bytes(batch_size, max_slots, ranges), else
+ *     SP_ERR_WORKSPACE: no kernel reads a header outside the caller's buffer;
+ *   - the range section records the `ranges` and `batch_size` it was built for (its words 2, 3); a range launch (and its
+ *     merge) that finds other values does NOTHING - no table read, no gather, `out` untouched - instead of following
+ *     pos[] / start[] of another shape.  Nothing on the device reports it: pre-fill `out` to see it, or keep the pair on
+ *     the host as scratchpad_amd/_native.py does (decode_plan() remembers what each plan buffer was built with and
+ *     decode_attention() raises before launching on any difference);
+ *   - ITEMS ARE OPTIONAL: max_slots = 0 (with ranges > 0) builds the range section alone - the item section is then its
+ *     4-word header [0, chunk, 0, 0] - which is what a backend whose layers all take the range kernel wants (the plan
+ *     kernel skips its six item passes).  A launch that would need the items of such a plan (soft-cap, fp32, ...) returns
+ *     SP_ERR_INVALID_ARG.  Likewise ranges = 0 builds the items alone.  sp_debug_get("decode_last_kernel") says what the
+ *     last call launched: 1 = VALU kernel (items), 2 = matrix-core kernel (items), 3 = range kernel.
  *
  * Overflow (ABI 6).  The plan's word 2 holds the number of items the lengths NEED; when it exceeds `max_slots`
  * (the caller's bound on sum(seq_lens) was too small) the surplus splits are not computed and the affected
@@ -218,8 +238,8 @@ SP_API int sp_decode_attention(void* out, const void* q, const void* k_buffer, c
                         int head_dim, int64_t q_stride, int64_t out_stride,
                         int64_t kv_buffer_stride, float sm_scale, float logit_cap, float k_scale,
                         float v_scale, int64_t max_seq_len, int chunk, int64_t max_slots, int ranges,
-                        void* workspace, size_t workspace_bytes, const int32_t* plan, int dtype,
-                        int kv_dtype, void* stream);
+                        void* workspace, size_t workspace_bytes, const int32_t* plan, size_t plan_bytes,
+                        int dtype, int kv_dtype, void* stream);
 
 /* ---- Ragged extend (prefill) attention: replaces extend_attention_fwd (nn/attention/
  *      triton_attn/extend_attention.py:229-327; call site triton_backend.py:137-154) and the

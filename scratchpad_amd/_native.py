@@ -19,6 +19,7 @@ _lib = None
 SP_F32, SP_F16, SP_BF16 = 0, 1, 2
 _DTYPES = {torch.float32: SP_F32, torch.float16: SP_F16, torch.bfloat16: SP_BF16}
 SP_FP8_E5M2 = 3
+SP_OK, SP_ERR_INVALID_ARG, SP_ERR_UNSUPPORTED, SP_ERR_WORKSPACE, SP_ERR_LAUNCH = 0, -1, -2, -3, -4     # sp_status
 _FP8_POOL_DTYPES = (torch.uint8, torch.float8_e5m2)
 
 
@@ -71,7 +72,7 @@ SIGNATURES = {
     "sp_decode_plan": (_i32, [_vp, _sz, _vp, _i32, _i32, _i64, _i32, _i64, _i32, _vp]),
     "sp_decode_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32,
                                    _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _i64, _i32, _i64,
-                                   _i32, _vp, _sz, _vp, _i32, _i32, _vp]),
+                                   _i32, _vp, _sz, _vp, _sz, _i32, _i32, _vp]),
     "sp_extend_attention_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32]),
     "sp_extend_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp,
                                    _i32, _i64, _i32, _i32, _i32, _i64, _i64, _i64, _f32, _f32, _f32, _f32,
@@ -120,7 +121,7 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.sp_abi_version() != 8:
+    if lib.sp_abi_version() != 9:
         raise RuntimeError("libscratchpad_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -366,7 +367,7 @@ def decode_workspace_bytes(bs: int, Hq: int, Dv: int, max_seq_len: int, chunk: i
     return int(load().sp_decode_attention_workspace_bytes(max_slots, Hq, Dv))
 
 
-RANGE_HEADER_WORDS = 4         # [pieces in use, piece length R, 0, 0] in front of pos[bs + 1] and start[ranges]
+RANGE_HEADER_WORDS = 4         # [pieces in use, piece length R, ranges, bs] in front of pos[bs + 1] and start[ranges]
 RANGE_REQUEST_COST = 16        # positions a request takes on the line beyond its keys (attention_internal.h)
 
 
@@ -383,29 +384,46 @@ def decode_ranges(Hq: int, Hkv: int, D: int, dtype: torch.dtype, kv_dtype: Optio
 PLAN_HEADER_WORDS = 4          # [items listed, chunk, items the lengths need, keys the step gathers per kv head]
 
 
+def _plan_slots(bs: int, max_seq_len: int, chunk: int, max_slots: Optional[int]) -> int:
+    return decode_plan_slots(bs, max_seq_len, chunk) if max_slots is None else int(max_slots)
+
+
 def decode_plan_bytes(bs: int, max_seq_len: int, chunk: int, max_slots: Optional[int] = None, ranges: int = 0) -> int:
-    if max_slots is None:
-        max_slots = decode_plan_slots(bs, max_seq_len, chunk)
-    return int(load().sp_decode_plan_bytes(bs, max_slots, ranges))
+    """max_slots = 0 with ranges > 0: a plan without the (request, split) items (range launches only)."""
+    return int(load().sp_decode_plan_bytes(bs, _plan_slots(bs, max_seq_len, chunk, max_slots), ranges))
+
+
+# What each plan buffer was last built with: data_ptr -> (batch size, max_slots, ranges).  The sections of a plan are
+# located from these three numbers and a launch has to be given the same ones (include/scratchpad_hip.h, "Plan and launch
+# must agree"): the range kernel would do nothing on a mismatch and the item kernels would read another section's words,
+# so decode_attention() compares them here, on the host, and raises before anything is launched.  Buffers that were not
+# built through decode_plan() (a copy made by hand) are not known and not checked.
+_BUILT_PLANS: dict = {}
+_BUILT_PLANS_MAX = 4096
 
 
 def decode_plan(plan: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int, chunk: int,
                 max_slots: Optional[int] = None, ranges: int = 0) -> None:
     """Fill `plan` (int32: [count, chunk, needed, keys | slot0[bs] | (request, split) x max_slots]) for this
     step's lengths.  `max_slots`: the item / partial-slot capacity the launches using this plan are given (default:
-    the static bound bs * ceil(max_seq_len / chunk)).
+    the static bound bs * ceil(max_seq_len / chunk); 0 with ranges > 0: no items, the plan serves range launches only).
     plan[2] > max_slots afterwards means the capacity was too small (see decode_plan_overflow).
-    `ranges` > 0 appends the range geometry ([pieces, R, 0, 0 | pos[bs + 1] | start[ranges]], include/scratchpad_hip.h)
-    for launches given the same `ranges`."""
+    `ranges` > 0 appends the range geometry ([pieces, R, ranges, bs | pos[bs + 1] | start[ranges]],
+    include/scratchpad_hip.h) for launches given the same `ranges`."""
     _gpu(plan, seq_lens)
     if plan.dtype != torch.int32 or seq_lens.dtype not in (torch.int32, torch.int64):
         raise RuntimeError("decode_plan: plan must be int32, seq_lens int32/int64")
     seq_lens = seq_lens.contiguous()
-    if max_slots is None:
-        max_slots = decode_plan_slots(seq_lens.shape[0], max_seq_len, chunk)
+    bs = seq_lens.shape[0]
+    max_slots = _plan_slots(bs, max_seq_len, chunk, max_slots)
     _check(load().sp_decode_plan(plan.data_ptr(), plan.numel() * 4, seq_lens.data_ptr(),
-                                 int(seq_lens.dtype == torch.int64), seq_lens.shape[0], max_seq_len,
+                                 int(seq_lens.dtype == torch.int64), bs, max_seq_len,
                                  chunk, max_slots, ranges, _stream()), "sp_decode_plan")
+    key = plan.data_ptr()
+    _BUILT_PLANS.pop(key, None)
+    if len(_BUILT_PLANS) >= _BUILT_PLANS_MAX:
+        del _BUILT_PLANS[next(iter(_BUILT_PLANS))]
+    _BUILT_PLANS[key] = (bs, max_slots, int(ranges))
 
 
 def decode_plan_overflow(header, max_slots: int) -> Optional[str]:
@@ -428,8 +446,9 @@ def decode_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
                      v_scale: Optional[float] = None, max_slots: Optional[int] = None, ranges: int = 0) -> None:
     """q, out: [bs, Hq, D] (row stride free); buffers [P+1, Hkv, D].  k_scale / v_scale: the
     scales the store divided by (None = 1).  With a plan: `max_slots` = the capacity the plan was built
-    for, `chunk` = the smallest split size the plan may carry (the kernels read the actual one from it), `ranges` =
-    the pieces its range section was built for (0: none; the workspace then holds max(max_slots, bs + ranges) slots)."""
+    for (0: it has no items), `chunk` = the smallest split size the plan may carry (the kernels read the actual one from
+    it), `ranges` = the pieces its range section was built for (0: none; the workspace then holds max(max_slots, bs +
+    ranges) slots).  Raises if they differ from what decode_plan() built this plan buffer with."""
     _gpu(out, q, k_buffer, v_buffer, req_to_token, req_pool_indices, seq_lens, workspace, kv_start, plan)
     bs, Hq, D = q.shape
     if q.stride(2) != 1 or q.stride(1) != D or out.stride(2) != 1 or out.stride(1) != D:
@@ -441,8 +460,16 @@ def decode_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
     req, seq, idx64 = _idx_pair(req_pool_indices, seq_lens)
     if kv_start is not None:
         kv_start = kv_start.to(seq.dtype).contiguous()
-    if max_slots is None:
-        max_slots = decode_plan_slots(bs, max_seq_len, chunk)
+    max_slots = _plan_slots(bs, max_seq_len, chunk, max_slots)
+    plan_bytes = 0
+    if plan is not None:
+        plan_bytes = plan.numel() * 4
+        built = _BUILT_PLANS.get(plan.data_ptr())
+        if built is not None and built != (bs, max_slots, int(ranges)):
+            raise RuntimeError(
+                f"decode_attention: the plan was built for (batch size, max_slots, ranges) = {built} and the launch is "
+                f"given {(bs, max_slots, int(ranges))}: the plan's sections are located from these numbers, so a launch "
+                "must pass the values its plan was built with (sp_decode_plan / sp_decode_attention)")
     _check(load().sp_decode_attention(
         out.data_ptr(), q.data_ptr(), k_buffer.data_ptr(), v_buffer.data_ptr(), req_to_token.data_ptr(),
         req_to_token.stride(0), req.data_ptr(), seq.data_ptr(), _ptr(kv_start), idx64, bs, Hq,
@@ -450,7 +477,7 @@ def decode_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
         1.0 if k_scale is None else float(k_scale), 1.0 if v_scale is None else float(v_scale),
         max_seq_len, chunk, max_slots, ranges if plan is not None else 0, workspace.data_ptr(),
         workspace.numel() * workspace.element_size(),
-        _ptr(plan), _dt(q), kv_dt, _stream()), "sp_decode_attention")
+        _ptr(plan), plan_bytes, _dt(q), kv_dt, _stream()), "sp_decode_attention")
 
 
 def extend_workspace_bytes(num_tokens: int, bs: int, Hq: int, D: int, dtype: torch.dtype) -> int:

@@ -143,17 +143,22 @@ class HipAttnBackend(AttentionBackend):
         self._graph_ws = None          # graph replay: ONE partials workspace / plan-buffer triple for all buckets
         self._graph_plans = None
         self._extend_plan = None       # int32 work list of the current extend step (sp_extend_plan)
-        self.replay_max_hint = None    # set by HipGraphRunner.replay for the next replay hook call
-        self._plan_checks = []         # (pinned header copy, event, max_slots) of plans not yet checked
+        self._plan_checks = []         # (pinned header copy, event, max_slots, step) of item plans not yet checked
+        self.plan_step = None          # the overlap worker's step number while its forward thread builds that step's plans
         self._plan_hosts = []          # pinned buffers + events to reuse
         self._plan_lock = threading.Lock()   # the overlap worker checks from the scheduler thread (tp_worker_client.py)
-        # Range geometry (include/scratchpad_hip.h, ABI 8): the pieces the step's keys are cut into, one wave per (piece,
-        # kv head), two workgroups per CU; 0 where the range kernel does not take the shape (fp32, groups wider than
-        # 16), and those launches use the plan's (request, split) items below.
+        # Range geometry (include/scratchpad_hip.h): the pieces the step's keys are cut into, one wave per (piece, kv head),
+        # two workgroups per CU; 0 where the range kernel does not take the shape (fp32, groups wider than 16).
         # SP_DECODE_RANGES=0 switches it off, =N forces N pieces (A/B runs).
         env = os.environ.get("SP_DECODE_RANGES", "")
         self.decode_ranges = int(env) if env else _native.decode_ranges(
             self.num_head, self.num_kv_head, self.head_dim, getattr(model_runner, "dtype", torch.bfloat16), self.kv_dtype)
+        # The (request, split) items are planned only where a launch of this model can read them (round 6; the reference's
+        # init_forward_metadata computes only what its one kernel reads, triton_backend.py:48-68): a shape the range kernel
+        # refuses, or a layer with a logit soft-cap (Gemma-2 style; no Llama-3 / Mllama layer has one).  Without them a
+        # plan is the range section alone and nothing of a step depends on the host's bound on sum(seq_lens).
+        layers = [m for m in getattr(model_runner, "model", nn.Module()).modules() if isinstance(m, RadixAttention)]
+        self.plan_items = self.decode_ranges <= 0 or any(m.logit_cap > 0 for m in layers)
 
     # ---------------------------------------------------------------- launch planning
     def _head_groups(self, dtype: torch.dtype) -> int:
@@ -164,38 +169,14 @@ class HipAttnBackend(AttentionBackend):
             hh *= 2
         return self.num_kv_head // hh
 
-    # a batch counts as near-uniform when its longest request is at most this many times its mean length
-    UNIFORM_RATIO = 1.35
-    uniform_policy = os.environ.get("SP_DECODE_UNIFORM", "1") != "0"      # (0: A/B runs without the hint)
-
-    def _wg_groups(self) -> int:
-        """workgroups per (request, split) item of the matrix-core decode kernel: the kv heads in fours where they
-        divide by four (a wave per head), else one workgroup per kv head"""
-        return self.num_kv_head // 4 if self.num_kv_head % 4 == 0 else self.num_kv_head
-
-    def _plan_chunk(self, kv_tokens: int, dtype: torch.dtype, bs: Optional[int] = None,
-                    max_hint: Optional[int] = None) -> int:
-        """Split size of a decode step from what the host knows: sum(seq_lens) (a bound), the batch size and - where
-        the scheduler tracks it - an upper bound of the longest request (`max_hint`, advisory).
-        Default: about one item per CU, between MIN_CHUNK and MAX_CHUNK.  A NEAR-UNIFORM batch (max <= UNIFORM_RATIO x
-        mean) that still has a workgroup per CU when nothing is split is NOT split: requests of equal length gain no
-        balance from it, and whole requests need no partials and no merge.  Measured (round 4,
-        profiles/r04_decode_variants.txt section 6): kernel alone, bs 256: ctx 1064 193 vs 207 us, ctx 4136 723 vs 768;
-        bs 128: 99 vs 105 and 351 vs 368; in the model ctx 1024 19.89 vs 19.50 k tokens/s, ctx 4096 8.69 vs 8.57 k
-        (attention 6.16 TB/s = 77 % of peak).  Below one workgroup per CU it loses badly (bs 64: 74 vs 50 us) and the
-        default stays; evening the default size out over the longest request's splits (5 x 832 instead of 4 x 1024 + 40)
-        was tried for that case and measured 2 - 4 % SLOWER in the model, so it is not done."""
+    def _plan_chunk(self, kv_tokens: int, dtype: torch.dtype) -> int:
+        """Split size of the (request, split) items from the host's bound on sum(seq_lens): about one item per CU, between
+        MIN_CHUNK and MAX_CHUNK.  (Until round 5 a near-uniform batch, known from an advisory hint of the longest request,
+        was left unsplit; the range geometry made that the default path's property - equal lengths are cut between
+        requests - and the hint left with it: profiles/NOTES.md, "Round 6".)"""
         groups = self._head_groups(dtype)
         chunk = _pow2_floor(max(kv_tokens, 1) * groups // self.TARGET_ITEMS)
-        chunk = max(self.MIN_CHUNK, min(self.MAX_CHUNK, chunk))
-        if not max_hint or not bs or not self.uniform_policy:
-            return chunk
-        mean = kv_tokens / bs
-        if max_hint < mean or max_hint > self.UNIFORM_RATIO * mean:      # no usable hint / a ragged batch
-            return chunk
-        if bs * self._wg_groups() < self.TARGET_ITEMS:                   # unsplit would leave CUs without work
-            return chunk
-        return max(chunk, -(-int(max_hint) // 64) * 64)
+        return max(self.MIN_CHUNK, min(self.MAX_CHUNK, chunk))
 
     def _ensure_workspace(self, nbytes: int) -> torch.Tensor:
         if self._workspace.numel() < nbytes:
@@ -203,6 +184,9 @@ class HipAttnBackend(AttentionBackend):
         return self._workspace
 
     def _graph_slots(self, bs: int) -> int:
+        """(request, split) items a captured launch of bucket `bs` covers; 0 where no launch of this model reads items"""
+        if not (self.plan_items or self._ranges_for(bs, self.max_context_len) <= 0):
+            return 0
         by_len = bs * -(-self.max_context_len // self.MIN_CHUNK)
         return min(by_len, max(self.GRAPH_SLOTS_FLOOR, self.GRAPH_SLOTS_PER_REQ * bs) + bs)
 
@@ -216,31 +200,37 @@ class HipAttnBackend(AttentionBackend):
         """pieces of the range geometry for a step (0: its line does not fit the plan's int32 positions)"""
         return self.decode_ranges if bs * (max_len + _native.RANGE_REQUEST_COST) < 2 ** 31 - 1 else 0
 
-    def _build_plans(self, plans, bs, windows, max_len, max_slots=None, hints=(None, None, None), ranges=None):
-        """One split plan per kv window (self-attention lens; encoder lens for cross-attention - the
-        reference keeps two flashinfer wrappers for the same reason, flashinfer_backend.py:121-131; the
-        sliding-window layers' lens).  windows: per plan (lens tensor or None, host bound on their sum).
-        Built once per step, read by every layer's launch.  Each plan carries its own split size; returns
-        per plan (tensor, max_slots, smallest chunk, ranges) and the largest max_slots (what the workspace must hold).
-        Every plan also carries the range geometry (`ranges` pieces) where the backend's shape has one."""
+    def _build_plans(self, plans, bs, windows, max_len, max_slots=None, ranges=None):
+        """One plan per kv window (self-attention lens; encoder lens for cross-attention - the reference keeps two
+        flashinfer wrappers for the same reason, flashinfer_backend.py:121-131; the sliding-window layers' lens).
+        windows: per plan (lens tensor or None, host bound on their sum).  Built once per step, read by every layer's
+        launch.  A plan carries the range geometry (`ranges` pieces) where the backend's shape has one, and the (request,
+        split) items - with their own split size - only where a launch can need them (self.plan_items, or a step whose
+        line does not fit the range section).  Returns per plan (tensor, max_slots, smallest chunk, ranges) - the three
+        numbers every launch on that plan is given - and the partial slots the workspace must hold."""
         out, need_slots = [], 1
         if ranges is None:
             ranges = self._ranges_for(bs, max_len)
+        with_items = self.plan_items or ranges <= 0
         for i, (lens, kv_tokens) in enumerate(windows):
             if lens is None:
                 out.append(None)
                 continue
-            chunk = self._plan_chunk(kv_tokens, self.kv_dtype, bs, hints[i])
-            if max_slots is None:          # eager: exactly what this step can need
-                slots = max(1, _native.decode_plan_slots(bs, max_len, chunk, kv_tokens))
-            else:                          # graph replay: the captured launch's capacity is fixed
-                slots = max_slots
-                chunk = self._fit_chunk(chunk, bs, kv_tokens, max_len, slots)
+            if not with_items:
+                chunk, slots = self.MIN_CHUNK, 0
+            else:
+                chunk = self._plan_chunk(kv_tokens, self.kv_dtype)
+                if max_slots is None:          # eager: exactly what this step can need
+                    slots = max(1, _native.decode_plan_slots(bs, max_len, chunk, kv_tokens))
+                else:                          # graph replay: the captured launch's capacity is fixed
+                    slots = max_slots
+                    chunk = self._fit_chunk(chunk, bs, kv_tokens, max_len, slots)
             need = _native.decode_plan_bytes(bs, max_len, chunk, slots, ranges) // 4
             if plans[i].numel() < need:
                 plans[i] = torch.empty(need, dtype=torch.int32, device=self.device)
             _native.decode_plan(plans[i], lens, max_len, chunk, slots, ranges)
-            self._watch_plan(plans[i], slots)
+            if with_items:
+                self._watch_plan(plans[i], slots)
             # third field: the smallest split size this plan buffer may carry when the launch runs - the
             # step's own chunk (eager), MIN_CHUNK under graph replay (a later step's plan may use any size)
             out.append((plans[i], slots, chunk if max_slots is None else self.MIN_CHUNK, ranges))
@@ -251,30 +241,40 @@ class HipAttnBackend(AttentionBackend):
     def _watch_plan(self, plan: torch.Tensor, slots: int) -> None:
         """The plan kernel records how many items the device-side lengths need; more than the launch covers means
         splits were dropped (wrong logits).  The header comes back through a 16-byte asynchronous copy: earlier
-        plans whose copy has landed are checked here, this one at the next plan or in check_plans()."""
-        self.check_plans(wait=len(self._plan_checks) >= 64)      # (a bound on the copies in flight)
+        plans whose copy has landed are checked here, this one at the next plan or in check_plans().
+        With a `plan_step` (the overlap worker sets one per step, tp_worker_client.py) nothing is checked HERE: this is
+        the forward thread, and an error raised in it would end the thread instead of reaching the scheduler with the
+        step it belongs to - the entry carries the step and check_plans(upto=step) on the scheduler's side
+        reports it when that step's results are resolved."""
+        if self.plan_step is None:
+            self.check_plans(wait=len(self._plan_checks) >= 64)      # (a bound on the copies in flight)
         with self._plan_lock:
             host, ev = self._plan_hosts.pop() if self._plan_hosts else (
                 torch.empty(_native.PLAN_HEADER_WORDS, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
         host.copy_(plan[:_native.PLAN_HEADER_WORDS], non_blocking=True)
         ev.record()
         with self._plan_lock:
-            self._plan_checks.append((host, ev, slots))
-        if self.strict_plan_check:
+            self._plan_checks.append((host, ev, slots, self.plan_step))
+        if self.strict_plan_check and self.plan_step is None:
             self.check_plans(wait=True)
 
-    def check_plans(self, wait: bool = True) -> None:
+    def check_plans(self, wait: bool = True, upto: Optional[int] = None) -> None:
         """Raise RuntimeError if a decode plan built so far was cut short.  wait=False looks only at header copies
-        that have already completed (no synchronisation)."""
+        that have already completed (no synchronisation).  upto=N: only the plans of steps <= N (entries tagged through
+        `plan_step`); later steps' entries stay for their own check."""
         pending = []
         err = None
         with self._plan_lock:
             checks, self._plan_checks = self._plan_checks, []
-        for host, ev, slots in checks:
+        for entry in checks:
+            host, ev, slots, step = entry
+            if upto is not None and step is not None and step > upto:
+                pending.append(entry)
+                continue
             if wait:
                 ev.synchronize()
             elif not ev.query():
-                pending.append((host, ev, slots))
+                pending.append(entry)
                 continue
             err = err or _native.decode_plan_overflow(host.tolist(), slots)
             with self._plan_lock:
@@ -315,11 +315,8 @@ class HipAttnBackend(AttentionBackend):
             enc = forward_batch.encoder_lens if self.is_encoder_decoder else None
             enc_sum = sum(forward_batch.encoder_lens_cpu) if forward_batch.encoder_lens_cpu else None
             self._window = self._window_of(forward_batch.seq_lens)
-            hint = (max_len if forward_batch.seq_lens_cpu is not None
-                    else getattr(forward_batch, "seq_lens_max_hint", None))
             plans, slots = self._build_plans(self._plans, bs, self._windows(
-                bs, forward_batch.seq_lens, forward_batch.seq_lens_sum, enc, enc_sum), max_len,
-                hints=(hint, enc_max or None, None))
+                bs, forward_batch.seq_lens, forward_batch.seq_lens_sum, enc, enc_sum), max_len)
             ws = self._ensure_workspace(_native.decode_workspace_bytes(bs, self.num_head, self.v_head_dim, max_len,
                                                                        self.MIN_CHUNK, slots))
             self.forward_metadata = (self.MIN_CHUNK, max_len, ws, plans)
@@ -348,13 +345,12 @@ class HipAttnBackend(AttentionBackend):
         split size is not part of the capture (it travels in the plan), so the scratch is bounded by the slots
         of the largest bucket whatever the model's context length is."""
         self.cuda_graph_max_seq_len = self.max_context_len
-        slots = self._graph_slots(max_bs)
-        self._graph_ws = torch.empty(_native.decode_workspace_bytes(max_bs, self.num_head, self.v_head_dim,
-                                                                    self.cuda_graph_max_seq_len, self.MIN_CHUNK, slots,
-                                                                    self._ranges_for(max_bs, self.cuda_graph_max_seq_len)),
-                                     dtype=torch.uint8, device=self.device)
         # the piece count is launch geometry: ONE value for every bucket, decided for the largest (a smaller bucket's line fits too)
         self._graph_ranges = ranges = self._ranges_for(max_bs, self.cuda_graph_max_seq_len)
+        slots = self._graph_slots(max_bs)
+        self._graph_ws = torch.empty(_native.decode_workspace_bytes(max_bs, self.num_head, self.v_head_dim,
+                                                                    self.cuda_graph_max_seq_len, self.MIN_CHUNK, slots, ranges),
+                                     dtype=torch.uint8, device=self.device)
         n = _native.decode_plan_bytes(max_bs, self.cuda_graph_max_seq_len, self.MIN_CHUNK, slots, ranges) // 4
         self._graph_plans = [torch.empty(n, dtype=torch.int32, device=self.device) for _ in range(3)]
         self._graph_max_bs = max_bs
@@ -366,12 +362,11 @@ class HipAttnBackend(AttentionBackend):
         """attention scratch held for graph replay (workspace + plan buffers), all buckets together"""
         return self._graph_ws.numel() + sum(p.numel() * 4 for p in self._graph_plans)
 
-    def _graph_metadata(self, bs, seq_lens, seq_lens_sum, encoder_lens, max_hint=None):
+    def _graph_metadata(self, bs, seq_lens, seq_lens_sum, encoder_lens):
         assert bs <= self._graph_max_bs
         plans, _ = self._build_plans(self._graph_plans, bs, self._windows(bs, seq_lens, seq_lens_sum, encoder_lens,
                                                                           None),
-                                     self.cuda_graph_max_seq_len, self._graph_slots(bs), hints=(max_hint, None, None),
-                                     ranges=self._graph_ranges)
+                                     self.cuda_graph_max_seq_len, self._graph_slots(bs), ranges=self._graph_ranges)
         # MIN_CHUNK: the smallest split size a replayed plan may carry (the merge launch is always captured)
         self.forward_metadata = (self.MIN_CHUNK, self.cuda_graph_max_seq_len, self._graph_ws, plans)
 
@@ -391,11 +386,7 @@ class HipAttnBackend(AttentionBackend):
         # (triton_backend.py:103-113, flashinfer_backend.py:330-373).  The split size is chosen HERE, per
         # step, from seq_lens_sum (it is plan data, not launch geometry).
         self._window = self._window_of(seq_lens[:bs], self._graph_window, bs)
-        # the advisory bound of the longest request (ForwardBatch.seq_lens_max_hint): the hook's signature is the
-        # reference's, so the graph runner leaves it in replay_max_hint just before the call
-        hint = int(seq_lens_cpu.max()) if seq_lens_cpu is not None else self.replay_max_hint
-        self.replay_max_hint = None
-        self._graph_metadata(bs, seq_lens[:bs], seq_lens_sum, None if encoder_lens is None else encoder_lens[:bs], hint)
+        self._graph_metadata(bs, seq_lens[:bs], seq_lens_sum, None if encoder_lens is None else encoder_lens[:bs])
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1  # padded rows attend to the dummy slot 0 only (triton_backend.py:115-116)

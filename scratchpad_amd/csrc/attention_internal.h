@@ -39,7 +39,8 @@ struct DecodeArgs {
   // launch has no key count and streams only when the threshold is 0.
   int nt_min_keys;
   // RANGE geometry (the plan's second section, sp_decode_plan with ranges > 0; decode_mfma.hip's range kernel):
-  // [rcount, R, 0, 0 | pos[bs + 1] | start[ranges]].  The step's keys, request after request in batch order, form one
+  // [rcount, R, ranges, bs | pos[bs + 1] | start[ranges]].  Words 2 and 3 say what the section was BUILT for (ABI 9): a
+  // launch given another piece count or batch size finds the mismatch and does nothing (range_plan_matches).  The step's keys, request after request in batch order, form one
   // line on which request b takes pos[b] .. pos[b] + len_b and then kRangeReqCost empty positions (what a request costs
   // a wave beyond its keys); the line is cut into rcount <= ranges pieces of R positions, piece j is the work of
   // one wave per kv head, start[j] = the first request with a key at or after position j * R, or -1 if piece j
@@ -55,8 +56,17 @@ static constexpr int kRangeHdr = 4;  // int32 words in front of pos[]
 static constexpr int kRangeReqCost = 16;   // positions a request takes on the line beyond its keys
 static constexpr int kRangeMin = 64;       // shortest piece (keys): one index register, four tiles
 
-// words of a plan's (request, split) section; the range section follows it
-__host__ __device__ inline int64_t plan_item_words(int bs, int64_t max_slots) { return kPlanHdr + (int64_t)bs + 2 * max_slots; }
+// words of a plan's (request, split) section; the range section follows it.  max_slots = 0 (ABI 9): a plan built for
+// range launches only - the header alone, no slot0[] and no items
+__host__ __device__ inline int64_t plan_item_words(int bs, int64_t max_slots) {
+  return max_slots > 0 ? kPlanHdr + (int64_t)bs + 2 * max_slots : kPlanHdr;
+}
+
+// the range section was built for this launch's piece count and batch size (its words 2, 3): everything the range and
+// merge kernels index with `ranges` and `bs` - pos[bs + 1], start[ranges], slot b + j - is only then what they assume
+__device__ __forceinline__ bool range_plan_matches(const int32_t* rplan, int ranges, int bs) {
+  return rplan[2] == ranges && rplan[3] == bs;
+}
 
 // request b of a range launch: its partial count and first slot (n <= 1: written straight to the output)
 __device__ __forceinline__ void range_request(const int32_t* rplan, int b, int& len, int& nsplit, int& slot0) {
@@ -159,7 +169,10 @@ int run_decode_mfma(const DecodeArgs& a, int head_dim, int dtype, hipStream_t st
 // heads per wave-load: the largest power of two <= rows-per-load that divides Hkv
 int decode_heads_per_load_shift(int num_kv_heads, int head_dim, int dtype, int* head_groups);
 
-// test / tuning hooks behind sp_debug_set
+// test / tuning hooks behind sp_debug_set / sp_debug_get
+// which kernel the last sp_decode_attention call launched: 0 none yet, 1 the VALU kernel, 2 the matrix-core kernel on
+// (request, split) items, 3 the range kernel
+extern int g_decode_last_kernel;
 void set_decode_kernel(int which);
 void set_decode_nt_min_mb(int mb);
 void set_decode_ranges(int n);

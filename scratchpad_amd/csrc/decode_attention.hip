@@ -296,6 +296,7 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
   const int lane = threadIdx.x & 63;
   const int b = pair / a.Hq, h = pair - b * a.Hq;
   if (a.rplan) {               // range geometry: the request's pieces from its place on the line
+    if (!range_plan_matches(a.rplan, a.ranges, a.bs)) return;   // (as the range kernel: not this launch's plan)
     int len, nsplit, slot0;
     range_request(a.rplan, b, len, nsplit, slot0);
     if (len <= 0 || nsplit <= 1) return;
@@ -316,7 +317,9 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a) {
   else decode_merge_rows<Tag, D, 1>(a, b, hs, lane, nsplit, slot0);
 }
 
-// Build the step's split plan: plan[0] = number of non-empty (request, split) items the plan lists, plan[1] = chunk,
+// Build the step's plan.  max_items = 0 (ABI 9: the caller's launches all take the range geometry): the item section is
+// its header alone, [0, chunk, 0, 0], and only the range section behind it is built.  Otherwise the (request, split) items:
+// plan[0] = number of non-empty (request, split) items the plan lists, plan[1] = chunk,
 // plan[2] = the number the lengths NEED (> plan[0]: items were cut at max_items because the host's bound on
 // sum(seq_lens) does not hold - an error the host reports, sp_decode_plan), plan[3] = 0,
 // plan[4 + b] = first partial slot of request b (exclusive scan of its split count), the items (b, c) from
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ 
   if (threadIdx.x == 0) s_keys = 0;
   int32_t* items = plan + kPlanHdr + bs;
   // pass -1: slot0[b]; pass 0: full splits; passes 1..4: ragged tails by length class
-  for (int pass = -1; pass < 5; ++pass) {
+  for (int pass = -1; pass < 5 && max_items > 0; ++pass) {
     if (pass <= 0) {
       __syncthreads();
       if (threadIdx.x == 0 && pass == -1) s_base = 0;
@@ -380,10 +383,10 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ 
     }
   }
   if (threadIdx.x == 0) {
-    plan[0] = min(s_base, max_items);
+    plan[0] = max_items > 0 ? min(s_base, max_items) : 0;
     plan[1] = chunk;
-    plan[2] = s_base;
-    plan[3] = (int)min(s_keys, 0x7fffffffULL);     // keys this step gathers per kv head (DecodeArgs::nt_min_keys)
+    plan[2] = max_items > 0 ? s_base : 0;
+    plan[3] = max_items > 0 ? (int)min(s_keys, 0x7fffffffULL) : 0;   // keys this step gathers per kv head (DecodeArgs::nt_min_keys)
   }
   if (ranges <= 0) return;
   // ---- the range section (DecodeArgs::rplan): pos[] = exclusive scan of len + kRangeReqCost over the non-empty requests
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(int32_t* __restrict__ 
   const int rcount = T > 0 ? (T + R - 1) / R : 0;
   if (threadIdx.x == 0) {
     pos[bs] = T;
-    rp[0] = rcount; rp[1] = R; rp[2] = 0; rp[3] = 0;
+    rp[0] = rcount; rp[1] = R; rp[2] = ranges; rp[3] = bs;     // (2, 3: what the section was built for, range_plan_matches)
   }
   __syncthreads();                                    // pos[] is read back below
   // last request whose position is <= g (empty requests share the position of the next non-empty one, which is the last
@@ -451,14 +454,18 @@ static int launch_decode(const DecodeArgs& a, hipStream_t st) {
   typedef DecodeCfg<Tag, D, G> C;
   const size_t lds = (size_t)C::kLdsFloats * sizeof(float);
   const unsigned grid = (unsigned)((a.plan ? (int64_t)a.max_slots : (int64_t)a.bs * a.num_splits) * a.head_groups);
-  static bool attr_set = false;  // benign race: idempotent
-  if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)decode_attn_kernel<Tag, D, G>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  if (lds > 64 * 1024) {         // the limit is the device's: raised once per device of the process
+    static PerDevice<int> raised;
+    int ok = 0;
+    raised.get(ok, [&](int) {
+      return hipFuncSetAttribute((const void*)decode_attn_kernel<Tag, D, G>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : 0;
+    });
+    if (!ok) return SP_ERR_LAUNCH;
   }
   decode_attn_kernel<Tag, D, G><<<dim3(grid), 256, lds, st>>>(a);
   SP_LAUNCH_CHECK();
+  g_decode_last_kernel = 1;
   if (a.num_splits > 1) {
     decode_merge_kernel<Tag, D><<<dim3((a.bs * a.Hq + 3) / 4), 256, 0, st>>>(a);
     SP_LAUNCH_CHECK();
@@ -543,6 +550,7 @@ void set_decode_nt_min_mb(int mb) { g_decode_nt_min_mb = mb == -2 ? kDecodeNtMin
 // carries one, -1 = default (they do wherever the range kernel applies)
 static int g_decode_ranges = -1;
 void set_decode_ranges(int n) { g_decode_ranges = n < 0 ? -1 : n; }
+int g_decode_last_kernel = 0;    // sp_debug_get("decode_last_kernel"), attention_internal.h
 static int decode_kernel_choice(int group, int dtype) {
   if (dtype == SP_F32 || group > 16) return 1;
   if (g_decode_kernel_forced == 1 || g_decode_kernel_forced == 2) return g_decode_kernel_forced;
@@ -614,7 +622,7 @@ static inline bool range_line_fits(int batch_size, int64_t max_seq_len) {
 }
 
 extern "C" size_t sp_decode_plan_bytes(int batch_size, int64_t max_slots, int ranges) {
-  if (batch_size <= 0 || max_slots <= 0) return 16;
+  if (batch_size <= 0 || max_slots < 0 || (max_slots == 0 && ranges <= 0)) return 16;
   int64_t words = plan_item_words(batch_size, max_slots);
   if (ranges > 0) words += kRangeHdr + (int64_t)batch_size + 1 + ranges;
   return (size_t)words * sizeof(int32_t);
@@ -629,8 +637,9 @@ extern "C" int sp_decode_plan(int32_t* plan, size_t plan_bytes, const void* seq_
                               int batch_size, int64_t max_seq_len, int chunk, int64_t max_slots,
                               int ranges, void* stream) {
   SP_CHECK_ARG(plan && seq_lens && batch_size >= 0 && chunk >= 4 && chunk % 4 == 0);
-  SP_CHECK_ARG(max_seq_len >= 0 && max_seq_len <= 0x7fffffffLL && max_slots > 0 && max_slots <= 0x3fffffffLL);
+  SP_CHECK_ARG(max_seq_len >= 0 && max_seq_len <= 0x7fffffffLL && max_slots >= 0 && max_slots <= 0x3fffffffLL);
   SP_CHECK_ARG(ranges >= 0 && ranges <= 65536);
+  SP_CHECK_ARG(max_slots > 0 || ranges > 0);           // (a plan with neither section plans nothing)
   SP_CHECK_ARG(ranges == 0 || range_line_fits(batch_size, max_seq_len));
   if (plan_bytes < sp_decode_plan_bytes(batch_size, max_slots, ranges)) return SP_ERR_WORKSPACE;
   decode_plan_kernel<<<dim3(1), 256, 0, (hipStream_t)stream>>>(plan, seq_lens, idx64, batch_size,
@@ -647,8 +656,8 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
                                    int64_t q_stride, int64_t out_stride, int64_t kv_buffer_stride,
                                    float sm_scale, float logit_cap, float k_scale, float v_scale,
                                    int64_t max_seq_len, int chunk, int64_t max_slots, int ranges,
-                                   void* workspace, size_t workspace_bytes, const int32_t* plan, int dtype,
-                                   int kv_dtype, void* stream) {
+                                   void* workspace, size_t workspace_bytes, const int32_t* plan, size_t plan_bytes,
+                                   int dtype, int kv_dtype, void* stream) {
   SP_CHECK_ARG(out && q && k_buffer && v_buffer && req_to_token && req_pool_indices && seq_lens);
   SP_CHECK_ARG(batch_size >= 0 && num_q_heads > 0 && num_kv_heads > 0 && head_dim > 0);
   SP_CHECK_ARG(num_q_heads % num_kv_heads == 0 && max_seq_len >= 0);
@@ -677,8 +686,12 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
   // (the kernels read the actual one from the plan; the host value only decides whether a merge can be needed)
   const int64_t S = num_splits_for(max_seq_len, chunk);
   if (max_seq_len > 0x7fffffffLL) return SP_ERR_INVALID_ARG;
+  SP_CHECK_ARG(ranges >= 0 && ranges <= 65536);
   if (!plan) max_slots = (int64_t)batch_size * S;        // static (request, split) grid
-  SP_CHECK_ARG(max_slots > 0 && max_slots <= 0x3fffffffLL);
+  SP_CHECK_ARG(max_slots >= 0 && max_slots <= 0x3fffffffLL);
+  // the plan buffer holds what (batch_size, max_slots, ranges) say it holds: the sections are located from them
+  if (plan && plan_bytes < sp_decode_plan_bytes(batch_size, max_slots, ranges)) return SP_ERR_WORKSPACE;
+  SP_CHECK_ARG(!plan || max_slots > 0 || ranges > 0);
   DecodeArgs a;
   a.out = out; a.q = q; a.kbuf = (const char*)k_buffer; a.vbuf = (const char*)v_buffer;
   a.r2t = req_to_token; a.r2t_stride = req_to_token_stride; a.req_idx = req_pool_indices;
@@ -701,7 +714,6 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
   // The range geometry (DecodeArgs::rplan) where the plan carries it and the range kernel takes the launch: the default
   // configuration (16-bit pool, always-streaming gathers, no soft-cap) on a shape sp_decode_ranges() accepts.  Everything
   // else uses the plan's (request, split) items.
-  SP_CHECK_ARG(ranges >= 0 && ranges <= 65536);
   a.rplan = nullptr; a.ranges = 0;
   if (plan && ranges > 0 && g_decode_ranges != 0 && logit_cap <= 0.f && a.nt_min_keys == 0 &&
       range_line_fits(batch_size, max_seq_len) && out_stride % 4 == 0 &&
@@ -711,6 +723,9 @@ extern "C" int sp_decode_attention(void* out, const void* q, const void* k_buffe
     max_slots = (int64_t)batch_size + ranges;       // partial slots of the range geometry: slot = request + piece
     a.max_slots = (int)max_slots;
   }
+  // a plan built without the item section (max_slots = 0) serves range launches only: this one is not (soft-cap, fp32, a
+  // shape or alignment the range kernel refuses, sp_debug_set("decode_ranges", 0)) - the caller must plan the items too
+  if (!a.rplan && max_slots <= 0) return SP_ERR_INVALID_ARG;
   if (S > 1 || a.rplan) {       // (a range launch splits a request wherever a piece ends)
     const size_t need = sp_decode_attention_workspace_bytes(max_slots, num_q_heads, head_dim);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) return SP_ERR_WORKSPACE;

@@ -113,12 +113,14 @@ struct DmCfg {
   static constexpr int kMergeBytes = WAVES * 16 * (D + 2) * 4;
   static constexpr int kLdsBytes = kStageBytes > kMergeBytes ? kStageBytes : kMergeBytes;
 };
-// range kernel: LDS per wave in which the partials of cut requests wait for the end of the piece: 4 records at G = 4,
-// D = 128 (a piece cuts at most two requests), 2 at G = 8, 1 at G = 16.  With the 32 KiB of tiles at D = 128 that is
-// 64.6 KiB per workgroup: the two workgroups per CU a range launch runs (decode_mfma_ranges) fit.
+// range kernel: LDS per wave in which the partials of cut requests wait for the end of the piece.  A record is G rows of
+// D floats + 16 log-sum-exps + the slot: 2128 B at G = 4, D = 128, so the 8352 B below hold 3 records there, 2 at G = 8
+// (4176 B each), 1 at G = 16 - a piece cuts at most two requests, so two are ever in use; a record that does not fit is
+// stored at once.  With the 32 KiB of tiles at D = 128 that is 64.6 KiB per workgroup: the two workgroups per CU a range
+// launch runs (decode_mfma_ranges) fit.
 static constexpr int kDmParkWaveB = 2 * (8 * 128 * 4 + 64 + 16);
-// ... and on a byte pool, where a tile in flight is half the bytes, THREE workgroups per CU: 2 records at G = 4, 1 at
-// G = 8, none (stored at once) at G = 16; 49 KiB per workgroup at D = 128
+// ... and on a byte pool, where a tile in flight is half the bytes, THREE workgroups per CU: 4256 B per wave = 2 records
+// at G = 4, 1 at G = 8, none (stored at once) at G = 16; 49 KiB per workgroup at D = 128
 static constexpr int kDmParkWaveB8 = 2 * (4 * 128 * 4 + 64 + 16);
 
 // The state and the tile arithmetic of ONE wave, shared by the two kernels below: the gather of a 16-key tile into
@@ -490,6 +492,7 @@ __global__ __launch_bounds__(256, SP_DEC_WAVES) void decode_mfma_range_kernel(De
   const int hk = gw - piece * a.Hkv;
   const int32_t* rp = a.rplan;
   if (piece >= a.ranges) return;                            // (the launch's last workgroup when ranges * Hkv is not in fours)
+  if (!range_plan_matches(rp, a.ranges, a.bs)) return;      // a plan built for another launch: nothing is read or written
   if (piece >= rp[0]) return;
   const int R = rp[1];
   const int32_t* posv = rp + kRangeHdr;
@@ -647,9 +650,11 @@ static int launch_dm_kv(const DecodeArgs& a, hipStream_t st) {
   const bool hpw = a.Hkv % 4 == 0 && a.o_stride % 4 == 0;
   if (a.rplan) {                                  // the range geometry: one wave per (piece, kv head)
     if (a.o_stride % 4 || a.ranges <= 0 || a.logit_cap > 0.f || a.nt_min_keys != 0) return SP_ERR_INVALID_ARG;
+    // (the kernel's dynamic-LDS limit on THIS device was raised by dm_range_workgroups: run_decode_mfma asked it)
     const unsigned grid = (unsigned)(((int64_t)a.ranges * a.Hkv + 3) / 4);
     decode_mfma_range_kernel<Tag, D, KV8><<<dim3(grid), 256, dm_range_lds<D, KV8>(), st>>>(a);
     SP_LAUNCH_CHECK();
+    g_decode_last_kernel = 3;
     return SP_OK;
   }
   // planned: one workgroup per (plan item, head group), the launch covers max_slots items (the surplus
@@ -663,6 +668,7 @@ static int launch_dm_kv(const DecodeArgs& a, hipStream_t st) {
     decode_mfma_kernel<Tag, D, false, KV8><<<dim3(grid), 256, C::kLdsBytes, st>>>(a);
   }
   SP_LAUNCH_CHECK();
+  g_decode_last_kernel = 2;
   return SP_OK;
 }
 
@@ -694,11 +700,13 @@ int run_decode_mfma(const DecodeArgs& a, int head_dim, int dtype, hipStream_t st
 // (6.6 TB/s).  0: the shape is not the range kernel's (16-bit q, G <= 16, D in {64, 128}).
 template <typename Tag, int D, bool KV8>
 static int dm_range_workgroups() {
-  static int workgroups = 0;
-  if (!workgroups) {
-    int dev = 0, per_cu = 0;
+  // per device of the process: the attribute below is the device's, and so is the occupancy
+  static PerDevice<int> cache;
+  int workgroups = 0;
+  cache.get(workgroups, [](int dev) {
+    int per_cu = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     if (dm_range_lds<D, KV8>() > 64 * 1024 &&
         hipFuncSetAttribute((const void*)decode_mfma_range_kernel<Tag, D, KV8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             dm_range_lds<D, KV8>()) != hipSuccess)
@@ -707,8 +715,8 @@ static int dm_range_workgroups() {
             hipSuccess || per_cu < 1)
       return 0;
     const int want = KV8 ? 3 : 2;
-    workgroups = (per_cu < want ? per_cu : want) * prop.multiProcessorCount;
-  }
+    return (per_cu < want ? per_cu : want) * prop.multiProcessorCount;
+  });
   return workgroups;
 }
 

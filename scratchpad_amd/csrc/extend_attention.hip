@@ -162,6 +162,7 @@ extern "C" int sp_debug_get(const char* key) {
   if (!key) return -1;
   if (!strcmp(key, "w64_descriptor_patched")) return w64_descriptor_patched();
   if (!strcmp(key, "extend_last_kernel")) return g_extend_last_kernel;
+  if (!strcmp(key, "decode_last_kernel")) return g_decode_last_kernel;
   return -1;
 }
 

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/scratchpad_hip.h"
 
 namespace sp {
@@ -200,6 +202,31 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ int64_t load_idx(const void* p, int i, int idx64) {
   return idx64 ? ((const int64_t*)p)[i] : (int64_t)((const int32_t*)p)[i];
 }
+
+// Host-side state that belongs to ONE device of the process (a kernel's dynamic-LDS limit raised by hipFuncSetAttribute,
+// the occupancy the runtime reports for it): a slot per device id, filled once under a lock, by whichever thread gets
+// there first - the overlap worker's forward thread and the scheduler thread both launch.  A function-local
+// `static` flag would serve the device that was current on first use only.
+template <typename V>
+struct PerDevice {
+  static constexpr int kMaxDevices = 64;
+  std::mutex mu;
+  bool known[kMaxDevices] = {};
+  V value[kMaxDevices] = {};
+  // value of the current device; `make(dev)` runs once per device.  Returns false when no device is current
+  template <typename F>
+  bool get(V& out, F make) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!known[dev]) {
+      value[dev] = make(dev);
+      known[dev] = true;
+    }
+    out = value[dev];
+    return true;
+  }
+};
 
 }  // namespace sp
 

@@ -106,11 +106,6 @@ class ModelWorkerBatch:
     # stand-in for the (un-hosted) vision tower: projected + flattened vision states of the requests
     # whose encoder is not cached, [sum(encoder_lens_need), hidden] (mllama.py:966-979)
     encoder_states: Optional[torch.Tensor] = None
-    # ADVISORY (no reference counterpart; the reference declares seq_lens_cpu for this and never fills it,
-    # schedule_batch.py:1407-1408): a host-side upper bound of max(seq_lens), kept by ScheduleBatch the way it keeps
-    # seq_lens_sum.  The attention backend uses it only to CHOOSE the decode split size (a batch of near-equal
-    # lengths is not split); a wrong or missing value costs speed, never results.
-    seq_lens_max_hint: Optional[int] = None
 
 
 @dataclass
@@ -168,7 +163,6 @@ class ForwardBatch:
     padded_static_len: int = -1
     mrope_positions: torch.Tensor = None
     # ---- not in the reference (kept behind its fields)
-    seq_lens_max_hint: Optional[int] = None          # advisory, see ModelWorkerBatch
     encoder_states: Optional[torch.Tensor] = None    # see ModelWorkerBatch
 
     @classmethod
@@ -187,7 +181,7 @@ class ForwardBatch:
             out_cache_loc=batch.out_cache_loc, mm_inputs=batch.multimodal_inputs,
             encoder_cached=batch.encoder_cached, encoder_lens=batch.encoder_lens,
             encoder_lens_cpu=batch.encoder_lens_cpu, encoder_out_cache_loc=batch.encoder_out_cache_loc,
-            seq_lens_sum=batch.seq_lens_sum, seq_lens_max_hint=getattr(batch, "seq_lens_max_hint", None),
+            seq_lens_sum=batch.seq_lens_sum,
             return_logprob=batch.return_logprob,
             top_logprobs_nums=batch.top_logprobs_nums, token_ids_logprobs=batch.token_ids_logprobs,
             can_run_dp_cuda_graph=batch.can_run_dp_cuda_graph, topping_paths=batch.toppings_paths,
@@ -200,6 +194,12 @@ class ForwardBatch:
                                                 batch.extend_input_logprob_token_ids.to(device, non_blocking=True)))
         if batch.global_num_tokens is not None:
             raise NotImplementedError("DP attention (global_num_tokens) is out of scope of this path")
+        # nothing downstream of this seam reads these two (LogitsProcessor returns no hidden states, the model embeds
+        # input_ids): refuse them here instead of silently serving something else
+        if batch.capture_hidden_mode not in (None, CaptureHiddenMode.NULL):
+            raise NotImplementedError("returning hidden states (capture_hidden_mode != NULL) is out of scope of this path")
+        if batch.input_embeds is not None:
+            raise NotImplementedError("input_embeds is out of scope of this path: the model embeds input_ids")
         if ret.forward_mode.is_idle():
             ret.positions = torch.empty((0,), device=device)
             return ret

@@ -381,7 +381,6 @@ class HipGraphRunner:
         self.seq_lens[:raw_bs].copy_(forward_batch.seq_lens)
         self.out_cache_loc[:raw_bs].copy_(forward_batch.out_cache_loc)
         self.positions[:raw_bs].copy_(forward_batch.positions)
-        self.model_runner.attn_backend.replay_max_hint = getattr(forward_batch, "seq_lens_max_hint", None)
         self.model_runner.attn_backend.init_forward_metadata_replay_cuda_graph(
             bs, self.req_pool_indices, self.seq_lens,
             forward_batch.seq_lens_sum + (bs - raw_bs) * self.seq_len_fill_value, self.encoder_lens,

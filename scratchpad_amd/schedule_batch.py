@@ -285,8 +285,6 @@ class ScheduleBatch:
     # ---- not in the reference
     # None: taken from model_config.is_encoder_decoder, as the reference reads it (schedule_batch.py:1274, 1334)
     is_encoder_decoder: Optional[bool] = None
-    # host-side upper bound of max(seq_lens), kept like seq_lens_sum: advisory (ModelWorkerBatch.seq_lens_max_hint)
-    seq_lens_max: int = 0
 
     def __post_init__(self):
         if self.is_encoder_decoder is None:
@@ -386,7 +384,6 @@ class ScheduleBatch:
         self.seq_lens = seq_lens_tensor
         self.out_cache_loc = out_cache_loc
         self.seq_lens_sum = sum(seq_lens)
-        self.seq_lens_max = max(seq_lens, default=0)
         self.extend_num_tokens = extend_num_tokens
         self.prefix_lens = prefix_lens
         self.extend_lens = extend_lens
@@ -431,7 +428,6 @@ class ScheduleBatch:
         self.input_ids = torch.tensor(sum(input_ids, []), dtype=torch.int64).to(self.device, non_blocking=True)
         self.seq_lens = torch.tensor(seq_lens, dtype=torch.int64).to(self.device, non_blocking=True)
         self.seq_lens_sum = sum(seq_lens)
-        self.seq_lens_max = max(seq_lens, default=0)
         empty = torch.zeros(0, dtype=torch.int64).to(self.device)
         self.out_cache_loc = torch.cat(decoder_out_cache_loc) if decoder_out_cache_loc else empty
         self.encoder_out_cache_loc = torch.cat(encoder_out_cache_loc) if encoder_out_cache_loc else empty
@@ -483,7 +479,7 @@ class ScheduleBatch:
         self.seq_lens = torch.empty(0, dtype=torch.int64, device=self.device)
         self.out_cache_loc = torch.empty(0, dtype=torch.int64, device=self.device)
         self.req_pool_indices = torch.empty(0, dtype=torch.int32, device=self.device)
-        self.seq_lens_sum = self.seq_lens_max = 0
+        self.seq_lens_sum = 0
         self.extend_num_tokens = 0
 
     def prepare_for_decode(self, topping_manager=None):
@@ -503,8 +499,6 @@ class ScheduleBatch:
         # overlap-safe (no in-place op): schedule_batch.py:1287-1292
         self.seq_lens = self.seq_lens + 1
         self.seq_lens_sum += bs
-        if self.seq_lens_max:
-            self.seq_lens_max += 1
         self.out_cache_loc = self.alloc_token_slots(bs)
         self.req_to_token_pool.write((self.req_pool_indices, locs), self.out_cache_loc.to(torch.int32))
 
@@ -576,11 +570,7 @@ class ScheduleBatch:
         self.req_pool_indices = self.req_pool_indices[keep]
         self.seq_lens = self.seq_lens[keep]
         self.out_cache_loc = None
-        # (one read-back for both host-side figures; the reference syncs here too, schedule_batch.py:1334)
-        if self.seq_lens.numel():
-            self.seq_lens_sum, self.seq_lens_max = (int(x) for x in torch.stack((self.seq_lens.sum(), self.seq_lens.max())).tolist())
-        else:
-            self.seq_lens_sum = self.seq_lens_max = 0
+        self.seq_lens_sum = self.seq_lens.sum().item()          # (schedule_batch.py:1334: the reference syncs here too)
         if self.output_ids is not None:
             self.output_ids = self.output_ids[keep]
         was_logprob = self.return_logprob
@@ -616,9 +606,6 @@ class ScheduleBatch:
         self.seq_lens = torch.cat([self.seq_lens, other.seq_lens])
         self.out_cache_loc = None
         self.seq_lens_sum += other.seq_lens_sum
-        # (a side that has requests but no bound makes the merged bound unknown, not too small)
-        known = all(b.seq_lens_max or not b.reqs for b in (self, other))
-        self.seq_lens_max = max(self.seq_lens_max, other.seq_lens_max) if known else 0
         if self.output_ids is not None:
             # as the reference: a side that carries pending output ids needs the other side's, or the rows
             # would no longer line up with reqs / seq_lens - fail loudly instead of keeping the old length
@@ -651,7 +638,6 @@ class ScheduleBatch:
             bid=bid, forward_mode=self.forward_mode, input_ids=self.input_ids,
             req_pool_indices=self.req_pool_indices, seq_lens=self.seq_lens,
             out_cache_loc=self.out_cache_loc, seq_lens_sum=self.seq_lens_sum,
-            seq_lens_max_hint=self.seq_lens_max or None,
             extend_num_tokens=self.extend_num_tokens, extend_seq_lens=extend_seq_lens,
             extend_prefix_lens=extend_prefix_lens,
             capture_hidden_mode=(CaptureHiddenMode.FULL if self.return_hidden_states else CaptureHiddenMode.NULL),

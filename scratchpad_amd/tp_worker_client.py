@@ -38,6 +38,7 @@ class TpModelWorkerClient:
         self.forward_stream = torch.cuda.Stream(device=self.device)
         self.scheduler_stream = torch.cuda.current_stream(self.device)
         self.error: Optional[BaseException] = None
+        self.step = 0                  # steps enqueued so far: tags a step's decode plans (HipAttnBackend.plan_step)
         self.forward_thread = threading.Thread(target=self.forward_thread_func, daemon=True)
         self.forward_thread.start()
 
@@ -64,7 +65,7 @@ class TpModelWorkerClient:
                 self.forward_thread_func_()
         except BaseException as e:  # the reference SIGQUITs its parent (110-116); we surface it
             self.error = e
-            self.output_queue.put((None, None, None))
+            self.output_queue.put((None, None, None, None))
 
     @torch.inference_mode()
     def forward_thread_func_(self):
@@ -73,34 +74,41 @@ class TpModelWorkerClient:
         batch's placeholders, and hand the results back without waiting for the GPU."""
         import collections
         in_flight = collections.deque(maxlen=2)      # the GPU may still be reading the previous batch's tensors
-        for batch, first_slot in iter(self.input_queue.get, (None, None)):
+        for batch, first_slot, step in iter(self.input_queue.get, (None, None, None)):
             in_flight.append(batch)
-            self.output_queue.put(self._run_one(batch, first_slot))
+            self.output_queue.put(self._run_one(batch, first_slot, step))
 
-    def _run_one(self, batch: ModelWorkerBatch, first_slot: int):
+    def _run_one(self, batch: ModelWorkerBatch, first_slot: int, step: int):
         resolve_future_token_ids(batch.input_ids, self.future_token_ids_map)
+        # the step's decode plans are tagged with it and checked by the scheduler's thread when THIS step is resolved;
+        # the forward thread itself never raises a plan overflow (it may already be running step N + 1 when step N's
+        # header lands: raising here ended the thread and step N's ids went out unreported - ADVICE r5)
+        backend = getattr(self.model_runner, "attn_backend", None)
+        if hasattr(backend, "plan_step"):
+            backend.plan_step = step
         logits_output, ids = self.worker.forward_batch_generation(batch)
         n = len(batch.seq_lens)
         self.future_token_ids_map[first_slot + 1:first_slot + 1 + n] = ids       # placeholder -k reads map[k]
         host_ids = ids.to("cpu", non_blocking=True)
         done = torch.cuda.Event()
         done.record()                                 # after the D2H copy on forward_stream
-        return done, logits_output, host_ids
+        return done, logits_output, host_ids, step
 
     def resolve_last_batch_result(self, launch_done: Optional[threading.Event] = None):
         """tp_worker_client.py:170-190: wait for the previous batch's results (one step later)."""
-        copy_done, logits_output, next_token_ids = self.output_queue.get()
+        copy_done, logits_output, next_token_ids, step = self.output_queue.get()
         if copy_done is None:
             raise RuntimeError("forward thread failed") from self.error
         if launch_done is not None:
             launch_done.wait()
         copy_done.synchronize()
         # the step's split-plan headers were copied out ahead of its forward on the same stream: they have landed.  A
-        # plan that was cut short (the scheduler understated seq_lens_sum) raises HERE, before this step's token ids
-        # are handed out - not one step later (VERDICT r4, weak 7)
+        # plan that was cut short (the scheduler understated seq_lens_sum) raises HERE, in the scheduler's thread, before
+        # this step's token ids are handed out (VERDICT r4, weak 7) - exactly this step's plans: the forward thread may
+        # already have built step N + 1's, which are reported with step N + 1 (ADVICE r5)
         backend = getattr(self.model_runner, "attn_backend", None)
         if hasattr(backend, "check_plans"):
-            backend.check_plans(wait=False)
+            backend.check_plans(wait=True, upto=step)
         return logits_output, next_token_ids.tolist()
 
     def forward_batch_generation(self, model_worker_batch: ModelWorkerBatch):
@@ -110,7 +118,8 @@ class TpModelWorkerClient:
         # the scheduler's writes (req_to_token, allocator slices, input ids) must be visible to
         # the forward stream before it reads them (203-204)
         self.scheduler_stream.synchronize()
-        self.input_queue.put((model_worker_batch, self.future_token_ids_ct))
+        self.step += 1
+        self.input_queue.put((model_worker_batch, self.future_token_ids_ct, self.step))
         bs = len(model_worker_batch.seq_lens)
         future_next_token_ids = torch.arange(-(self.future_token_ids_ct + 1),
                                              -(self.future_token_ids_ct + 1 + bs), -1,
@@ -119,5 +128,8 @@ class TpModelWorkerClient:
         return None, future_next_token_ids
 
     def close(self):
-        self.input_queue.put((None, None))
+        self.input_queue.put((None, None, None))
         self.forward_thread.join(timeout=30)
+        backend = getattr(self.model_runner, "attn_backend", None)
+        if hasattr(backend, "plan_step"):
+            backend.plan_step = None          # the runner's later (non-overlapped) steps check their plans themselves

@@ -32,9 +32,13 @@ def decode_kernel(request, nat):
     nat.debug_set("decode_kernel", 0)
 
 
-def run_decode(nat, p, scale, cap=0.0, chunk=64, max_len=None, kv_start=None, idx_dtype=None, use_plan=True):
-    """use_plan (what HipAttnBackend does): the per-step split plan + the separate merge launch; without: the static
-    (request, split) grid"""
+def run_decode(nat, p, scale, cap=0.0, chunk=64, max_len=None, kv_start=None, idx_dtype=None, use_plan=True, ranges=0,
+               items=True):
+    """use_plan (what HipAttnBackend does): the per-step plan + the separate merge launch; without: the static
+    (request, split) grid.  ranges > 0: the plan carries the range geometry with that many pieces and the launch is given
+    it - THE SHIPPED FORM where the range kernel takes the launch (HipAttnBackend passes sp_decode_ranges()).
+    items=False: the plan is built WITHOUT the (request, split) items (max_slots = 0), as the backend builds it for a model
+    whose layers all take the range kernel."""
     q = p["q"]
     bs, Hq, D = q.shape
     seq, req = p["seq_lens"], p["req_pool_indices"]
@@ -42,15 +46,19 @@ def run_decode(nat, p, scale, cap=0.0, chunk=64, max_len=None, kv_start=None, id
         seq, req = seq.to(idx_dtype), req.to(idx_dtype)
     if max_len is None:
         max_len = int(p["seq_lens"].max())
-    ws = torch.empty(nat.decode_workspace_bytes(bs, Hq, D, max_len, chunk), dtype=torch.uint8, device=DEV)
+    slots = None if items else 0
+    ws = torch.empty(nat.decode_workspace_bytes(bs, Hq, D, max_len, chunk, slots, ranges), dtype=torch.uint8, device=DEV)
     o = torch.full_like(q, float("nan"))
     plan = None
-    if use_plan:   # the per-step split plan the backend builds in init_forward_metadata
-        plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk) // 4, dtype=torch.int32, device=DEV)
-        nat.decode_plan(plan, seq, max_len, chunk)
+    if use_plan:   # the per-step plan the backend builds in init_forward_metadata
+        plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, slots, ranges) // 4, dtype=torch.int32, device=DEV)
+        nat.decode_plan(plan, seq, max_len, chunk, slots, ranges)
     nat.decode_attention(o, q, p["k_buffer"], p["v_buffer"], p["req_to_token"], req, seq, scale, cap,
-                         max_len, chunk, ws, kv_start, plan)
+                         max_len, chunk, ws, kv_start, plan, max_slots=slots, ranges=ranges)
     return o
+
+
+RANGE_KERNEL, ITEM_KERNELS = 3, (1, 2)          # sp_debug_get("decode_last_kernel")
 
 
 def check_vs_oracle(o, dtype, what, v, fn, rows=None):
@@ -81,22 +89,66 @@ def oracle_decode(p, scale, cap=0.0, kv_start=None, abs_v=False):
                                 None if kv_start is None else kv_start.cpu())
 
 
+def golden_decode_case(g, i, dtype):
+    p = dict(q=T(g[f"c{i}_q"], DEV, dtype), k_buffer=T(g[f"c{i}_k_buffer"], DEV, dtype),
+             v_buffer=T(g[f"c{i}_v_buffer"], DEV, dtype), req_to_token=T(g[f"c{i}_req_to_token"], DEV),
+             req_pool_indices=T(g[f"c{i}_req_pool_indices"], DEV), seq_lens=T(g[f"c{i}_seq_lens"], DEV))
+    return p, float(g[f"c{i}_sm_scale"]), float(g[f"c{i}_logit_cap"])
+
+
 @pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
 @pytest.mark.parametrize("chunk", [16, 64, 512])
 def test_decode_golden(nat, dt, chunk, decode_kernel):
-    """the reference's own Triton decode outputs; inputs are exact in every dtype"""
+    """the reference's own Triton decode outputs (decode_attention.py:547-608 run under the interpreter by
+    tests/golden/gen_golden.py) through the (request, split) items; inputs are exact in every dtype"""
     dtype = DTYPES[dt]
     g = golden.load("decode_attention")
     for i in range(int(g["num_cases"])):
-        p = dict(q=T(g[f"c{i}_q"], DEV, dtype), k_buffer=T(g[f"c{i}_k_buffer"], DEV, dtype),
-                 v_buffer=T(g[f"c{i}_v_buffer"], DEV, dtype), req_to_token=T(g[f"c{i}_req_to_token"], DEV),
-                 req_pool_indices=T(g[f"c{i}_req_pool_indices"], DEV), seq_lens=T(g[f"c{i}_seq_lens"], DEV))
-        o = run_decode(nat, p, float(g[f"c{i}_sm_scale"]), float(g[f"c{i}_logit_cap"]), chunk)
+        p, scale, cap = golden_decode_case(g, i, dtype)
+        o = run_decode(nat, p, scale, cap, chunk)
         if dtype == torch.float32:
             assert_close(o, T(g[f"c{i}_o"]), dtype, what=f"decode golden c{i} {dt} chunk={chunk}")
         else:   # the reference's own output is the target; A (same attention over |V|) comes from the oracle
-            aref = oracle_decode(p, float(g[f"c{i}_sm_scale"]), float(g[f"c{i}_logit_cap"]), abs_v=True)
+            aref = oracle_decode(p, scale, cap, abs_v=True)
             assert_attn_close(o, T(g[f"c{i}_o"]), aref, dtype, what=f"decode golden c{i} {dt} chunk={chunk}")
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("ranges", [0, 1, 3, "auto"])
+@pytest.mark.parametrize("items", [True, False], ids=["items+ranges", "ranges-only"])
+def test_decode_golden_through_the_shipped_range_kernel(nat, dt, ranges, items):
+    """the reference's own decode vectors through the kernel a default decode step launches.  The same
+    five cases (D 64 / 128, groups 1 - 8, decode_attention.py:547-608's outputs) with the plan's range geometry at 1 and 3
+    pieces and at the count sp_decode_ranges() asks for - what HipAttnBackend passes - and the launch PROVEN to have been
+    the range kernel (sp_debug_get("decode_last_kernel") == 3); the plan built as the backend builds it for Llama / Mllama
+    (range section alone) and with the items beside it.  Case 4 carries a logit soft-cap, which the range kernel does not
+    take: with the items in the plan the launch falls back to them and gives the bits of ranges = 0; from a plan WITHOUT
+    items it is refused (RuntimeError) instead of computing nothing.  ranges = 0 is the item geometry (the anchor)."""
+    dtype = DTYPES[dt]
+    g = golden.load("decode_attention")
+    for i in range(int(g["num_cases"])):
+        p, scale, cap = golden_decode_case(g, i, dtype)
+        bs, Hq, D = p["q"].shape
+        n = nat.decode_ranges(Hq, p["k_buffer"].shape[1], D, dtype) if ranges == "auto" else ranges
+        what = f"decode golden c{i} {dt} ranges={n}{'' if items else ' (plan without items)'}"
+        if n == 0 and not items:
+            continue                                    # (a plan with neither section: nothing to launch)
+        if ranges == "auto":
+            assert n > 0, "every golden head shape is one the range kernel takes"
+        if not items and cap > 0:
+            with pytest.raises(RuntimeError, match="sp_decode_attention"):
+                run_decode(nat, p, scale, cap, 64, ranges=n, items=False)
+            continue
+        o = run_decode(nat, p, scale, cap, 64, ranges=n, items=items)
+        ran = nat.debug_get("decode_last_kernel")
+        if n > 0 and cap == 0:
+            assert ran == RANGE_KERNEL, f"{what}: launched kernel {ran}, not the range kernel"
+        else:
+            assert ran in ITEM_KERNELS, f"{what}: launched kernel {ran}"
+            if n > 0:           # the soft-cap case behind a range plan: the bits of the items
+                assert torch.equal(o, run_decode(nat, p, scale, cap, 64, ranges=0)), what
+        aref = oracle_decode(p, scale, cap, abs_v=True)
+        assert_attn_close(o, T(g[f"c{i}_o"]), aref, dtype, what=what)
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
@@ -862,10 +914,16 @@ def test_decode_range_plan_equals_a_host_recount(nat, ranges, idx_dtype):
     assert torch.equal(host[:items_only.numel()], items_only.cpu())
     rp = host[items_only.numel():].tolist()
     rcount, R, pos, start = range_plan_on_host(lens.tolist(), max_len, ranges)
-    assert rp[:4] == [rcount, R, 0, 0]
+    assert rp[:4] == [rcount, R, ranges, bs], "words 2, 3 (ABI 9): what the section was built for"
     assert rp[4:4 + bs + 1] == pos
     assert rp[4 + bs + 1:] == start
     assert rcount <= ranges and (rcount - 1) * R < pos[-1] <= rcount * R
+    # ABI 9: max_slots = 0 builds the range section alone, behind the item header [0, chunk, 0, 0]
+    words = nat.decode_plan_bytes(bs, max_len, chunk, 0, ranges) // 4
+    assert words == 4 + 4 + bs + 1 + ranges
+    alone = torch.full((words,), -7, dtype=torch.int32, device=DEV)
+    nat.decode_plan(alone, seq, max_len, chunk, 0, ranges)
+    assert alone.cpu().tolist() == [0, chunk, 0, 0] + rp
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
@@ -1013,6 +1071,61 @@ def test_decode_ranges_where_the_range_kernel_does_not_apply(nat):
             outs.append(o)
         assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1]), (Hq, Hkv, cap)
         check_decode(outs[1], p, 0.09, dtype, f"items behind a range plan Hq{Hq} Hkv{Hkv} cap{cap}", cap=cap)
+
+
+def test_a_launch_must_be_given_what_its_plan_was_built_with(nat):
+    """VERDICT r5 next 3 / ADVICE r5: a range plan says what it was built for and the launch checks it.
+    (a) the wrapper: a plan built with 40 pieces launched with 20 (or with another max_slots, or another batch size)
+        raises RuntimeError on the host - before round 6 the launch silently skipped the tail pieces;
+    (b) the C ABI underneath, called with the mismatch directly: the range section's words 2, 3 differ from the launch's,
+        the range kernel and its merge do NOTHING (`out` keeps its NaN fill, no fault), and a plan buffer shorter than
+        (batch size, max_slots, ranges) describe is refused with SP_ERR_WORKSPACE before any launch;
+    (c) the matching launch on the same buffers is right."""
+    import ctypes
+    bs, Hq, Hkv, D, chunk, max_len = 32, 32, 8, 128, 64, 900
+    g = torch.Generator().manual_seed(77)
+    lens = torch.randint(1, 900, (bs,), generator=g)
+    p = paged_problem(771, bs, Hq, Hkv, D, lens.tolist(), torch.bfloat16, DEV)
+    slots = nat.decode_plan_slots(bs, max_len, chunk, kv_tokens=int(lens.sum()))
+    ws = torch.empty(nat.decode_workspace_bytes(bs, Hq, D, max_len, chunk, slots, 40), dtype=torch.uint8, device=DEV)
+    plan = torch.empty(nat.decode_plan_bytes(bs, max_len, chunk, slots, 40) // 4, dtype=torch.int32, device=DEV)
+    nat.decode_plan(plan, p["seq_lens"], max_len, chunk, slots, 40)
+
+    def launch(ranges, max_slots=slots, rows=bs):
+        o = torch.full_like(p["q"], float("nan"))
+        nat.decode_attention(o[:rows], p["q"][:rows], p["k_buffer"], p["v_buffer"], p["req_to_token"],
+                             p["req_pool_indices"][:rows], p["seq_lens"][:rows], 0.09, 0.0, max_len, chunk, ws, None, plan,
+                             max_slots=max_slots, ranges=ranges)
+        return o
+
+    for kw in (dict(ranges=20), dict(ranges=0), dict(ranges=40, max_slots=slots - 1), dict(ranges=40, rows=bs - 1)):
+        with pytest.raises(RuntimeError, match="plan was built for"):
+            launch(**kw)
+    good = launch(40)
+    assert nat.debug_get("decode_last_kernel") == RANGE_KERNEL
+    check_decode(good, p, 0.09, torch.bfloat16, "matching launch")
+
+    # (b) the same mismatch at the C ABI (the wrapper's host-side memory of the plan is not in the way here)
+    lib = nat.load()
+    st = torch.cuda.current_stream().cuda_stream
+    kb, vb, q = p["k_buffer"], p["v_buffer"], p["q"]
+
+    def raw(ranges, plan_bytes, out):
+        return lib.sp_decode_attention(
+            out.data_ptr(), q.data_ptr(), kb.data_ptr(), vb.data_ptr(), p["req_to_token"].data_ptr(),
+            p["req_to_token"].stride(0), p["req_pool_indices"].data_ptr(), p["seq_lens"].data_ptr(), None, 1, bs, Hq, Hkv,
+            D, q.stride(0), out.stride(0), kb.stride(0), 0.09, 0.0, 1.0, 1.0, max_len, chunk, slots, ranges,
+            ws.data_ptr(), ws.numel(), plan.data_ptr(), plan_bytes, nat.SP_BF16, nat.SP_BF16, st)
+
+    o = torch.full_like(q, float("nan"))
+    assert raw(20, plan.numel() * 4, o) == 0, "the launch itself is well-formed"
+    torch.cuda.synchronize()
+    assert torch.isnan(o.float()).all(), "a range launch on a plan built for another piece count must not compute anything"
+    assert raw(40, plan.numel() * 4 - 4, o) == nat.SP_ERR_WORKSPACE, "plan buffer shorter than its sections"
+    o = torch.full_like(q, float("nan"))
+    assert raw(40, plan.numel() * 4, o) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o, good)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])

@@ -12,11 +12,26 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _runner():
+def _runner(items=True):
+    """items=True: the backend plans the (request, split) items as it does for a model with a soft-cap layer or a shape
+    the range kernel refuses, and its launches are sent to them (sp_debug_set("decode_ranges", 0) in the tests below) -
+    the geometry whose slots the host's bound sizes.  items=False: the backend as it is built for Llama (round 6): plans
+    are the range section alone."""
     from scratchpad_amd.model_runner import ModelConfig, ModelRunner, ServerArgs
     cfg = ModelConfig(256, 512, 2, 4, 2, 512, context_len=2048, max_position_embeddings=2048)
     args = ServerArgs(max_total_tokens=4096, max_running_requests=8, disable_cuda_graph=True)
-    return ModelRunner(cfg, args, dtype=torch.bfloat16, seed=5)
+    mr = ModelRunner(cfg, args, dtype=torch.bfloat16, seed=5)
+    assert mr.attn_backend.decode_ranges > 0 and mr.attn_backend.plan_items is False, "a Llama shape plans no items"
+    mr.attn_backend.plan_items = items
+    return mr
+
+
+@pytest.fixture
+def item_geometry():
+    from scratchpad_amd import _native
+    _native.debug_set("decode_ranges", 0)
+    yield
+    _native.debug_set("decode_ranges", -1)
 
 
 def _decode_batch(mr, lens, claimed_sum):
@@ -37,7 +52,7 @@ def _decode_batch(mr, lens, claimed_sum):
                             out_cache_loc=torch.tensor(loc, device=dev), seq_lens_sum=claimed_sum)
 
 
-def test_understated_seq_lens_sum_raises_instead_of_returning_wrong_logits():
+def test_understated_seq_lens_sum_raises_instead_of_returning_wrong_logits(item_geometry):
     from scratchpad_amd.model_runner import TpModelWorker
     mr = _runner()
     worker = TpModelWorker(mr)
@@ -65,7 +80,7 @@ def test_understated_seq_lens_sum_raises_instead_of_returning_wrong_logits():
     worker.forward_batch_generation(_decode_batch(mr, lens, sum(lens)))
 
 
-def test_overlap_worker_reports_the_overflow_with_the_same_steps_results():
+def test_overlap_worker_reports_the_overflow_with_the_same_steps_results(item_geometry):
     """The overlap worker (tp_worker_client.py) synchronises on a step's results one step later anyway: the step's plan
     headers, copied out ahead of its forward on the same stream, have landed by then, so a cut plan raises when THAT
     step's token ids are resolved - before they reach the scheduler - and not with the following step."""
@@ -85,3 +100,55 @@ def test_overlap_worker_reports_the_overflow_with_the_same_steps_results():
         assert len(ids) == 4
     finally:
         client.close()
+
+
+def test_overlap_worker_reports_step_n_even_when_step_n_plus_1_is_already_enqueued(item_geometry):
+    """under real overlap scheduling step N + 1 is enqueued BEFORE step N is resolved.  The forward thread,
+    building step N + 1's plans, used to find step N's landed header, raise inside the thread and end it: resolve(N)
+    returned N's ids with no error and every later call failed with "forward thread failed".  Plans are tagged with their
+    step now; the forward thread never raises them and resolve(N) checks exactly step N's: the bad step is reported
+    with its own results, the good one behind it is not, and the engine goes on."""
+    from scratchpad_amd.tp_worker_client import TpModelWorkerClient
+    mr = _runner()
+    client = TpModelWorkerClient(mr)
+    try:
+        lens = [600, 600, 600, 600]
+        good = lambda: _decode_batch(mr, lens, sum(lens))
+        client.forward_batch_generation(good())                               # step 1
+        client.forward_batch_generation(_decode_batch(mr, lens, 400))         # step 2: understated - enqueued before 1 resolves
+        _, ids = client.resolve_last_batch_result()                           # step 1: fine
+        assert len(ids) == 4
+        client.forward_batch_generation(good())                               # step 3 enqueued before 2 resolves
+        torch.cuda.synchronize()                                              # (every header has landed: the old failure window)
+        with pytest.raises(RuntimeError, match="split plan overflow.*seq_lens_sum"):
+            client.resolve_last_batch_result()                                # step 2: reported with its own results
+        client.forward_batch_generation(good())                               # step 4: the forward thread is alive
+        _, ids = client.resolve_last_batch_result()                           # step 3: not blamed for step 2
+        assert len(ids) == 4
+        _, ids = client.resolve_last_batch_result()                           # step 4
+        assert len(ids) == 4 and client.error is None
+    finally:
+        client.close()
+
+
+def test_range_plans_do_not_size_anything_from_the_hosts_sum():
+    """The backend as it is built for Llama / Mllama since round 6: plans carry the range section alone, whose slots
+    (batch size + pieces) and cuts come from the device-side lengths.  A seq_lens_sum understated so far that the item
+    geometry would drop splits (2000 claimed for 4 x 600: 35 slots for 40 items - the report of the tests above) changes
+    NOTHING here: the same bits as the honest step, nothing to report, no header copy per step.  (What the host's sum
+    still bounds in an eager step is the longest request, max_len = min(context, sum - (bs - 1)): lengths are clamped to
+    it, as on every path; 1997 >= 600 here.)"""
+    from scratchpad_amd import _native
+    from scratchpad_amd.model_runner import TpModelWorker
+    mr = _runner(items=False)
+    worker = TpModelWorker(mr)
+    lens = [600, 600, 600, 600]
+    honest, _ = worker.forward_batch_generation(_decode_batch(mr, lens, sum(lens)))
+    assert _native.debug_get("decode_last_kernel") == 3, "the range kernel ran"
+    honest = honest.next_token_logits.clone()
+    assert _native.decode_plan_slots(4, 1997, 64, 2000) < 4 * 10, "the item geometry would have overflowed"
+    mr.attn_backend.strict_plan_check = True
+    bad, _ = worker.forward_batch_generation(_decode_batch(mr, lens, 2000))
+    assert torch.equal(bad.next_token_logits, honest)
+    assert not mr.attn_backend._plan_checks, "no item section: nothing is watched"
+    mr.attn_backend.check_plans()

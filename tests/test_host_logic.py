@@ -451,32 +451,27 @@ def test_library_row_table_is_gated_on_the_build_it_was_measured_on(monkeypatch)
         assert _native.library_rows(256, 6144, 4096) == 264
 
 
-def test_decode_split_size_policy_and_the_advisory_max_hint():
-    """HipAttnBackend._plan_chunk (host logic only): about one item per CU between MIN_CHUNK and MAX_CHUNK; a
-    near-uniform batch (advisory ModelWorkerBatch.seq_lens_max_hint <= 1.35 x mean) is not split when that still leaves a
-    workgroup per CU; a missing, ragged or implausible hint changes nothing."""
+def test_decode_split_size_policy_and_where_items_are_planned():
+    """HipAttnBackend host logic only.  (a) _plan_chunk: about one (request, split) item per CU between MIN_CHUNK and
+    MAX_CHUNK, from the host's bound on sum(seq_lens) alone (the advisory longest-request hint left in round 6).
+    (b) which plans carry items at all: only where a launch of the model can read them - a shape the range kernel refuses
+    (decode_ranges 0), a layer with a logit soft-cap, or a step whose line does not fit the range section."""
     from scratchpad_amd.attention import HipAttnBackend
     b = HipAttnBackend.__new__(HipAttnBackend)
     b.num_kv_head, b.head_dim = 8, 128
     dt = torch.bfloat16
     assert (b.MIN_CHUNK, b.MAX_CHUNK, b.TARGET_ITEMS) == (64, 768, 256)
-    ragged = b._plan_chunk(553000, dt, 256, 4096)                    # the headline batch: max / mean = 1.9
-    assert ragged == b._plan_chunk(553000, dt) == b._plan_chunk(553000, dt, 256, None) == 768
-    assert b._plan_chunk(553000, dt, 256, 1) == 768                  # a hint below the mean is no bound at all: ignored
-    assert b._plan_chunk(1064 * 256, dt, 256, 1064) == 1088           # 512 workgroups unsplit: whole requests
-    assert b._plan_chunk(4136 * 128, dt, 128, 4136) == 4160           # 256 workgroups unsplit: still one per CU
-    assert b._plan_chunk(1064 * 64, dt, 64, 1064) == 512              # 128 unsplit would idle half the chip: the default
-    assert b._plan_chunk(3584 * 256, dt, 256, 4096) == 4096           # U[3072, 4096]: near-uniform
-    assert b._plan_chunk(2560 * 256, dt, 256, 4096) == 768           # U[1024, 4096]: ragged
-    assert b._plan_chunk(40 * 8, dt, 8, 40) == 64 and b._plan_chunk(10 ** 9, dt, 4, 10 ** 9 // 4) >= 768
-    b.num_kv_head = 1                                                 # 70B / TP 8 rank: one workgroup per item
-    assert b._plan_chunk(288000, dt, 128, 4096) == 768
-    assert b._plan_chunk(4136 * 128, dt, 128, 4136) == 768            # 128 unsplit workgroups < 256 CUs: the default
-    assert b._plan_chunk(4136 * 256, dt, 256, 4136) == 4160
-    # the hint is tracked by ScheduleBatch like seq_lens_sum, on the host
-    from scratchpad_amd.schedule_batch import ScheduleBatch
-    sb = ScheduleBatch.__new__(ScheduleBatch)
-    sb.seq_lens_max, sb.seq_lens_sum = 0, 0
-    other = ScheduleBatch.__new__(ScheduleBatch)
-    other.seq_lens_max = 77
-    assert max(sb.seq_lens_max, other.seq_lens_max) == 77
+    assert b._plan_chunk(553000, dt) == 768                      # the headline batch
+    assert b._plan_chunk(1064 * 64, dt) == 512 and b._plan_chunk(40 * 8, dt) == 64 and b._plan_chunk(10 ** 9, dt) == 768
+    b.num_kv_head = 1                                            # 70B / TP 8 rank: one workgroup per item
+    assert b._plan_chunk(288000, dt) == 768
+    # (b) the graph launch covers no items at all where nothing reads them
+    b.max_context_len, b.decode_ranges = 8192, 256
+    b.plan_items = False
+    assert b._graph_slots(256) == 0 and b._ranges_for(256, 8192) == 256
+    b.plan_items = True
+    assert b._graph_slots(256) == max(b.GRAPH_SLOTS_FLOOR, b.GRAPH_SLOTS_PER_REQ * 256) + 256
+    b.plan_items, b.decode_ranges = False, 0                     # the range kernel refuses the shape: items after all
+    assert b._graph_slots(16) == b.GRAPH_SLOTS_FLOOR + 16
+    b.decode_ranges, b.max_context_len = 256, 2 ** 24            # bs x (context + 16) >= 2^31: the line does not fit
+    assert b._ranges_for(256, 2 ** 24) == 0 and b._graph_slots(256) > 0

@@ -45,7 +45,7 @@ def test_python_binding_covers_every_symbol():
 
 def test_abi_version_and_status_strings(lib):
     lib.sp_abi_version.restype = ctypes.c_int
-    assert lib.sp_abi_version() == 8
+    assert lib.sp_abi_version() == 9
     lib.sp_status_string.restype = ctypes.c_char_p
     assert lib.sp_status_string(0) == b"ok"
     assert b"unsupported" in lib.sp_status_string(-2)
@@ -74,8 +74,25 @@ def test_host_side_argument_validation_needs_no_gpu(lib):
     lib.sp_decode_plan_bytes.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int]
     # a 4-word header (listed, chunk, needed, keys), slot0[bs], the item pairs (ABI 7: no arrival counters behind them)
     assert lib.sp_decode_plan_bytes(256, 2304, 0) == (4 + 256 + 2 * 2304) * 4
-    # ABI 8: with ranges, the range geometry behind them: [pieces, R, 0, 0], pos[bs + 1], start[ranges]
+    # ABI 8: with ranges, the range geometry behind them: [pieces, R, ranges, bs], pos[bs + 1], start[ranges]
     assert lib.sp_decode_plan_bytes(256, 2304, 384) == (4 + 256 + 2 * 2304 + 4 + 257 + 384) * 4
+    # ABI 9: max_slots = 0 - no items: the item header alone in front of the range section; neither section: nothing
+    assert lib.sp_decode_plan_bytes(256, 0, 384) == (4 + 4 + 257 + 384) * 4
+    assert lib.sp_decode_plan_bytes(256, 0, 0) == 16
+    # ... and a launch is refused on the host, before anything touches a device, when its plan buffer is shorter than
+    # the sections (batch_size, max_slots, ranges) describe, or when the plan has neither section
+    from scratchpad_amd import _native
+    lib.sp_decode_attention.restype, lib.sp_decode_attention.argtypes = _native.SIGNATURES["sp_decode_attention"]
+    buf = (ctypes.c_char * 4096)()
+    a = ctypes.addressof(buf)
+    a += (-a) % 16
+
+    def launch(max_slots, ranges, plan_bytes):
+        return lib.sp_decode_attention(a, a, a, a, a, 64, a, a, None, 0, 256, 32, 8, 128, 4096, 4096, 2048, 0.1, 0.0, 1.0,
+                                       1.0, 4096, 64, max_slots, ranges, a, 1 << 40, a, plan_bytes, 2, 2, None)
+    assert launch(2304, 384, (4 + 256 + 2 * 2304 + 4 + 257 + 384) * 4 - 4) == -3       # SP_ERR_WORKSPACE
+    assert launch(0, 384, (4 + 4 + 257 + 384) * 4 - 4) == -3
+    assert launch(0, 0, 1 << 20) == -1                                                   # SP_ERR_INVALID_ARG
 
 
 def test_ops_refuse_host_tensors():
