@@ -15,7 +15,22 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def test_graph_scratch_is_bounded_and_a_100k_token_decode_step_matches_the_oracle():
+@pytest.mark.parametrize("geometry", ["ranges", "items"])
+def test_graph_scratch_is_bounded_and_a_100k_token_decode_step_matches_the_oracle(geometry):
+    """geometry "ranges": the backend as it is built for a Llama shape (round 6) - plans are the range section alone, the
+    scratch is batch size + pieces slots.  "items": the backend planning the (request, split) items too, as it does for a
+    model with a soft-cap layer, and the launches sent to them (sp_debug_set("decode_ranges", 0)): the geometry whose
+    split size grows with the step so that its items fit the captured launch."""
+    from scratchpad_amd import _native
+    if geometry == "items":
+        _native.debug_set("decode_ranges", 0)
+    try:
+        _long_context_step(geometry)
+    finally:
+        _native.debug_set("decode_ranges", -1)
+
+
+def _long_context_step(geometry):
     from scratchpad_amd import _native
     from scratchpad_amd.forward_info import ForwardMode, ModelWorkerBatch
     from scratchpad_amd.model_runner import ModelConfig, ModelRunner, ServerArgs, TpModelWorker
@@ -27,15 +42,20 @@ def test_graph_scratch_is_bounded_and_a_100k_token_decode_step_matches_the_oracl
     pool = sum(lens) + 4 * BS + 64
     args = ServerArgs(max_total_tokens=pool, max_running_requests=256)       # default bucket list, up to bs 256
     mr = ModelRunner(cfg, args, dtype=torch.float16, seed=3)
-    mr.init_cuda_graphs()
     backend = mr.attn_backend
+    assert backend.plan_items is False and backend.decode_ranges > 0
+    backend.plan_items = geometry == "items"
+    mr.init_cuda_graphs()
     scratch = backend.graph_scratch_bytes()
     # what the same slot budget costs with Llama-3-8B's 32 query heads of 128 (the figure DESIGN.md quotes)
     slots = backend._graph_slots(256)
-    scratch_8b = _native.decode_workspace_bytes(256, 32, 128, CTX, 64, slots) + 3 * _native.decode_plan_bytes(256, CTX, 64, slots)
+    assert (slots == 0) == (geometry == "ranges")
+    r8b = _native.decode_ranges(32, 8, 128, torch.bfloat16) if geometry == "ranges" else 0
+    scratch_8b = (_native.decode_workspace_bytes(256, 32, 128, CTX, 64, slots, r8b)
+                  + 3 * _native.decode_plan_bytes(256, CTX, 64, slots, r8b))
     static_8b = _native.decode_workspace_bytes(256, 32, 128, CTX, 512)       # round 2: bs x ceil(ctx / 512) splits
-    print(f"graph attention scratch at context_len {CTX}: {scratch / 2**20:.1f} MiB for this model, "
-          f"{scratch_8b / 2**20:.1f} MiB at Llama-3-8B head counts ({slots} slots); the bs-256 bucket alone under "
+    print(f"graph attention scratch at context_len {CTX} ({geometry}): {scratch / 2**20:.1f} MiB for this model, "
+          f"{scratch_8b / 2**20:.1f} MiB at Llama-3-8B head counts ({slots or 256 + r8b} slots); the bs-256 bucket alone under "
           f"the round-2 static geometry: {static_8b / 2**20:.0f} MiB")
     assert scratch < 1.5e9 and scratch_8b < 1.5e9 and scratch_8b * 20 < static_8b
     assert len(mr.graph_runner.capture_bs) >= 30 and max(mr.graph_runner.capture_bs) == 256
@@ -65,8 +85,16 @@ def test_graph_scratch_is_bounded_and_a_100k_token_decode_step_matches_the_oracl
     got = out.next_token_logits.float().cpu()
     plan = backend.forward_metadata[3][0][0].cpu()
     chunk_used, items = int(plan[1]), int(plan[0])
-    assert items == sum(-(-int(s) // chunk_used) for s in seq) <= backend._graph_slots(8)
-    assert chunk_used >= 512, "the split size grew with the step's sum(seq_lens) instead of the slot count"
+    if geometry == "items":
+        assert _native.debug_get("decode_last_kernel") == 2          # (the launches the graphs captured)
+        assert items == sum(-(-int(s) // chunk_used) for s in seq) <= backend._graph_slots(8)
+        assert chunk_used >= 512, "the split size grew with the step's sum(seq_lens) instead of the slot count"
+    else:       # [0, chunk, 0, 0 | pieces in use, R, ranges, bs | ...]: every piece of the line in use, ~800 k positions cut evenly
+        assert _native.debug_get("decode_last_kernel") == 3 and items == 0
+        pieces, R, ranges, bs_built = plan[4:8].tolist()
+        line = int(seq.sum()) + 16 * BS
+        assert (ranges, bs_built) == (backend._graph_ranges, BS)
+        assert R == -(-line // ranges) and pieces == -(-line // R)
     mr.graph_runner = None
     out_e, _ = worker.forward_batch_generation(batch)                # the same step, eager launches
     eager = out_e.next_token_logits.float().cpu()
