@@ -7,6 +7,7 @@ signalled, managers/tp_worker_client.py:110-116).  Tensors are passed as raw dev
 """
 import ctypes
 import os
+import weakref
 from typing import Optional
 
 import torch
@@ -397,9 +398,20 @@ def decode_plan_bytes(bs: int, max_seq_len: int, chunk: int, max_slots: Optional
 # located from these three numbers and a launch has to be given the same ones (include/scratchpad_hip.h, "Plan and launch
 # must agree"): the range kernel would do nothing on a mismatch and the item kernels would read another section's words,
 # so decode_attention() compares them here, on the host, and raises before anything is launched.  Buffers that were not
-# built through decode_plan() (a copy made by hand) are not known and not checked.
-_BUILT_PLANS: dict = {}
+# built through decode_plan() (a copy made by hand) are not known and not checked; an entry whose tensor has died is stale
+# (the allocator may have handed its address to something else) and is dropped, not trusted.
+_BUILT_PLANS: dict = {}            # data_ptr -> (weakref to the plan tensor, (bs, max_slots, ranges))
 _BUILT_PLANS_MAX = 4096
+
+
+def _built_with(plan: torch.Tensor):
+    entry = _BUILT_PLANS.get(plan.data_ptr())
+    if entry is None:
+        return None
+    if entry[0]() is None:
+        del _BUILT_PLANS[plan.data_ptr()]
+        return None
+    return entry[1]
 
 
 def decode_plan(plan: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int, chunk: int,
@@ -423,7 +435,7 @@ def decode_plan(plan: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int, ch
     _BUILT_PLANS.pop(key, None)
     if len(_BUILT_PLANS) >= _BUILT_PLANS_MAX:
         del _BUILT_PLANS[next(iter(_BUILT_PLANS))]
-    _BUILT_PLANS[key] = (bs, max_slots, int(ranges))
+    _BUILT_PLANS[key] = (weakref.ref(plan), (bs, max_slots, int(ranges)))
 
 
 def decode_plan_overflow(header, max_slots: int) -> Optional[str]:
@@ -464,7 +476,7 @@ def decode_attention(out: torch.Tensor, q: torch.Tensor, k_buffer: torch.Tensor,
     plan_bytes = 0
     if plan is not None:
         plan_bytes = plan.numel() * 4
-        built = _BUILT_PLANS.get(plan.data_ptr())
+        built = _built_with(plan)
         if built is not None and built != (bs, max_slots, int(ranges)):
             raise RuntimeError(
                 f"decode_attention: the plan was built for (batch size, max_slots, ranges) = {built} and the launch is "

@@ -475,3 +475,21 @@ def test_decode_split_size_policy_and_where_items_are_planned():
     assert b._graph_slots(16) == b.GRAPH_SLOTS_FLOOR + 16
     b.decode_ranges, b.max_context_len = 256, 2 ** 24            # bs x (context + 16) >= 2^31: the line does not fit
     assert b._ranges_for(256, 2 ** 24) == 0 and b._graph_slots(256) > 0
+
+
+def test_plan_registry_trusts_only_live_plan_buffers():
+    """_native remembers what each decode plan buffer was built with (data_ptr -> (bs, max_slots, ranges)) so that a launch
+    given other values raises on the host (ABI 9).  A view of the buffer is the same plan; an entry whose tensor has died is
+    dropped - the allocator may have handed the address to a buffer that was never built through decode_plan()."""
+    import weakref
+    from scratchpad_amd import _native
+    t = torch.zeros(16, dtype=torch.int32)
+    key = t.data_ptr()
+    _native._BUILT_PLANS[key] = (weakref.ref(t), (4, 0, 256))
+    assert _native._built_with(t) == (4, 0, 256) and _native._built_with(t[:8]) == (4, 0, 256)
+
+    class SameAddress:                      # whatever the allocator puts at that address next
+        def data_ptr(self):
+            return key
+    del t
+    assert _native._built_with(SameAddress()) is None and key not in _native._BUILT_PLANS

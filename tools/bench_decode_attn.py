@@ -37,6 +37,9 @@ def main():
                     help="work items the launch covers (graph replay covers max(1024, 8 bs) + bs; default: what the step needs)")
     ap.add_argument("--gemm", action="store_true", help="interleave a bf16 GEMM between launches (as in a model)")
     ap.add_argument("--ranges", type=int, default=-1, help="pieces of the range geometry (-1: sp_decode_ranges(), 0: none)")
+    ap.add_argument("--items", action="store_true",
+                    help="build the (request, split) item section beside the range section (until round 6 every plan carried it; "
+                         "HipAttnBackend now builds it only for models with a launch that reads it)")
     a = ap.parse_args()
     if a.lib:
         _native._LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scratchpad_amd", "lib", a.lib)
@@ -86,6 +89,8 @@ def main():
     print(f"range geometry: {ranges} pieces" if ranges else "(request, split) items", flush=True)
     for chunk in [int(c) for c in a.chunks.split(",")]:
         slots = a.slots or None
+        if ranges > 0 and not a.items and not a.slots:
+            slots = 0                                    # the range section alone, as the backend builds it for a Llama shape
         ws = torch.empty(_native.decode_workspace_bytes(a.bs, a.Hq, a.D, max_len, chunk, slots, ranges), dtype=torch.uint8, device=dev)
         plan = None
         if not a.no_plan:
