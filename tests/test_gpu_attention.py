@@ -655,6 +655,60 @@ def test_backend_sliding_window_layers_decode_and_extend():
     assert_close(oe, ref, dtype, what="windowed extend layer")
 
 
+def test_backend_plans_items_only_for_a_model_with_a_soft_cap_layer(nat):
+    """HipAttnBackend.plan_items (round 6): a model whose layers all take the range kernel gets plans without the
+    (request, split) items; ONE layer with a logit soft-cap (Gemma-2 style) makes the backend plan them too - that layer's
+    launches run the items, its neighbours stay on the range kernel, both against the oracle - and a backend told there are
+    no items refuses the capped launch instead of computing nothing."""
+    from types import SimpleNamespace
+    from scratchpad_amd.attention import HipAttnBackend, RadixAttention
+    from scratchpad_amd.forward_info import ForwardMode
+    dtype = torch.bfloat16
+    Hq, Hkv, D = 8, 2, 128
+    seq = [5, 380, 39, 900, 120, 1]
+    bs = len(seq)
+    p = paged_problem(61, bs, Hq, Hkv, D, seq, dtype, DEV, scale=2.0)
+    pool = SimpleNamespace(dtype=dtype, get_value_buffer=lambda l: p["v_buffer"],
+                           get_kv_buffer=lambda l: (p["k_buffer"], p["v_buffer"]))
+    cfg = SimpleNamespace(num_attention_heads=Hq, head_dim=D, context_len=1024, get_num_kv_heads=lambda tp: Hkv)
+    plain = RadixAttention(Hq, D, D ** -0.5, Hkv, layer_id=0)
+    capped = RadixAttention(Hq, D, D ** -0.5, Hkv, layer_id=1, logit_cap=20.0)
+    fb = SimpleNamespace(forward_mode=ForwardMode.DECODE, batch_size=bs, seq_lens=p["seq_lens"], seq_lens_cpu=None,
+                         seq_lens_sum=sum(seq), encoder_lens=None, encoder_lens_cpu=None,
+                         req_pool_indices=p["req_pool_indices"], token_to_kv_pool=pool,
+                         req_to_token_pool=SimpleNamespace(req_to_token=p["req_to_token"]), out_cache_loc=None)
+    q = p["q"].reshape(bs, -1)
+
+    def backend(layers):
+        model = torch.nn.Module()
+        model.layers = torch.nn.ModuleList(layers)
+        return HipAttnBackend(SimpleNamespace(model_config=cfg, tp_size=1, token_to_kv_pool=pool, device=DEV,
+                                              dtype=dtype, model=model))
+
+    be = backend([plain])
+    assert be.decode_ranges > 0 and be.plan_items is False
+    be.init_forward_metadata(fb)
+    plan, slots, _, ranges = be.forward_metadata[3][0]
+    assert slots == 0 and ranges == be.decode_ranges and plan[:4].tolist()[0] == 0, "the range section alone"
+    o = be.forward_decode(q, None, None, plain, fb, save_kv_cache=False).view(bs, Hq, D)
+    assert nat.debug_get("decode_last_kernel") == RANGE_KERNEL
+    check_decode(o, p, D ** -0.5, dtype, "plain layer, plan without items")
+    with pytest.raises(RuntimeError, match="sp_decode_attention"):
+        be.forward_decode(q, None, None, capped, fb, save_kv_cache=False)       # no items were planned for it
+
+    be = backend([plain, capped])
+    assert be.plan_items is True
+    be.init_forward_metadata(fb)
+    assert be.forward_metadata[3][0][1] > 0, "the items are planned beside the ranges"
+    o = be.forward_decode(q, None, None, plain, fb, save_kv_cache=False).view(bs, Hq, D)
+    assert nat.debug_get("decode_last_kernel") == RANGE_KERNEL, "the plain layer keeps the range kernel"
+    check_decode(o, p, D ** -0.5, dtype, "plain layer beside a capped one")
+    oc = be.forward_decode(q, None, None, capped, fb, save_kv_cache=False).view(bs, Hq, D)
+    assert nat.debug_get("decode_last_kernel") in ITEM_KERNELS
+    check_decode(oc, p, D ** -0.5, dtype, "capped layer on the items", cap=20.0)
+    be.check_plans()
+
+
 def test_random_shapes_decode_and_extend_against_oracle(nat):
     """40 seeded random problems: head layout, head size, dtype, batch, ragged lengths (including
     empty prefixes, single keys, lengths straddling chunk/tile edges), soft cap, kv_start offsets,

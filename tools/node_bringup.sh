@@ -17,7 +17,16 @@
 set -o pipefail
 export HSA_ENABLE_IPC_MODE_LEGACY=0          # dmabuf IPC: RCCL and the direct all-reduce need it on this image
 REHEARSAL=0
-[ "$1" = "--rehearsal" ] && REHEARSAL=1
+ONLY=""                                      # --only 0,1 / --only 2,3,4,5: a subset of the steps (a 20-minute box runs the rehearsal in two calls)
+while [ $# -gt 0 ]; do
+  case "$1" in
+    --rehearsal) REHEARSAL=1 ;;
+    --only) ONLY=",$2,"; shift ;;
+    *) echo "usage: $0 [--rehearsal] [--only STEP[,STEP...]]"; exit 2 ;;
+  esac
+  shift
+done
+want() { [ -z "$ONLY" ] || case "$ONLY" in *",$1,"*) return 0 ;; *) return 1 ;; esac; }
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
 OUT=gpurun_out/bringup
@@ -54,17 +63,21 @@ RH=""
 fits() { [ $REHEARSAL -eq 1 ] && [ "$1" -le 4 ] && return 0; [ $REHEARSAL -eq 0 ] && [ "$1" -le "$NDEV" ]; }
 
 # ---- step 0: the single-device suite's attention + plan tests (is this box's one-device path what the rounds measured?)
+if want 0; then
 run 00_single_device_tests 900 python -m pytest tests/test_gpu_attention.py tests/test_gpu_plan_overflow.py -x -q -m gpu ||
   { echo "the one-device path is broken on this box: nothing below would mean anything"; printf '%s\n' "${SUMMARY[@]}"; exit $FAILED; }
+fi
 
 # ---- step 1: the tensor-parallel tests.  On the node the 21 one-device-per-rank cases (world 2 / 4 / 8: RCCL and the
 # direct all-reduce; prefill, eager decode, graph decode with the collectives inside the graph; Llama-3-70B's 64 / 8 heads
 # over 8 ranks) RUN instead of being skipped: expected "N passed, 0 skipped" with >= 8 devices.  Under --rehearsal they
 # stay skipped and the shared-device twins of the same flows run (expected "... passed, 21 skipped").
 # If this fails: stop - the bench lines below exercise the same collectives with less to look at.
+if want 1; then
 run 01_tensor_parallel_tests 1500 python -m pytest tests/test_gpu_tensor_parallel.py -x -q -m gpu -rs ||
   { echo "tensor-parallel tests failed: fix before benchmarking"; printf '%s\n' "${SUMMARY[@]}"; exit $FAILED; }
 grep -h "passed\|skipped" $OUT/01_tensor_parallel_tests.log | tail -1
+fi
 
 # ---- step 2: the headline config as N independent replicas (config 2 does not shard: weak scaling, no data-path
 # collective, the ranks meet at the timing barriers).  Expected per N: one JSON line, "n_gpus": N, "scaling": "weak",
@@ -72,6 +85,7 @@ grep -h "passed\|skipped" $OUT/01_tensor_parallel_tests.log | tail -1
 # RCCL all-reduce over all replicas: they can talk over xGMI), "rccl_note": null.
 # The driver computes efficiency itself from the per-N values; this script prints the lines and nothing derived from them.
 for N in 1 2 4 8; do
+  want 2 || continue
   fits $N || { SUMMARY+=("02_replicas_$N: skipped (needs $N devices)"); continue; }
   EXTRA=""
   [ $REHEARSAL -eq 1 ] && EXTRA="--layers 4 --steps 4 --warmup 1 --no-cpu-baseline --no-ttft"
@@ -84,17 +98,24 @@ done
 # "devices_seen": 8, "allreduce_us_per_call", "allreduces_per_step": 161, eager / graph ms per step, tokens/s of the group.
 # If RCCL fails here but step 1 passed: look at "rccl_note" in the step-2 lines (communicator creation) first.
 TP=8
-[ $REHEARSAL -eq 1 ] && TP=2
-if fits $TP; then
+VIA=rccl
+[ $REHEARSAL -eq 1 ] && TP=2 && VIA=gloo_standin      # (RCCL refuses two ranks on one device: the rehearsal's collectives go over gloo)
+if ! want 3; then
+  SUMMARY+=("03..05: not selected")
+elif fits $TP; then
   EXTRA=""
   [ $REHEARSAL -eq 1 ] && EXTRA="--layers 8 --steps 8 --warmup 2"
-  run 03_tp${TP}_rccl 1200 python bench.py --mode tp --gpus $TP --tp $TP --model llama3-70b $RH $EXTRA && line 03_tp${TP}_rccl
+  run 03_tp${TP}_${VIA} 1200 python bench.py --mode tp --gpus $TP --tp $TP --model llama3-70b $RH $EXTRA && line 03_tp${TP}_${VIA}
   RCCL_OK=$?
   # ---- step 4: the same with the direct IPC all-reduce (csrc/allreduce.hip: peers' buffers mapped by IPC handle, system-scope
   # flags over xGMI - unproven across devices, hence opt-in).  Only meaningful once step 3 gave a line to compare with:
   # expected config.all_reduce "direct IPC kernel (SP_CUSTOM_ALLREDUCE=1)" and "allreduce_us_per_call" to set against step
   # 3's (bit-identical sums on every rank are what step 1's tests assert).  A hang here ends at
   # SP_CUSTOM_ALLREDUCE_TIMEOUT_S (collective, fatal, reported by every rank).
+  # (Under --rehearsal "graph_ms_per_step" of this step is seconds, not milliseconds: two processes time-sliced on ONE device,
+  # each replaying a graph whose all-reduce kernels spin on the other's flags, wait out whole time slices.  It says nothing
+  # about a node, where every rank's kernels are resident on their own device; the eager figure is the one to read there too
+  # until the graph one has been seen.)
   if [ $RCCL_OK -eq 0 ]; then
     SP_CUSTOM_ALLREDUCE=1 SP_CUSTOM_ALLREDUCE_TIMEOUT_S=20 run 04_tp${TP}_direct 1200 python bench.py --mode tp --gpus $TP --tp $TP --model llama3-70b $RH $EXTRA && line 04_tp${TP}_direct
     DIRECT_OK=$?
@@ -110,7 +131,7 @@ if fits $TP; then
     SUMMARY+=("04_tp${TP}_direct: skipped (no RCCL line to compare with)" "05_tp${TP}_direct_fused: skipped")
   fi
 else
-  SUMMARY+=("03_tp${TP}_rccl: skipped (needs $TP devices)")
+  SUMMARY+=("03_tp${TP}_${VIA}: skipped (needs $TP devices)")
 fi
 
 echo
