@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--bs", type=int, default=256)
     ap.add_argument("--out", default="")
+    ap.add_argument("--pieces", default="", help="comma-separated piece counts for the attention launches (default: one and two "
+                                                 "workgroups per CU = sp_decode_ranges() / 2 and sp_decode_ranges())")
     a = ap.parse_args()
     L = a.layers
     torch.manual_seed(0)
@@ -162,6 +164,8 @@ def main():
     rows_all, rows_a, rows_b = list(range(a.bs)), list(range(half)), list(range(half, a.bs))
     auto = _native.decode_ranges(HQ, HKV, D, DT)                      # two workgroups per CU
     side = torch.cuda.Stream()
+    wg = lambda r: f"{r * HKV / 4 / 256:g}wg"                          # workgroups per CU of a launch of r pieces (MI355X: 256 CUs)
+    variants = [(wg(int(r)), int(r)) for r in a.pieces.split(",")] if a.pieces else [("1wg", auto // 2), ("2wg", auto)]
     res = {"layers": L, "reps": a.reps, "bs": a.bs, "tokens": total, "ranges_2wg": auto, "ranges_1wg": auto // 2,
            "device": torch.cuda.get_device_name(0), "library_rows": {}}
     print(f"{res['device']}: {a.bs} requests, {total} context tokens, {L} layers cycled, "
@@ -173,7 +177,7 @@ def main():
     res["stage_a"] = {"t_gemm_us": t_gemm, "gemm_weight_GB": proj_half.weight_bytes / 1e9,
                       "gemm_TBps": proj_half.weight_bytes / t_gemm / 1e6}
     print(f"stage A  projections alone, M = {half}: {t_gemm:7.1f} us / layer  ({proj_half.weight_bytes / t_gemm / 1e6:.2f} TB/s of weights)", flush=True)
-    for name, ranges in (("1wg", auto // 2), ("2wg", auto)):
+    for name, ranges in variants:
         att = Attention(arenas, r2t, ctx, rows_a, ranges)
         t_attn = time_graph(capture(chain([lambda l=l: att(l) for l in range(L)])), a.reps, L)
         both = capture(two_chains([lambda l=l: att(l) for l in range(L)], [lambda l=l: proj_half(l) for l in range(L)]), side)
@@ -181,7 +185,7 @@ def main():
         ratio = t_both / (t_attn + t_gemm)
         res["stage_a"][name] = {"ranges": ranges, "t_attn_us": t_attn, "attn_TBps": att.alg_bytes / t_attn / 1e6,
                                 "t_both_us": t_both, "ratio_to_sum": ratio, "gate_0.80": ratio <= 0.80}
-        print(f"stage A  attention alone, {half} requests, {ranges} pieces ({name[0]} workgroup(s) per CU): {t_attn:7.1f} us / layer "
+        print(f"stage A  attention alone, {half} requests, {ranges} pieces ({name[:-2]} workgroup(s) per CU): {t_attn:7.1f} us / layer "
               f"({att.alg_bytes / t_attn / 1e6:.2f} TB/s);  both on two streams: {t_both:7.1f} us = {ratio:.3f} x the sum "
               f"-> gate (<= 0.80) {'PASSES' if ratio <= 0.80 else 'FAILS'}", flush=True)
 
@@ -194,7 +198,7 @@ def main():
     t_full = time_graph(capture(chain(work)), a.reps, L)
     res["full_us"] = t_full
     print(f"full     one stream, attention({a.bs}) + projections(M = {a.bs}): {t_full:7.1f} us / layer", flush=True)
-    for name, ranges in (("1wg", auto // 2), ("2wg", auto)):
+    for name, ranges in variants:
         att_a, att_b = Attention(arenas, r2t, ctx, rows_a, ranges), Attention(arenas, r2t, ctx, rows_b, ranges)
         proj_b = Projections(weights, half)
         serial, wa, wb = [], [], []
