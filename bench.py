@@ -564,7 +564,10 @@ def serve_main(args, rank, local_rank, world):
         running = None
         first_t, last_t, itl = [None] * n_req, [None] * n_req, []
         reserved = 0            # output tokens promised to running requests but not yet allocated
-        steps = {"extend": 0, "decode": 0, "hit_tokens": 0}
+        # device_s: wall time between handing a batch to the worker and its token ids reaching the host - the only spans in
+        # which the GPU has work; the rest of the trace's duration is the scheduler side alone (admission, prefix cache,
+        # prepare_for_*, result bookkeeping) with the GPU idle: what an overlapped event loop could hide
+        steps = {"extend": 0, "decode": 0, "hit_tokens": 0, "device_s": 0.0}
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         now = lambda: time.perf_counter() - t0
@@ -589,9 +592,12 @@ def serve_main(args, rank, local_rank, world):
                 nb.prepare_for_extend()
                 if args.sample:
                     nb.sampling_info = SamplingBatchInfo.from_schedule_batch(nb, cfg.vocab_size)
-                _, ids = worker.forward_batch_generation(nb.get_model_worker_batch())
+                mwb = nb.get_model_worker_batch()
+                t_dev = now()
+                _, ids = worker.forward_batch_generation(mwb)
                 toks = ids.tolist()                     # first tokens reach the host
                 t = now()
+                steps["device_s"] += t - t_dev
                 for i, tok in zip(admit, toks):
                     reqs[i].output_ids.append(tok)
                     first_t[i] = last_t[i] = t
@@ -620,9 +626,12 @@ def serve_main(args, rank, local_rank, world):
             if not running.check_decode_mem():
                 raise RuntimeError("serve trace: KV pool exhausted despite the admission reserve")
             running.prepare_for_decode()
-            _, ids = worker.forward_batch_generation(running.get_model_worker_batch())
+            mwb = running.get_model_worker_batch()
+            t_dev = now()
+            _, ids = worker.forward_batch_generation(mwb)
             toks = ids.tolist()
             t = now()
+            steps["device_s"] += t - t_dev
             running.output_ids = ids
             steps["decode"] += 1
             any_done = False
@@ -669,6 +678,9 @@ def serve_main(args, rank, local_rank, world):
                       "input_tokens": total_in, "output_tokens": total_out, "extend_steps": steps["extend"],
                       "decode_steps": steps["decode"], "prefix_cache_hit_tokens": steps["hit_tokens"]},
            "duration_s": round(dur, 3), "total_tokens_per_sec": round((total_in + total_out) / dur, 1),
+           # the scheduler side alone, GPU idle (this loop is synchronous: no overlap worker in it)
+           "scheduler_only_s": round(dur - steps["device_s"], 3),
+           "scheduler_only_frac": round((dur - steps["device_s"]) / dur, 4),
            "ttft_ms": {"p50": round(pct(ttft, 0.5), 1), "p99": round(pct(ttft, 0.99), 1),
                        "mean": round(sum(ttft) / len(ttft) * 1e3, 1)},
            "tpot_ms": {"p50": round(pct(tpot, 0.5), 2), "p99": round(pct(tpot, 0.99), 2),
