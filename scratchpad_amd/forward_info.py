@@ -195,7 +195,8 @@ class ForwardBatch:
         if batch.global_num_tokens is not None:
             raise NotImplementedError("DP attention (global_num_tokens) is out of scope of this path")
         # nothing downstream of this seam reads these two (LogitsProcessor returns no hidden states, the model embeds
-        # input_ids): refuse them here instead of silently serving something else
+        # input_ids - the reference's own ModelRunner.forward_extend, model_runner.py:516-529, never hands input_embeds to
+        # the model either): refuse them here instead of silently serving something else
         if batch.capture_hidden_mode not in (None, CaptureHiddenMode.NULL):
             raise NotImplementedError("returning hidden states (capture_hidden_mode != NULL) is out of scope of this path")
         if batch.input_embeds is not None:

@@ -493,3 +493,23 @@ def test_plan_registry_trusts_only_live_plan_buffers():
             return key
     del t
     assert _native._built_with(SameAddress()) is None and key not in _native._BUILT_PLANS
+
+
+def test_forward_batch_refuses_what_nothing_behind_it_reads():
+    """ScheduleBatch.get_model_worker_batch forwards return_hidden_states (as CaptureHiddenMode.FULL) and
+    input_embeds like the reference; nothing behind ForwardBatch.init_new reads either, so it raises instead of serving such
+    a request as an ordinary one (the DP-attention refusal beside them was already there)."""
+    from types import SimpleNamespace
+    from scratchpad_amd.forward_info import CaptureHiddenMode, ForwardBatch, ForwardMode, ModelWorkerBatch
+    runner = SimpleNamespace(device="cpu", req_to_token_pool=None, token_to_kv_pool=None, attn_backend=None)
+
+    def batch(**kw):
+        return ModelWorkerBatch(bid=0, forward_mode=ForwardMode.DECODE, input_ids=torch.zeros(2, dtype=torch.int64),
+                                req_pool_indices=torch.zeros(2, dtype=torch.int64), seq_lens=torch.ones(2, dtype=torch.int64),
+                                out_cache_loc=torch.zeros(2, dtype=torch.int64), seq_lens_sum=2, **kw)
+    with pytest.raises(NotImplementedError, match="hidden states"):
+        ForwardBatch.init_new(batch(capture_hidden_mode=CaptureHiddenMode.FULL), runner)
+    with pytest.raises(NotImplementedError, match="input_embeds"):
+        ForwardBatch.init_new(batch(input_embeds=torch.zeros(2, 8)), runner)
+    with pytest.raises(NotImplementedError, match="DP attention"):
+        ForwardBatch.init_new(batch(global_num_tokens=[2]), runner)
