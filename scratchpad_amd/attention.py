@@ -500,6 +500,11 @@ class HipAttnBackend(AttentionBackend):
         seq_lens, kv_start = self._kv_window(layer, forward_batch)
         entry = plans[2] if self._is_windowed(layer) else (plans[1] if layer.is_cross_attention else plans[0])
         plan, slots, chunk, ranges = entry if entry is not None else (None, None, chunk, 0)
+        if plan is not None and slots == 0 and layer.logit_cap > 0:
+            # (the library would refuse the launch anyway - SP_ERR_INVALID_ARG - this says why)
+            raise RuntimeError(f"layer {layer.layer_id} carries a logit soft-cap, which the range kernel does not take, but this "
+                               "backend plans no (request, split) items: it found no such layer in model_runner.model when "
+                               "it was constructed (HipAttnBackend.plan_items) - construct it after the model")
         kb, vb = forward_batch.token_to_kv_pool.get_kv_buffer(layer.layer_id)
         _native.decode_attention(
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim),

@@ -693,7 +693,7 @@ def test_backend_plans_items_only_for_a_model_with_a_soft_cap_layer(nat):
     o = be.forward_decode(q, None, None, plain, fb, save_kv_cache=False).view(bs, Hq, D)
     assert nat.debug_get("decode_last_kernel") == RANGE_KERNEL
     check_decode(o, p, D ** -0.5, dtype, "plain layer, plan without items")
-    with pytest.raises(RuntimeError, match="sp_decode_attention"):
+    with pytest.raises(RuntimeError, match="plans no .request, split. items"):
         be.forward_decode(q, None, None, capped, fb, save_kv_cache=False)       # no items were planned for it
 
     be = backend([plain, capped])
